@@ -1,0 +1,36 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """Outputs of the reference itself (oracle/gen_golden.py ran it in the build container)."""
+    with open(os.path.join(GOLDEN, "reference_cases.json")) as f:
+        manifest = json.load(f)
+    arrays = dict(np.load(os.path.join(GOLDEN, "reference_cases.npz")))
+    return manifest, arrays
+
+
+def case_matrices(case, arrays):
+    """Rebuild the input matrices of a golden dense case (oracle generator or matrix.txt data)."""
+    from oracle import davidson_oracle as O
+    if case["matrix"] == "matrix_txt":
+        return arrays["matrix_txt__A"], None
+    A = O.generate_diagonal_dominant(case["n"], case["sparsity"], seed=case["seed_a"])
+    B = None
+    if case["gev"]:
+        B = O.generate_diagonal_dominant(case["n"], case["sparsity"], 1.0, seed=case["seed_b"])
+    return A, B
