@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py - Davidson iterations/s + achieved A*V HBM GB/s vs roofline (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete `generalized_eigensolver` solve (Fortran driver loop on the HIP engine) of
+the workload BASELINE.json quotes the metric on that fits one GPU: configs[1] = N=20000 dense fp64,
+lowest=8, DPR, tol=1e-8, generate_diagonal_dominant(N, 1e-3) - the matrix is generated in HBM before
+the timed region and stays resident.  value = Davidson iterations per second over the K timed solves.
+N > 1: the same problem row-partitioned over the ranks (strong scaling), new-basis block exchanged with
+an RCCL all-gather inside libdavidson_hip.so; torch.distributed (gloo) is only the control plane
+(unique-id broadcast, barriers, max-over-ranks of the time).
+
+Extra objects in the JSON line: `roofline` (dominant kernel = dense block matvec, HIP-event timed on
+the engine's stream inside the timed region), `cpu_baseline` (the reference itself, oracle/_ref, on
+the host cores in a child process), `apply_k8` (the north-star microbenchmark: A*V at k=8) and
+`large` (one solve of a larger resident matrix, to show how the sharded path scales).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--lowest", type=int, default=8)
+    ap.add_argument("--sparsity", type=float, default=1e-3)
+    ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--large-n", type=int, default=80000, help="order of the extra large-matrix solve (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=0, help="order for the CPU baseline (0 = same as --n)")
+    return ap.parse_args()
+
+
+CPU_CHILD = r"""
+import ctypes, json, os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+n, lowest, sparsity, tol = {n}, {lowest}, {sparsity}, {tol}
+import fortran_davidson_amd as fd            # host-side generator only (no GPU call)
+A = fd.generate_diagonal_dominant(n, sparsity, None, 1)
+from oracle import ref, davidson_oracle as O
+out = dict(n=n)
+if ref.available():
+    try:
+        mkl = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so")
+        threads = int(mkl.mkl_get_max_threads())
+    except Exception:
+        threads = os.cpu_count()
+    t = time.perf_counter(); lam, vec, it = ref.dense_solve(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
+    out.update(kind="reference", iters=int(it), seconds=dt, cores=threads, evals=[float(x) for x in lam])
+else:
+    t = time.perf_counter(); lam, vec, it = O.generalized_eigensolver_dense(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
+    out.update(kind="port", iters=int(it), seconds=dt, cores=os.cpu_count(), evals=[float(x) for x in lam])
+print("CPU_BASELINE " + json.dumps(out))
+"""
+
+
+def cpu_baseline(n, lowest, sparsity, tol):
+    """The reference's own CPU+LAPACK path (oracle/_ref = the reference compiled with flang + MKL) on
+    the same generate_diagonal_dominant input, timed in a child process that never touches the GPU
+    (and never imports torch, whose libgomp breaks threaded MKL)."""
+    code = CPU_CHILD.format(root=ROOT, n=n, lowest=lowest, sparsity=sparsity, tol=tol)
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    try:
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        for line in res.stdout.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        return {"error": (res.stderr or res.stdout)[-400:]}
+    except Exception as exc:       # noqa: BLE001
+        return {"error": repr(exc)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    import fortran_davidson_amd as fd
+
+    def make_engine(n, lowest):
+        eng = fd.DavidsonEngine(n, lowest, None, gev=False, device=local_rank, rank=rank, nranks=world)
+        if world > 1:
+            ident = [fd.CEngine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            eng.comm_init(ident[0])
+        return eng
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- the timed workload: configs[1] -----------------------------------------------------------
+    n, lowest = args.n, args.lowest
+    eng = make_engine(n, lowest)
+    eng.generate_diagonal_dominant(1, args.sparsity, seed=1)       # resident in HBM before timing
+    for _ in range(args.warmup):
+        lam, _, iters = eng.solve("DPR", 1000, args.tol, want_vectors=False)
+    eng.c.synchronize()
+    eng.c.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    total_iters = 0
+    for _ in range(args.steps):
+        lam, _, iters = eng.solve("DPR", 1000, args.tol, want_vectors=False)
+        total_iters += iters
+    eng.c.synchronize()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    st = eng.c.stats()
+    value = total_iters / elapsed
+
+    # roofline of the dominant kernel over the timed region (HIP events on the engine's stream)
+    ach = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "matvec_dense_kernel<NT> (A*V block matvec, full storage)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "traffic": None, "launches": int(st.applies), "avg_launch_ms": round(st.apply_ms / max(st.applies, 1), 4),
+                "algorithmic_bytes_per_launch": round(st.apply_bytes / max(st.applies, 1), 0),
+                "note": "per-rank; bytes = 8*nloc*N + 16*N*k per launch (SURVEY 8d)"}
+    phase = {"apply_ms": round(st.apply_ms / args.steps, 4), "gram_ms": round(st.gram_ms / args.steps, 4),
+             "panel_ms": round(st.panel_ms / args.steps, 4), "comm_ms": round(st.comm_ms / args.steps, 4)}
+
+    # north-star microbenchmark: A*V at k=8 (and 16, 32) on the resident matrix
+    apply_k = {}
+    for k in (8, 16, 32):
+        ms, nbytes = eng.c.bench_apply(k, 20)
+        apply_k[f"k{k}"] = {"ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                            "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    eng.close()
+
+    # ---- a larger resident matrix (same code path) ------------------------------------------------
+    large = None
+    if args.large_n > 0:
+        try:
+            big = make_engine(args.large_n, lowest)
+            big.generate_diagonal_dominant(1, args.sparsity, seed=1)
+            big.solve("DPR", 1000, args.tol, want_vectors=False)
+            big.c.synchronize(); big.c.reset_stats(); barrier()
+            t1 = time.perf_counter()
+            reps = 3
+            it_big = 0
+            for _ in range(reps):
+                _, _, it = big.solve("DPR", 1000, args.tol, want_vectors=False)
+                it_big += it
+            big.c.synchronize(); barrier()
+            dt = max_over_ranks(time.perf_counter() - t1)
+            sb = big.c.stats()
+            ms8, b8 = big.c.bench_apply(8, 10)
+            large = {"workload": f"N={args.large_n} dense fp64 full storage, lowest={lowest}, DPR, row-partitioned over {world} GPU(s)",
+                     "iterations_per_s": round(it_big / dt, 2), "iters_per_solve": it_big // reps,
+                     "apply_GBps_per_rank": round(sb.apply_bytes / (sb.apply_ms * 1e-3) / 1e9, 1),
+                     "apply_k8_GBps_per_rank": round(b8 / (ms8 * 1e-3) / 1e9, 1)}
+            big.close()
+        except Exception as exc:       # noqa: BLE001
+            large = {"error": repr(exc)[:300]}
+
+    # ---- CPU baseline: rank 0, N=1 only -----------------------------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cn = args.cpu_n or n
+        raw = cpu_baseline(cn, lowest, args.sparsity, args.tol)
+        if "seconds" in raw:
+            cpu = {"value": round(raw["iters"] / raw["seconds"], 4), "unit": "Davidson iterations/s", "cores": raw["cores"],
+                   "kind": raw["kind"], "seconds": round(raw["seconds"], 3), "iters": raw["iters"],
+                   "sample": f"one full solve of the same workload (N={cn}, lowest={lowest}, DPR, tol={args.tol}) by the "
+                             "reference built with flang+MKL (oracle/_ref), all host threads",
+                   "max_abs_eigenvalue_diff_vs_gpu": float(np.abs(np.array(raw["evals"]) - lam).max()) if cn == n else None}
+        else:
+            cpu = raw
+
+    if rank == 0:
+        line = {"metric": "Davidson iterations/sec (dense DPR solve, matrix resident in HBM) + A*V HBM GB/s vs roofline",
+                "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"N={n} dense fp64 full storage, lowest={lowest}, DPR, tol={args.tol}, "
+                                       f"generate_diagonal_dominant(N,{args.sparsity}) seed 1, max_dim={10 * lowest}",
+                           "N": n, "lowest": lowest, "iters_per_solve": total_iters // args.steps,
+                           "basis_widths": "2L,4L,8L", "parallelism": f"row-slab x{world}"},
+                "eigenvalues": [float(x) for x in lam[:3]],
+                "roofline": roofline, "phase_ms_per_step": phase, "apply": apply_k, "large": large, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

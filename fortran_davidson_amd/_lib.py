@@ -1,0 +1,51 @@
+"""Locating, building and loading the native libraries.  Fails loudly when they are missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HIP_LIB = os.path.join(LIB_DIR, "libdavidson_hip.so")
+FORTRAN_LIB = os.path.join(LIB_DIR, "libfortran_davidson_amd.so")
+
+_hip = None
+_fortran = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> None:
+    """Compile every HIP kernel for gfx950 (hipcc cross-compiles without a GPU) and the Fortran host."""
+    res = subprocess.run(["make", "-C", _HERE, "-j4"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise RuntimeError("building fortran_davidson_amd failed")
+
+
+def hip_lib() -> C.CDLL:
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise NativeLibraryMissing(f"{HIP_LIB} not built: run `make -C fortran_davidson_amd` "
+                                       "(there is no CPU fallback)")
+        _hip = C.CDLL(HIP_LIB, mode=C.RTLD_LOCAL)
+        _hip.dav_last_error.restype = C.c_char_p
+    return _hip
+
+
+def fortran_lib() -> C.CDLL:
+    global _fortran
+    if _fortran is None:
+        hip_lib()
+        if not os.path.exists(FORTRAN_LIB):
+            raise NativeLibraryMissing(f"{FORTRAN_LIB} not built: run `make -C fortran_davidson_amd`")
+        _fortran = C.CDLL(FORTRAN_LIB, mode=C.RTLD_GLOBAL)  # MKL dlopens its kernels and needs libmkl_core global
+        _fortran.fd_engine_create.restype = C.c_void_p
+        _fortran.fd_engine_handle.restype = C.c_void_p
+    return _fortran

@@ -1,0 +1,819 @@
+// Engine + C ABI (include/davidson_hip.h).  Owns every N-long object in HBM and sequences the kernels
+// of k_*.hip on one HIP stream; the host (Fortran driver) keeps only m x m matrices.
+#include "../../include/davidson_hip.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string& msg) {
+  g_err = msg;
+  return 1;
+}
+#define HIPCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" +      \
+                  std::to_string(__LINE__) + ")");                                                    \
+  } while (0)
+#define CHK(call)            \
+  do {                       \
+    int r_ = (call);         \
+    if (r_ != 0) return r_;  \
+  } while (0)
+
+// ---- RCCL, loaded lazily so that single-GPU use never touches it ------------------------------------
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return fail(std::string("cannot load librccl.so: ") + dlerror());
+#define SYM(field, name)                                              \
+  *(void**)(&g_rccl.field) = dlsym(lib, name);                        \
+  if (!g_rccl.field) return fail(std::string("librccl.so lacks ") + name);
+  SYM(GetUniqueId, "ncclGetUniqueId")
+  SYM(CommInitRank, "ncclCommInitRank")
+  SYM(CommDestroy, "ncclCommDestroy")
+  SYM(AllGather, "ncclAllGather")
+  SYM(AllReduce, "ncclAllReduce")
+  SYM(Broadcast, "ncclBroadcast")
+  SYM(GroupStart, "ncclGroupStart")
+  SYM(GroupEnd, "ncclGroupEnd")
+  SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  g_rccl.lib = lib;
+  return 0;
+}
+#define NCCLCHK(call)                                                                              \
+  do {                                                                                             \
+    ncclResult_t r_ = (call);                                                                      \
+    if (r_ != ncclSuccess) return fail(std::string(#call) + " failed: " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+struct OpDesc {
+  int kind = DAV_KIND_NONE;
+  double* a = nullptr;       // dense: nloc_pad x ncols_pad, column-major, lda = nloc_pad
+  uint64_t seed = 0;
+  double sparsity = 0;
+  int use_diag = 0;
+  double diag_val = 0;
+  int trig = 0;
+  double* e_table = nullptr; // device
+  double* diag = nullptr;    // device, nloc_pad (local rows)
+};
+
+struct SmallBuf {            // device small matrix + pinned staging
+  double* dev = nullptr;
+  double* host = nullptr;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
+constexpr int N_SMALL = 4;
+constexpr int N_EVPAIRS = 64;
+
+struct dav_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t n = 0, nslab = 0, nloc = 0, row0 = 0, nloc_pad = 0, ncols_pad = 0;
+  int rank = 0, nranks = 1, gev = 0;
+  int max_cols = 0, cols_alloc = 0;
+  int m = 0;
+  double* panel[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t ldp = 0;
+  double* xt = nullptr;
+  int64_t xt_group_stride = 0;
+  double* scratch = nullptr;
+  size_t scratch_doubles = 0;
+  double* gram_dev = nullptr;     // result of gram / norms on device
+  double* gram_host = nullptr;    // pinned
+  size_t gram_doubles = 0;
+  double* gather_dev = nullptr;   // nranks*nslab staging for panel_get / diagonal gather
+  int64_t* idx_dev = nullptr;
+  double* norm_partial = nullptr;
+  SmallBuf sm[N_SMALL];
+  size_t small_doubles = 0;
+  ncclComm_t comm = nullptr;
+  OpDesc op[2];
+  std::vector<double> diag_host[2];
+  // statistics
+  dav_stats st{};
+  hipEvent_t ev[N_EVPAIRS][2];
+  double ev_bytes[N_EVPAIRS];
+  int ev_kind[N_EVPAIRS];
+  int ev_used = 0;
+};
+typedef dav_engine E;
+
+static inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+static int bind(E* e) { HIPCHK(hipSetDevice(e->device)); return 0; }
+
+static int collect_events(E* e) {
+  for (int i = 0; i < e->ev_used; ++i) {
+    HIPCHK(hipEventSynchronize(e->ev[i][1]));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[i][0], e->ev[i][1]));
+    if (e->ev_kind[i] == 0) {
+      e->st.apply_ms += ms;
+      e->st.apply_bytes += e->ev_bytes[i];
+      e->st.last_apply_ms = ms;
+      e->st.last_apply_bytes = e->ev_bytes[i];
+    } else if (e->ev_kind[i] == 1) {
+      e->st.gram_ms += ms;
+    } else if (e->ev_kind[i] == 2) {
+      e->st.panel_ms += ms;
+    } else {
+      e->st.comm_ms += ms;
+    }
+  }
+  e->ev_used = 0;
+  return 0;
+}
+struct Timed {   // RAII-less helper: begin/end record an event pair on the stream
+  E* e; int slot;
+};
+static int timed_begin(E* e, int kind, double bytes, int* slot) {
+  if (e->ev_used == N_EVPAIRS) CHK(collect_events(e));
+  *slot = e->ev_used++;
+  e->ev_kind[*slot] = kind;
+  e->ev_bytes[*slot] = bytes;
+  HIPCHK(hipEventRecord(e->ev[*slot][0], e->stream));
+  return 0;
+}
+static int timed_end(E* e, int slot) {
+  HIPCHK(hipEventRecord(e->ev[slot][1], e->stream));
+  return 0;
+}
+
+// upload a p x q host matrix (ld) into small buffer i, zero padded to (pad4(p)) x (pad64(q)); returns ldm
+static int small_upload(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* ldm_out) {
+  SmallBuf& b = e->sm[i];
+  int64_t ldm = roundup(std::max(p, 1), 4), qp = roundup(std::max(q, 1), 64);
+  if ((size_t)(ldm * qp) > e->small_doubles) return fail("small matrix exceeds engine capacity");
+  if (b.pending) {
+    HIPCHK(hipEventSynchronize(b.done));
+    b.pending = false;
+  }
+  std::memset(b.host, 0, sizeof(double) * ldm * qp);
+  for (int j = 0; j < q; ++j) std::memcpy(b.host + j * ldm, src + j * ld, sizeof(double) * p);
+  HIPCHK(hipMemcpyAsync(b.dev, b.host, sizeof(double) * ldm * qp, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipEventRecord(b.done, e->stream));
+  b.pending = true;
+  *ldm_out = ldm;
+  return 0;
+}
+
+static double* panel_ptr(E* e, int panel, int col) {
+  return e->panel[panel] + (int64_t)col * e->ldp;
+}
+static int check_panel(E* e, int panel, int c0, int k) {
+  if (panel < 0 || panel > 5 || !e->panel[panel]) return fail("invalid or unallocated panel id");
+  if (c0 < 0 || k < 0 || c0 + k > e->cols_alloc) return fail("panel column range out of bounds");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* dav_last_error(void) { return g_err.c_str(); }
+extern "C" int dav_version(void) { return 100; }
+
+extern "C" int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, int gev, int rank, int nranks) {
+  if (!h || n <= 0 || max_cols <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return fail("dav_create: bad arguments");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail("dav_create: no HIP device visible - the HIP path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail("dav_create: device index out of range");
+  E* e = new E();
+  e->device = device;
+  e->n = n;
+  e->rank = rank;
+  e->nranks = nranks;
+  e->gev = gev ? 1 : 0;
+  e->max_cols = max_cols;
+  e->cols_alloc = (int)roundup(max_cols, 16) + 16;
+  e->nslab = roundup((n + nranks - 1) / nranks, 16);
+  e->row0 = (int64_t)rank * e->nslab;
+  e->nloc = std::max<int64_t>(0, std::min<int64_t>(e->nslab, n - e->row0));
+  e->nloc_pad = roundup(e->nslab, MV_ROWS);
+  e->ncols_pad = roundup((int64_t)nranks * e->nslab, 64);
+  e->ldp = e->nloc_pad;
+  e->st.n = n;
+  e->st.nloc = e->nloc;
+  e->st.rank = rank;
+  e->st.nranks = nranks;
+  *h = e;
+  CHK(bind(e));
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  size_t pbytes = sizeof(double) * (size_t)e->ldp * e->cols_alloc;
+  for (int p = 0; p < 6; ++p) {
+    if (p == DAV_PANEL_BV && !e->gev) continue;
+    HIPCHK(hipMalloc(&e->panel[p], pbytes));
+    HIPCHK(hipMemsetAsync(e->panel[p], 0, pbytes, e->stream));
+  }
+  e->xt_group_stride = e->ncols_pad * 16;
+  HIPCHK(hipMalloc(&e->xt, sizeof(double) * e->xt_group_stride * 4));
+  HIPCHK(hipMemsetAsync(e->xt, 0, sizeof(double) * e->xt_group_stride * 4, e->stream));
+  int nsplit, jc;
+  matvec_plan(e->nloc_pad, e->ncols_pad, 4, &nsplit, &jc);
+  size_t s1 = matvec_slab_doubles(e->nloc_pad, 4, nsplit);
+  size_t s2 = gram_scratch_doubles(e->cols_alloc, e->cols_alloc, e->nloc_pad);
+  e->scratch_doubles = std::max(s1, s2);
+  HIPCHK(hipMalloc(&e->scratch, sizeof(double) * e->scratch_doubles));
+  e->gram_doubles = (size_t)e->cols_alloc * e->cols_alloc;
+  HIPCHK(hipMalloc(&e->gram_dev, sizeof(double) * e->gram_doubles));
+  HIPCHK(hipHostMalloc(&e->gram_host, sizeof(double) * e->gram_doubles, hipHostMallocDefault));
+  HIPCHK(hipMalloc(&e->gather_dev, sizeof(double) * (size_t)e->ncols_pad));
+  HIPCHK(hipMalloc(&e->idx_dev, sizeof(int64_t) * e->cols_alloc));
+  HIPCHK(hipMalloc(&e->norm_partial, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc));
+  e->small_doubles = (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
+  for (int i = 0; i < N_SMALL; ++i) {
+    HIPCHK(hipMalloc(&e->sm[i].dev, sizeof(double) * e->small_doubles));
+    HIPCHK(hipHostMalloc(&e->sm[i].host, sizeof(double) * e->small_doubles, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&e->sm[i].done, hipEventDisableTiming));
+  }
+  for (int i = 0; i < N_EVPAIRS; ++i) {
+    HIPCHK(hipEventCreate(&e->ev[i][0]));
+    HIPCHK(hipEventCreate(&e->ev[i][1]));
+  }
+  for (int w = 0; w < 2; ++w) {
+    HIPCHK(hipMalloc(&e->op[w].diag, sizeof(double) * e->nloc_pad));
+    HIPCHK(hipMemsetAsync(e->op[w].diag, 0, sizeof(double) * e->nloc_pad, e->stream));
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int dav_destroy(dav_handle_t e) {
+  if (!e) return 0;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->comm && g_rccl.lib) g_rccl.CommDestroy(e->comm);
+  for (int p = 0; p < 6; ++p)
+    if (e->panel[p]) hipFree(e->panel[p]);
+  hipFree(e->xt);
+  hipFree(e->scratch);
+  hipFree(e->gram_dev);
+  if (e->gram_host) hipHostFree(e->gram_host);
+  hipFree(e->gather_dev);
+  hipFree(e->idx_dev);
+  hipFree(e->norm_partial);
+  for (int i = 0; i < N_SMALL; ++i) {
+    hipFree(e->sm[i].dev);
+    if (e->sm[i].host) hipHostFree(e->sm[i].host);
+    if (e->sm[i].done) hipEventDestroy(e->sm[i].done);
+  }
+  for (int i = 0; i < N_EVPAIRS; ++i) {
+    if (e->ev[i][0]) hipEventDestroy(e->ev[i][0]);
+    if (e->ev[i][1]) hipEventDestroy(e->ev[i][1]);
+  }
+  for (int w = 0; w < 2; ++w) {
+    hipFree(e->op[w].a);
+    hipFree(e->op[w].e_table);
+    hipFree(e->op[w].diag);
+  }
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return 0;
+}
+
+extern "C" int dav_comm_unique_id(void* id128) {
+  CHK(rccl_load());
+  ncclUniqueId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int dav_comm_init(dav_handle_t e, const void* id128) {
+  if (e->nranks == 1) return 0;
+  CHK(rccl_load());
+  CHK(bind(e));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  NCCLCHK(g_rccl.CommInitRank(&e->comm, e->nranks, id, e->rank));
+  return 0;
+}
+
+extern "C" int dav_synchronize(dav_handle_t e) {
+  CHK(bind(e));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int dav_get_stats(dav_handle_t e, dav_stats* out) {
+  CHK(bind(e));
+  CHK(collect_events(e));
+  e->st.m = e->m;
+  *out = e->st;
+  return 0;
+}
+
+extern "C" int dav_reset_stats(dav_handle_t e) {
+  CHK(bind(e));
+  CHK(collect_events(e));
+  dav_stats z{};
+  z.n = e->n; z.nloc = e->nloc; z.rank = e->rank; z.nranks = e->nranks;
+  e->st = z;
+  return 0;
+}
+
+extern "C" int dav_local_rows(dav_handle_t e, int64_t* row0, int64_t* nloc) {
+  *row0 = e->row0;
+  *nloc = e->nloc;
+  return 0;
+}
+
+// ---- operators ---------------------------------------------------------------------------------
+static int need_comm(E* e) {
+  if (e->nranks > 1 && !e->comm) return fail("multi-rank engine used before dav_comm_init");
+  return 0;
+}
+
+static int refresh_diag_host(E* e, int which) {
+  // global diagonal on the host (stable top-k selection, dav_get_diagonal)
+  std::vector<double>& d = e->diag_host[which];
+  d.assign((size_t)e->n, 0.0);
+  if (e->nranks == 1) {
+    HIPCHK(hipMemcpyAsync(d.data(), e->op[which].diag, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  } else {
+    CHK(need_comm(e));
+    NCCLCHK(g_rccl.AllGather(e->op[which].diag, e->gather_dev, (size_t)e->nslab, ncclDouble, e->comm, e->stream));
+    HIPCHK(hipMemcpyAsync(d.data(), e->gather_dev, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
+static int alloc_dense(E* e, int which) {
+  OpDesc& o = e->op[which];
+  if (!o.a) {
+    size_t bytes = sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
+    hipError_t r = hipMalloc(&o.a, bytes);
+    if (r != hipSuccess)
+      return fail("hipMalloc of the dense matrix slab (" + std::to_string(bytes >> 20) + " MiB) failed: " + hipGetErrorString(r));
+  }
+  return 0;
+}
+
+extern "C" int dav_set_dense_host(dav_handle_t e, int which, const double* a, int64_t lda) {
+  if (which < 0 || which > 1 || !a || lda < e->n) return fail("dav_set_dense_host: bad arguments");
+  CHK(bind(e));
+  CHK(alloc_dense(e, which));
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_DENSE;
+  HIPCHK(hipMemsetAsync(o.a, 0, sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad, e->stream));
+  if (e->nloc > 0)
+    HIPCHK(hipMemcpy2DAsync(o.a, sizeof(double) * e->nloc_pad, a + e->row0, sizeof(double) * lda,
+                            sizeof(double) * e->nloc, (size_t)e->n, hipMemcpyHostToDevice, e->stream));
+  launch_diag_dense(e->stream, o.a, e->nloc_pad, e->row0, e->nloc, o.diag);
+  CHK(refresh_diag_host(e, which));
+  return 0;
+}
+
+extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed, double sparsity, int use_diag_val,
+                                       double diag_val) {
+  if (which < 0 || which > 1) return fail("dav_set_dense_generated: bad operator id");
+  CHK(bind(e));
+  CHK(alloc_dense(e, which));
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_DENSE;
+  launch_generate_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->row0, e->nloc, e->n, seed, sparsity,
+                        use_diag_val, diag_val);
+  launch_diag_dense(e->stream, o.a, e->nloc_pad, e->row0, e->nloc, o.diag);
+  CHK(refresh_diag_host(e, which));
+  return 0;
+}
+
+static OpParams op_params(const OpDesc& o) {
+  OpParams p;
+  p.kind = o.kind; p.seed = o.seed; p.sparsity = o.sparsity; p.use_diag = o.use_diag; p.diag_val = o.diag_val;
+  p.trig = o.trig; p.e_table = o.e_table;
+  return p;
+}
+
+extern "C" int dav_set_operator_hashed(dav_handle_t e, int which, uint64_t seed, double sparsity, int use_diag_val,
+                                       double diag_val) {
+  if (which < 0 || which > 1) return fail("dav_set_operator_hashed: bad operator id");
+  CHK(bind(e));
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_HASHED; o.seed = seed; o.sparsity = sparsity; o.use_diag = use_diag_val; o.diag_val = diag_val;
+  launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
+  CHK(refresh_diag_host(e, which));
+  return 0;
+}
+
+extern "C" int dav_set_operator_harness(dav_handle_t e, int which, const double* e_table) {
+  if (which < 0 || which > 1 || !e_table) return fail("dav_set_operator_harness: bad arguments");
+  CHK(bind(e));
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_HARNESS; o.trig = which == DAV_OP_A ? 0 : 1;
+  if (!o.e_table) HIPCHK(hipMalloc(&o.e_table, sizeof(double) * e->n));
+  HIPCHK(hipMemcpyAsync(o.e_table, e_table, sizeof(double) * e->n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
+  CHK(refresh_diag_host(e, which));
+  return 0;
+}
+
+extern "C" int dav_set_operator_identity(dav_handle_t e, int which) {
+  if (which < 0 || which > 1) return fail("dav_set_operator_identity: bad operator id");
+  CHK(bind(e));
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_IDENTITY;
+  launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
+  CHK(refresh_diag_host(e, which));
+  return 0;
+}
+
+extern "C" int dav_set_operator_host(dav_handle_t e, int which, const double* diag) {
+  if (which < 0 || which > 1 || !diag) return fail("dav_set_operator_host: bad arguments");
+  CHK(bind(e));
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_HOST;
+  if (e->nloc > 0)
+    HIPCHK(hipMemcpyAsync(o.diag, diag + e->row0, sizeof(double) * e->nloc, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->diag_host[which].assign(diag, diag + e->n);
+  return 0;
+}
+
+extern "C" int dav_get_diagonal(dav_handle_t e, int which, double* out) {
+  if (which < 0 || which > 1 || e->diag_host[which].empty()) return fail("dav_get_diagonal: operator not set");
+  std::memcpy(out, e->diag_host[which].data(), sizeof(double) * e->n);
+  return 0;
+}
+
+// ---- K1 -----------------------------------------------------------------------------------------
+static int apply_impl(E* e, int which, int src_panel, int c0, int k, int dst_panel, int d0, bool timed) {
+  CHK(check_panel(e, src_panel, c0, k));
+  CHK(check_panel(e, dst_panel, d0, k));
+  OpDesc& o = e->op[which];
+  if (o.kind == DAV_KIND_NONE) return fail("dav_apply: operator not set");
+  if (o.kind == DAV_KIND_HOST) return fail("dav_apply: host operator - move blocks with dav_panel_get/put");
+  if (o.kind == DAV_KIND_IDENTITY) {
+    launch_copy_columns(e->stream, panel_ptr(e, src_panel, c0), e->ldp, panel_ptr(e, dst_panel, d0), e->ldp, e->nloc_pad, k);
+    return 0;
+  }
+  CHK(need_comm(e));
+  for (int c = 0; c < k; c += 64) {
+    int kk = std::min(64, k - c);
+    int groups = (kk + 15) / 16;
+    int ngroups = groups == 3 ? 4 : groups;
+    launch_pack_xt(e->stream, panel_ptr(e, src_panel, c0 + c), e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
+    if (e->nranks > 1) {
+      int slot;
+      CHK(timed_begin(e, 3, 0, &slot));
+      NCCLCHK(g_rccl.GroupStart());
+      for (int g = 0; g < groups; ++g) {
+        double* base = e->xt + g * e->xt_group_stride;
+        NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, e->stream));
+      }
+      NCCLCHK(g_rccl.GroupEnd());
+      CHK(timed_end(e, slot));
+    }
+    int nsplit, jc;
+    matvec_plan(e->nloc_pad, e->ncols_pad, ngroups, &nsplit, &jc);
+    if (matvec_slab_doubles(e->nloc_pad, ngroups, nsplit) > e->scratch_doubles) return fail("matvec scratch too small");
+    int slot = -1;
+    double bytes = 8.0 * (double)e->nloc * (double)e->n + 16.0 * (double)e->n * kk;
+    if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
+    if (o.kind == DAV_KIND_DENSE)
+      launch_matvec_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->xt, e->xt_group_stride, ngroups,
+                          e->scratch, nsplit, jc);
+    else
+      launch_matvec_free(e->stream, op_params(o), e->row0, e->nloc, e->n, e->nloc_pad, e->ncols_pad, e->xt,
+                         e->xt_group_stride, ngroups, e->scratch, nsplit, jc);
+    if (timed) CHK(timed_end(e, slot));     // the event pair brackets the block-matvec kernel alone
+    launch_slab_reduce(e->stream, e->scratch, nsplit, e->nloc_pad, ngroups, e->nloc, kk, panel_ptr(e, dst_panel, d0 + c), e->ldp);
+    if (which == DAV_OP_A) {
+      e->st.applies += 1;
+      e->st.apply_cols += kk;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dav_apply(dav_handle_t e, int which, int src_panel, int c0, int k, int dst_panel, int d0) {
+  if (which < 0 || which > 1) return fail("dav_apply: bad operator id");
+  CHK(bind(e));
+  return apply_impl(e, which, src_panel, c0, k, dst_panel, d0, true);
+}
+
+// ---- K2 -----------------------------------------------------------------------------------------
+// result left in e->gram_host (p x q, ld = p) after the call
+static int gram_impl(E* e, const double* P, int p, const double* Q, int q) {
+  if ((size_t)p * q > e->gram_doubles) return fail("gram result exceeds engine capacity");
+  if (gram_scratch_doubles(p, q, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
+  int slot;
+  CHK(timed_begin(e, 1, 0, &slot));
+  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, e->gram_dev);
+  CHK(timed_end(e, slot));
+  if (e->nranks > 1) {
+    CHK(need_comm(e));
+    NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)p * q, ncclDouble, ncclSum, e->comm, e->stream));
+  }
+  HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * p * q, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int dav_gram(dav_handle_t e, int panel_p, int p0, int p, int panel_q, int q0, int q, double* out, int64_t ldo) {
+  CHK(bind(e));
+  CHK(check_panel(e, panel_p, p0, p));
+  CHK(check_panel(e, panel_q, q0, q));
+  if (p <= 0 || q <= 0 || ldo < p) return fail("dav_gram: bad shape");
+  CHK(gram_impl(e, panel_ptr(e, panel_p, p0), p, panel_ptr(e, panel_q, q0), q));
+  for (int j = 0; j < q; ++j) std::memcpy(out + j * ldo, e->gram_host + (size_t)j * p, sizeof(double) * p);
+  return 0;
+}
+
+extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh, double* S, int64_t lds) {
+  CHK(bind(e));
+  int mt = c0 + k;
+  CHK(check_panel(e, DAV_PANEL_V, 0, mt));
+  if (k <= 0 || ldh < mt) return fail("dav_project: bad shape");
+  for (int pass = 0; pass < 2; ++pass) {
+    double* out = pass == 0 ? H : S;
+    int64_t ld = pass == 0 ? ldh : lds;
+    if (pass == 1 && (!e->gev || !S)) break;
+    int panel = pass == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
+    CHK(gram_impl(e, panel_ptr(e, DAV_PANEL_V, 0), mt, panel_ptr(e, panel, c0), k));
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < mt; ++i) {
+        double v = e->gram_host[(size_t)j * mt + i];
+        out[(c0 + j) * ld + i] = v;
+        if (i < c0) out[i * ld + (c0 + j)] = v;       // mirror: the projected matrices are symmetric
+      }
+  }
+  return 0;
+}
+
+// ---- K6 -----------------------------------------------------------------------------------------
+extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
+  CHK(bind(e));
+  if (ncols <= 0 || ncols > e->max_cols || ncols > e->n) return fail("dav_init_basis: bad column count");
+  const std::vector<double>& d = e->diag_host[DAV_OP_A];
+  if (d.empty()) return fail("dav_init_basis: operator A not set");
+  std::vector<int64_t> order((size_t)e->n);
+  std::iota(order.begin(), order.end(), 0);
+  // stable selection of the ncols smallest diagonal entries (ties -> lower index first)
+  std::partial_sort(order.begin(), order.begin() + ncols, order.end(),
+                    [&](int64_t a, int64_t b) { return d[a] < d[b] || (d[a] == d[b] && a < b); });
+  order.resize(ncols);
+  HIPCHK(hipMemcpyAsync(e->idx_dev, order.data(), sizeof(int64_t) * ncols, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  launch_unit_columns(e->stream, e->idx_dev, ncols, e->row0, e->nloc, e->nloc_pad, panel_ptr(e, DAV_PANEL_V, 0), e->ldp);
+  for (int w = 0; w < (e->gev ? 2 : 1); ++w) {
+    OpDesc& o = e->op[w];
+    int dst = w == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
+    if (o.kind == DAV_KIND_DENSE)
+      launch_gather_columns(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
+    else if (o.kind == DAV_KIND_HOST) {
+      /* the driver fills W / BV through dav_panel_put */
+    } else
+      CHK(apply_impl(e, w, DAV_PANEL_V, 0, ncols, dst, 0, false));
+  }
+  e->m = ncols;
+  if (idx_out)
+    for (int i = 0; i < ncols; ++i) idx_out[i] = order[i] + 1;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- K3 -----------------------------------------------------------------------------------------
+extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, const double* Y, int64_t ldy,
+                                            const double* theta, int method, double* resnorm) {
+  CHK(bind(e));
+  if (m <= 0 || lowest <= 0 || lowest > m || ldy < m) return fail("dav_ritz_residual_correction: bad shape");
+  if (method == DAV_METHOD_DPR && 2 * m > e->cols_alloc) return fail("basis panel too narrow for the correction block");
+  CHK(check_panel(e, DAV_PANEL_V, 0, m));
+  int64_t ldm_y, ldm_y2, ldm_t;
+  CHK(small_upload(e, 0, Y, ldy, m, m, &ldm_y));
+  std::vector<double> y2((size_t)m * m);
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) y2[(size_t)j * m + i] = -Y[j * ldy + i] * theta[j];
+  CHK(small_upload(e, 1, y2.data(), m, m, m, &ldm_y2));
+  CHK(small_upload(e, 2, theta, m, m, 1, &ldm_t));
+
+  int slot;
+  CHK(timed_begin(e, 2, 0, &slot));
+  // X = V * Y(:, 1:nx)
+  int nx = method == DAV_METHOD_GJD ? m : lowest;
+  PanelGemmArgs a{};
+  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = e->sm[0].dev; a.ldm1 = ldm_y;
+  a.p2 = 0;
+  a.out = panel_ptr(e, DAV_PANEL_X, 0); a.ldo = e->ldp; a.q = nx;
+  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
+  launch_panel_gemm(e->stream, a);
+  // R = W*Y + Z*(-Y*diag(theta)), norms, (DPR) T
+  PanelGemmArgs r{};
+  r.P1 = panel_ptr(e, DAV_PANEL_W, 0); r.ld1 = e->ldp; r.p1 = m; r.M1 = e->sm[0].dev; r.ldm1 = ldm_y;
+  r.P2 = panel_ptr(e, e->gev ? DAV_PANEL_BV : DAV_PANEL_V, 0); r.ld2 = e->ldp; r.p2 = m; r.M2 = e->sm[1].dev; r.ldm2 = ldm_y2;
+  r.q = m; r.nloc = e->nloc; r.nrows_pad = e->nloc_pad;
+  r.theta = e->sm[2].dev; r.dA = e->op[DAV_OP_A].diag; r.dB = e->gev ? e->op[DAV_OP_B].diag : nullptr;
+  r.nnorm = lowest; r.norm_partial = e->norm_partial;
+  if (method == DAV_METHOD_DPR) {
+    r.out = panel_ptr(e, DAV_PANEL_V, m); r.ldo = e->ldp; r.epilogue = 1;
+  } else {
+    r.out = panel_ptr(e, DAV_PANEL_R, 0); r.ldo = e->ldp; r.epilogue = 2;
+  }
+  launch_panel_gemm(e->stream, r);
+  launch_norm_finish(e->stream, e->norm_partial, (int)(e->nloc_pad / PG_ROWS), lowest, e->gram_dev);
+  CHK(timed_end(e, slot));
+  if (e->nranks > 1) {
+    CHK(need_comm(e));
+    NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)lowest, ncclDouble, ncclSum, e->comm, e->stream));
+  }
+  HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * lowest, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int j = 0; j < lowest; ++j) resnorm[j] = std::sqrt(e->gram_host[j]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- K4 -----------------------------------------------------------------------------------------
+extern "C" int dav_ortho_gram(dav_handle_t e, int m, int kt, double* C, int64_t ldc, double* G, int64_t ldg) {
+  CHK(bind(e));
+  if (m < 0 || kt <= 0 || ldg < kt || (m > 0 && ldc < m)) return fail("dav_ortho_gram: bad shape");
+  CHK(check_panel(e, DAV_PANEL_V, 0, m + kt));
+  int p = m + kt;
+  CHK(gram_impl(e, panel_ptr(e, DAV_PANEL_V, 0), p, panel_ptr(e, DAV_PANEL_V, m), kt));
+  for (int j = 0; j < kt; ++j) {
+    for (int i = 0; i < m; ++i) C[j * ldc + i] = e->gram_host[(size_t)j * p + i];
+    for (int i = 0; i < kt; ++i) G[j * ldg + i] = e->gram_host[(size_t)j * p + m + i];
+  }
+  return 0;
+}
+
+extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm) {
+  CHK(bind(e));
+  if (m < 0 || kt <= 0 || ldm < kt) return fail("dav_ortho_apply: bad shape");
+  CHK(check_panel(e, DAV_PANEL_V, 0, m + kt));
+  int64_t ld_m, ld_cm = 4;
+  CHK(small_upload(e, 0, M, ldm, kt, kt, &ld_m));
+  if (m > 0) {
+    std::vector<double> cm((size_t)m * kt, 0.0);       // -(C*M)
+    for (int j = 0; j < kt; ++j)
+      for (int l = 0; l < kt; ++l) {
+        double mlj = M[j * ldm + l];
+        if (mlj == 0.0) continue;
+        for (int i = 0; i < m; ++i) cm[(size_t)j * m + i] -= C[l * ldc + i] * mlj;
+      }
+    CHK(small_upload(e, 1, cm.data(), m, m, kt, &ld_cm));
+  }
+  int slot;
+  CHK(timed_begin(e, 2, 0, &slot));
+  PanelGemmArgs a{};
+  a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = e->sm[0].dev; a.ldm1 = ld_m;
+  a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = e->sm[1].dev; a.ldm2 = ld_cm;
+  a.out = panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
+  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
+  launch_panel_gemm(e->stream, a);
+  launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, m), e->ldp, e->nloc_pad, kt);
+  CHK(timed_end(e, slot));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dav_expand(dav_handle_t e, int m, int kt) {
+  CHK(bind(e));
+  if (m < 0 || kt <= 0 || m + kt > e->cols_alloc) return fail("dav_expand: bad shape");
+  for (int w = 0; w < (e->gev ? 2 : 1); ++w) {
+    if (e->op[w].kind == DAV_KIND_HOST) continue;     // driver moves the block through the host callback
+    CHK(apply_impl(e, w, DAV_PANEL_V, m, kt, w == 0 ? DAV_PANEL_W : DAV_PANEL_BV, m, true));
+  }
+  e->m = m + kt;
+  return 0;
+}
+
+// ---- K5 -----------------------------------------------------------------------------------------
+extern "C" int dav_panel_transform(dav_handle_t e, int src_panel, int s0, int p, const double* M, int64_t ldm, int q,
+                                   int dst_panel, int d0) {
+  CHK(bind(e));
+  CHK(check_panel(e, src_panel, s0, p));
+  CHK(check_panel(e, dst_panel, d0, q));
+  if (p <= 0 || q <= 0 || ldm < p) return fail("dav_panel_transform: bad shape");
+  if (q > e->cols_alloc) return fail("dav_panel_transform: too many output columns");
+  int64_t ld_m;
+  CHK(small_upload(e, 3, M, ldm, p, q, &ld_m));
+  int slot;
+  CHK(timed_begin(e, 2, 0, &slot));
+  PanelGemmArgs a{};
+  a.P1 = panel_ptr(e, src_panel, s0); a.ld1 = e->ldp; a.p1 = p; a.M1 = e->sm[3].dev; a.ldm1 = ld_m;
+  a.p2 = 0;
+  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = q; a.ldo = e->ldp;
+  bool overlap = (src_panel == dst_panel);
+  a.out = overlap ? panel_ptr(e, DAV_PANEL_S, 0) : panel_ptr(e, dst_panel, d0);
+  if (overlap && src_panel == DAV_PANEL_S) return fail("dav_panel_transform: scratch panel cannot be transformed in place");
+  launch_panel_gemm(e->stream, a);
+  if (overlap) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, dst_panel, d0), e->ldp, e->nloc_pad, q);
+  CHK(timed_end(e, slot));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dav_restart(dav_handle_t e, int m, int keep, const double* Yk, int64_t ldy) {
+  CHK(bind(e));
+  if (keep <= 0 || keep > m) return fail("dav_restart: bad shape");
+  CHK(dav_panel_transform(e, DAV_PANEL_V, 0, m, Yk, ldy, keep, DAV_PANEL_V, 0));
+  e->m = keep;
+  return 0;
+}
+
+// ---- block movement --------------------------------------------------------------------------------
+extern "C" int dav_panel_get(dav_handle_t e, int panel, int c0, int k, double* out, int64_t ld) {
+  CHK(bind(e));
+  CHK(check_panel(e, panel, c0, k));
+  if (ld < e->n) return fail("dav_panel_get: leading dimension too small");
+  if (e->nranks == 1) {
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * ld, panel_ptr(e, panel, c0), sizeof(double) * e->ldp,
+                            sizeof(double) * e->n, (size_t)k, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+  }
+  CHK(need_comm(e));
+  for (int j = 0; j < k; ++j) {
+    NCCLCHK(g_rccl.AllGather(panel_ptr(e, panel, c0 + j), e->gather_dev, (size_t)e->nslab, ncclDouble, e->comm, e->stream));
+    HIPCHK(hipMemcpyAsync(out + j * ld, e->gather_dev, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
+extern "C" int dav_panel_put(dav_handle_t e, int panel, int c0, int k, const double* in, int64_t ld) {
+  CHK(bind(e));
+  CHK(check_panel(e, panel, c0, k));
+  if (ld < e->n) return fail("dav_panel_put: leading dimension too small");
+  if (e->nloc > 0) {
+    HIPCHK(hipMemcpy2DAsync(panel_ptr(e, panel, c0), sizeof(double) * e->ldp, in + e->row0, sizeof(double) * ld,
+                            sizeof(double) * e->nloc, (size_t)k, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
+extern "C" int dav_set_width(dav_handle_t e, int m) {
+  if (m < 0 || m > e->cols_alloc) return fail("dav_set_width: out of range");
+  e->m = m;
+  return 0;
+}
+
+// ---- measurement --------------------------------------------------------------------------------
+extern "C" int dav_bench_apply(dav_handle_t e, int which, int k, int reps, double* avg_ms, double* bytes) {
+  CHK(bind(e));
+  if (which != DAV_OP_A) return fail("dav_bench_apply: only operator A is timed");
+  if (k <= 0 || k > 64 || reps <= 0) return fail("dav_bench_apply: k must be in 1..64");
+  CHK(collect_events(e));
+  dav_stats saved = e->st;
+  // warm up once, then time the matvec + slab-reduce launches only (operands resident in HBM)
+  CHK(apply_impl(e, which, DAV_PANEL_V, 0, k, DAV_PANEL_S, 0, false));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  double total = 0;
+  int done = 0;
+  while (done < reps) {
+    int batch = std::min(reps - done, N_EVPAIRS / 2);
+    e->st.apply_ms = 0;
+    for (int i = 0; i < batch; ++i) CHK(apply_impl(e, which, DAV_PANEL_V, 0, k, DAV_PANEL_S, 0, true));
+    CHK(collect_events(e));
+    total += e->st.apply_ms;
+    done += batch;
+  }
+  *avg_ms = total / reps;
+  *bytes = 8.0 * (double)e->nloc * (double)e->n + 16.0 * (double)e->n * k;
+  e->st = saved;
+  return 0;
+}
+
+// ---- K7 (GJD) lives in gjd.hip ---------------------------------------------------------------------
+extern "C" int dav_gjd_correction(dav_handle_t e, int m, const double* theta, int max_inner, double inner_tol,
+                                  int* inner_iters_out) {
+  (void)e; (void)m; (void)theta; (void)max_inner; (void)inner_tol; (void)inner_iters_out;
+  return fail("dav_gjd_correction: not implemented yet");
+}

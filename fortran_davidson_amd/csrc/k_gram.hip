@@ -1,0 +1,130 @@
+// K2 - tall-skinny Gram / projection  C(p x q) = P^T Q  (replaces the DGEMM 'T','N' of
+// src/davidson.f90:131,223 outer; also the inner products of the block Gram-Schmidt that replaces
+// lapack_qr, src/lapack_wrapper.f90:176-236).
+//
+// The long dimension N is the MFMA contraction index.  Lane (c = lane & 15, g = lane >> 4) loads four
+// consecutive rows n0 + 4g .. 4g+3 of panel column c (two 16-byte loads: the 16 lanes of a column
+// group read one full 128-byte line per column), and MFMA step s uses element s of both fragments,
+// so A and B operands see the same permutation of the contraction index.  Each wave owns a
+// (16 PT) x (16 QT) tile of C over a 256-row chunk, the four waves of a workgroup are summed through
+// LDS, workgroup partials go to a slab, a second kernel adds the slabs in a fixed order.
+#include "kernels.h"
+
+template <int PT, int QT>
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P, int64_t ldp, int p,
+                                                   const double* __restrict__ Q, int64_t ldq, int q,
+                                                   int64_t nrows_pad, int qtiles, double* __restrict__ slab,
+                                                   int ppad, int qpad) {
+  __shared__ double red[4][PT * QT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int tp = blockIdx.x / qtiles, tq = blockIdx.x % qtiles;
+  const int pc0 = tp * 16 * PT, qc0 = tq * 16 * QT;
+  int64_t n0 = (int64_t)blockIdx.y * GRAM_ROWS + wave * (GRAM_ROWS / 4);
+  int64_t n1 = n0 + GRAM_ROWS / 4;
+  if (n1 > nrows_pad) n1 = nrows_pad;
+
+  // column pointers; columns past the panel width are clamped (their results are discarded)
+  const double* pp[PT];
+  const double* qp[QT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    int col = pc0 + 16 * t + c;
+    if (col >= p) col = p - 1;
+    pp[t] = P + (int64_t)col * ldp + 4 * g;
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    int col = qc0 + 16 * t + c;
+    if (col >= q) col = q - 1;
+    qp[t] = Q + (int64_t)col * ldq + 4 * g;
+  }
+
+  f64x4 acc[PT][QT];
+#pragma unroll
+  for (int a = 0; a < PT; ++a)
+#pragma unroll
+    for (int b = 0; b < QT; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  for (int64_t n = n0; n < n1; n += 16) {
+    f64x2 pf[PT][2], qf[QT][2];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      pf[t][0] = *reinterpret_cast<const f64x2*>(pp[t] + n);
+      pf[t][1] = *reinterpret_cast<const f64x2*>(pp[t] + n + 2);
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      qf[t][0] = *reinterpret_cast<const f64x2*>(qp[t] + n);
+      qf[t][1] = *reinterpret_cast<const f64x2*>(qp[t] + n + 2);
+    }
+#pragma unroll
+    for (int a = 0; a < PT; ++a)
+#pragma unroll
+      for (int b = 0; b < QT; ++b) {
+        acc[a][b] = mfma_f64(pf[a][0].x, qf[b][0].x, acc[a][b]);
+        acc[a][b] = mfma_f64(pf[a][0].y, qf[b][0].y, acc[a][b]);
+        acc[a][b] = mfma_f64(pf[a][1].x, qf[b][1].x, acc[a][b]);
+        acc[a][b] = mfma_f64(pf[a][1].y, qf[b][1].y, acc[a][b]);
+      }
+  }
+
+  // cross-wave sum through LDS, then one partial tile per workgroup
+#pragma unroll
+  for (int a = 0; a < PT; ++a)
+#pragma unroll
+    for (int b = 0; b < QT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][((a * QT + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+  __syncthreads();
+  double* out = slab + (int64_t)blockIdx.y * ppad * qpad;
+  for (int e = threadIdx.x; e < PT * QT * 256; e += 256) {
+    double v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    int l = e & 63, r = (e >> 6) & 3, ab = e >> 8;
+    int a = ab / QT, b = ab % QT;
+    int prow = pc0 + 16 * a + (l >> 4) + 4 * r;   // index into P columns  (row of C)
+    int qcol = qc0 + 16 * b + (l & 15);           // index into Q columns  (column of C)
+    if (prow < p && qcol < q) out[(int64_t)qcol * ppad + prow] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ slab, int nchunks, int p, int q,
+                                                          int ppad, int qpad, double* __restrict__ out) {
+  int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= p * q) return;
+  int row = e % p, col = e / p;
+  double s = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) s += slab[(int64_t)ch * ppad * qpad + (int64_t)col * ppad + row];
+  out[(int64_t)col * p + row] = s;
+}
+
+static inline int pad16(int x) { return (x + 15) / 16 * 16; }
+
+size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
+  int64_t nchunks = (nrows_pad + GRAM_ROWS - 1) / GRAM_ROWS;
+  return (size_t)nchunks * pad16(p) * pad16(q);
+}
+
+void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
+                 int64_t nrows_pad, double* scratch, double* out_dev) {
+  int nchunks = (int)((nrows_pad + GRAM_ROWS - 1) / GRAM_ROWS);
+  int ppad = pad16(p), qpad = pad16(q);
+  if (p > 16 && q > 16) {
+    constexpr int PT = 2, QT = 2;
+    int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
+    dim3 grid(ptiles * qtiles, nchunks);
+    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad);
+  } else if (p > 16) {
+    constexpr int PT = 2, QT = 1;
+    int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
+    dim3 grid(ptiles * qtiles, nchunks);
+    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad);
+  } else {
+    constexpr int PT = 1, QT = 1;
+    int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
+    dim3 grid(ptiles * qtiles, nchunks);
+    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad);
+  }
+  int total = p * q;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, nchunks, p, q, ppad, qpad, out_dev);
+}

@@ -1,0 +1,227 @@
+// K1 - block matvec W = A * X for a row slab of A (replaces the DGEMM 'N','N' of
+// src/davidson.f90:131,223 / lapack_wrapper.f90:279-328, and the callbacks of :378-379).
+//
+// HBM-bound for k <= ~32 columns: A (column-major, rows contiguous) is streamed exactly once with
+// 16-byte-per-lane coalesced loads (one wave-load = 32 rows x 4 columns = four 256-byte row runs);
+// the block X is pre-packed as Xt[group][row j][16] so that the MFMA B operand of a 4-column step is
+// one coalesced 512-byte load that stays in L2; the contraction runs on v_mfma_f64_16x16x4_f64 with
+// the accumulators (64 rows x 16*NT columns per wave) in registers for the whole column chunk.
+// The column range is split over blockIdx.y (>>256 workgroups); partial tiles go to a slab that a
+// second, tiny kernel sums in a fixed order (bitwise reproducible, no fp64 atomics).
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_xt_kernel(const double* __restrict__ src, int64_t ld, int64_t nloc,
+                                                      int64_t nslab, int k, double* __restrict__ xt,
+                                                      int64_t group_stride, int64_t row_off) {
+  int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int g = blockIdx.y;
+  if (j >= nslab) return;
+  double v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    int col = 16 * g + c;
+    v[c] = (col < k && j < nloc) ? src[j + (int64_t)col * ld] : 0.0;
+  }
+  f64x2* dst = reinterpret_cast<f64x2*>(xt + g * group_stride + (row_off + j) * 16);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) dst[c] = f64x2{v[2 * c], v[2 * c + 1]};
+}
+
+void launch_pack_xt(hipStream_t st, const double* src, int64_t ld, int64_t nloc, int64_t nslab, int k,
+                    double* xt, int64_t xt_group_stride, int64_t row_off) {
+  int groups = (k + 15) / 16;
+  dim3 grid((unsigned)((nslab + 255) / 256), groups);
+  hipLaunchKernelGGL(pack_xt_kernel, grid, dim3(256), 0, st, src, ld, nloc, nslab, k, xt, xt_group_stride, row_off);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One j-iteration = 16 columns of A = 4 MFMA k-steps.  Lane (c = lane & 15, g = lane >> 4):
+//   A loads:  rows r0 + 2c, r0 + 2c + 1 (+32 for the second load) of column j + 4u + g
+//   B loads:  Xt[group t][j + 4u + g][c]
+//   acc[rt][t]: rt = 2*half + parity -> rows r0 + 32*half + 2*(g + 4*reg) + parity, column 16 t + c
+template <int NT>
+__global__ __launch_bounds__(256) void matvec_dense_kernel(const double* __restrict__ A, int64_t lda,
+                                                           int64_t ncols_pad, const double* __restrict__ xt,
+                                                           int64_t group_stride, double* __restrict__ slab,
+                                                           int64_t nrows_pad, int jc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * MV_ROWS + wave * 64;
+  const int s = blockIdx.y;
+  const int64_t j0 = (int64_t)s * jc;
+  int64_t j1 = j0 + jc;
+  if (j1 > ncols_pad) j1 = ncols_pad;
+
+  const double* ap = A + r0 + 2 * c + (j0 + g) * lda;
+  const double* xp = xt + (j0 + g) * 16 + c;
+
+  f64x4 acc[4][NT];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[rt][t] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  for (int64_t j = j0; j < j1; j += 16) {
+    f64x2 a[4][2];
+    double b[4][NT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u][0] = *reinterpret_cast<const f64x2*>(ap + (int64_t)(4 * u) * lda);
+      a[u][1] = *reinterpret_cast<const f64x2*>(ap + (int64_t)(4 * u) * lda + 32);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[u][t] = xp[t * group_stride + 4 * u * 16];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[0][t] = mfma_f64(a[u][0].x, b[u][t], acc[0][t]);
+        acc[1][t] = mfma_f64(a[u][0].y, b[u][t], acc[1][t]);
+        acc[2][t] = mfma_f64(a[u][1].x, b[u][t], acc[2][t]);
+        acc[3][t] = mfma_f64(a[u][1].y, b[u][t], acc[3][t]);
+      }
+    }
+    ap += 16 * lda;
+    xp += 16 * 16;
+  }
+
+  double* out = slab + (int64_t)s * (NT * 16) * nrows_pad;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int half = rt >> 1, par = rt & 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        int64_t row = r0 + 32 * half + 2 * (g + 4 * reg) + par;
+        out[(int64_t)(16 * t + c) * nrows_pad + row] = acc[rt][t][reg];
+      }
+    }
+  }
+}
+
+// Matrix-free variant: the A entries of the same register tile are generated in place.
+template <int NT>
+__global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t row0, int64_t nloc, int64_t n,
+                                                          int64_t ncols_pad, const double* __restrict__ xt,
+                                                          int64_t group_stride, double* __restrict__ slab,
+                                                          int64_t nrows_pad, int jc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * MV_ROWS + wave * 64;
+  const int s = blockIdx.y;
+  const int64_t j0 = (int64_t)s * jc;
+  int64_t j1 = j0 + jc;
+  if (j1 > ncols_pad) j1 = ncols_pad;
+  const double* xp = xt + (j0 + g) * 16 + c;
+
+  f64x4 acc[4][NT];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[rt][t] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  int64_t li[4] = {r0 + 2 * c, r0 + 2 * c + 1, r0 + 32 + 2 * c, r0 + 32 + 2 * c + 1};
+  for (int64_t j = j0; j < j1; j += 4) {
+    const int64_t gj = j + g;
+    double a[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      double v = 0.0;
+      if (li[rt] < nloc && gj < n) {
+        int64_t gi = row0 + li[rt];
+        v = (op.kind == DAV_KIND_HASHED)
+                ? dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj)
+                : dav_harness_entry(op.e_table, op.trig, gi, gj);
+      }
+      a[rt] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double b = xp[t * group_stride];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt][t] = mfma_f64(a[rt], b, acc[rt][t]);
+    }
+    xp += 4 * 16;
+  }
+
+  double* out = slab + (int64_t)s * (NT * 16) * nrows_pad;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int half = rt >> 1, par = rt & 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        int64_t row = r0 + 32 * half + 2 * (g + 4 * reg) + par;
+        out[(int64_t)(16 * t + c) * nrows_pad + row] = acc[rt][t][reg];
+      }
+    }
+  }
+}
+
+void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc) {
+  int64_t rowblocks = nrows_pad / MV_ROWS;
+  int64_t target = 2048;                       // ~8 workgroups per CU
+  int64_t s = (target + rowblocks - 1) / rowblocks;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  int64_t chunk = (ncols_pad + s - 1) / s;
+  chunk = (chunk + 15) / 16 * 16;
+  if (chunk < 64) chunk = 64;
+  *jc = (int)chunk;
+  *nsplit = (int)((ncols_pad + chunk - 1) / chunk);
+  (void)ngroups;
+}
+
+size_t matvec_slab_doubles(int64_t nrows_pad, int ngroups, int nsplit) {
+  return (size_t)nsplit * (size_t)ngroups * 16 * (size_t)nrows_pad;
+}
+
+void launch_matvec_dense(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad,
+                         const double* xt, int64_t xt_group_stride, int ngroups, double* slab, int nsplit, int jc) {
+  dim3 grid((unsigned)(nrows_pad / MV_ROWS), nsplit);
+  switch (ngroups) {
+    case 1: hipLaunchKernelGGL(matvec_dense_kernel<1>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    case 2: hipLaunchKernelGGL(matvec_dense_kernel<2>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    default: hipLaunchKernelGGL(matvec_dense_kernel<4>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+  }
+}
+
+void launch_matvec_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t n, int64_t nrows_pad,
+                        int64_t ncols_pad, const double* xt, int64_t xt_group_stride, int ngroups, double* slab,
+                        int nsplit, int jc) {
+  dim3 grid((unsigned)(nrows_pad / MV_ROWS), nsplit);
+  switch (ngroups) {
+    case 1: hipLaunchKernelGGL(matvec_free_kernel<1>, grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    case 2: hipLaunchKernelGGL(matvec_free_kernel<2>, grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    default: hipLaunchKernelGGL(matvec_free_kernel<4>, grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restrict__ slab, int nsplit,
+                                                          int64_t nrows_pad, int ncol16, int64_t nloc, int k,
+                                                          double* __restrict__ dst, int64_t ldd) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  int col = blockIdx.y;
+  if (i >= nrows_pad || col >= k) return;
+  f64x2 sum = {0.0, 0.0};
+  const double* p = slab + (int64_t)col * nrows_pad + i;
+  const int64_t stride = (int64_t)ncol16 * nrows_pad;
+  for (int s = 0; s < nsplit; ++s) {
+    f64x2 v = *reinterpret_cast<const f64x2*>(p + s * stride);
+    sum.x += v.x;
+    sum.y += v.y;
+  }
+  if (i >= nloc) sum.x = 0.0;
+  if (i + 1 >= nloc) sum.y = 0.0;
+  *reinterpret_cast<f64x2*>(dst + (int64_t)col * ldd + i) = sum;
+}
+
+void launch_slab_reduce(hipStream_t st, const double* slab, int nsplit, int64_t nrows_pad, int ngroups,
+                        int64_t nloc, int k, double* dst, int64_t ldd) {
+  dim3 grid((unsigned)((nrows_pad / 2 + 255) / 256), k);
+  hipLaunchKernelGGL(slab_reduce_kernel, grid, dim3(256), 0, st, slab, nsplit, nrows_pad, ngroups * 16, nloc, k, dst, ldd);
+}

@@ -1,0 +1,92 @@
+// K6 setup kernels and small utilities: input generator (semantics of generate_diagonal_dominant,
+// src/array_utils.f90:86-113), diagonal extraction (array_utils.f90:115-134 without the O(N^2) loop),
+// unit-vector basis (array_utils.f90:136-160) and its image A*V0 as a column gather.
+#include "kernels.h"
+
+__global__ __launch_bounds__(256) void generate_dense_tile_kernel(double* __restrict__ A, int64_t lda, int64_t nrows_pad,
+                                                                  int64_t row0, int64_t nloc, int64_t n, int64_t col0,
+                                                                  uint64_t seed, double sparsity, int use_diag,
+                                                                  double diag_val) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  int64_t j = col0 + blockIdx.y;
+  if (i >= nrows_pad) return;
+  f64x2 v = {0.0, 0.0};
+  if (j < n) {
+    if (i < nloc) v.x = dav_hashed_entry(seed, sparsity, use_diag, diag_val, row0 + i, j);
+    if (i + 1 < nloc) v.y = dav_hashed_entry(seed, sparsity, use_diag, diag_val, row0 + i + 1, j);
+  }
+  *reinterpret_cast<f64x2*>(A + j * lda + i) = v;
+}
+
+void launch_generate_dense(hipStream_t st, double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad, int64_t row0,
+                           int64_t nloc, int64_t n, uint64_t seed, double sparsity, int use_diag, double diag_val) {
+  const int64_t ymax = 32768;   // grid.y limit: tile the columns
+  for (int64_t jb = 0; jb < ncols_pad; jb += ymax) {
+    int64_t ny = ncols_pad - jb < ymax ? ncols_pad - jb : ymax;
+    dim3 grid((unsigned)((nrows_pad / 2 + 255) / 256), (unsigned)ny);
+    hipLaunchKernelGGL(generate_dense_tile_kernel, grid, dim3(256), 0, st, A, lda, nrows_pad, row0, nloc, n, jb, seed,
+                       sparsity, use_diag, diag_val);
+  }
+}
+
+__global__ void diag_dense_kernel(const double* __restrict__ A, int64_t lda, int64_t row0, int64_t nloc,
+                                  double* __restrict__ diag) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nloc) diag[i] = A[(row0 + i) * lda + i];
+}
+void launch_diag_dense(hipStream_t st, const double* A, int64_t lda, int64_t row0, int64_t nloc, double* diag) {
+  if (nloc <= 0) return;
+  hipLaunchKernelGGL(diag_dense_kernel, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, st, A, lda, row0, nloc, diag);
+}
+
+__global__ void diag_free_kernel(OpParams op, int64_t row0, int64_t nloc, double* __restrict__ diag) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nloc) return;
+  int64_t gi = row0 + i;
+  double v;
+  if (op.kind == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gi);
+  else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op.e_table, op.trig, gi, gi);
+  else v = 1.0;
+  diag[i] = v;
+}
+void launch_diag_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, double* diag) {
+  if (nloc <= 0) return;
+  hipLaunchKernelGGL(diag_free_kernel, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, st, op, row0, nloc, diag);
+}
+
+__global__ void gather_columns_kernel(const double* __restrict__ A, int64_t lda, int64_t nrows_pad,
+                                      const int64_t* __restrict__ idx, double* __restrict__ dst, int64_t ldd) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int c = blockIdx.y;
+  if (i < nrows_pad) dst[(int64_t)c * ldd + i] = A[idx[c] * lda + i];
+}
+void launch_gather_columns(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad, const int64_t* idx_dev,
+                           int k, double* dst, int64_t ldd) {
+  hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, A, lda,
+                     nrows_pad, idx_dev, dst, ldd);
+}
+
+__global__ void unit_columns_kernel(const int64_t* __restrict__ idx, int64_t row0, int64_t nloc, int64_t nrows_pad,
+                                    double* __restrict__ dst, int64_t ldd) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int c = blockIdx.y;
+  if (i < nrows_pad) dst[(int64_t)c * ldd + i] = (i < nloc && row0 + i == idx[c]) ? 1.0 : 0.0;
+}
+void launch_unit_columns(hipStream_t st, const int64_t* idx_dev, int k, int64_t row0, int64_t nloc, int64_t nrows_pad,
+                         double* dst, int64_t ldd) {
+  hipLaunchKernelGGL(unit_columns_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, idx_dev, row0,
+                     nloc, nrows_pad, dst, ldd);
+}
+
+__global__ void copy_columns_kernel(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd,
+                                    int64_t nrows_pad) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  int c = blockIdx.y;
+  if (i < nrows_pad)
+    *reinterpret_cast<f64x2*>(dst + (int64_t)c * ldd + i) = *reinterpret_cast<const f64x2*>(src + (int64_t)c * lds + i);
+}
+void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t nrows_pad, int k) {
+  if (k <= 0) return;
+  hipLaunchKernelGGL(copy_columns_kernel, dim3((unsigned)((nrows_pad / 2 + 255) / 256), k), dim3(256), 0, st, src, lds,
+                     dst, ldd, nrows_pad);
+}

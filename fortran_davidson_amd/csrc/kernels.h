@@ -1,0 +1,68 @@
+// Host-side launchers of the gfx950 kernels (definitions in k_*.hip).  All pointers are device
+// pointers; all launches go to the given stream; nothing here synchronises.
+#pragma once
+#include "common.h"
+
+// ---- K1: block matvec ---------------------------------------------------------------------------
+// Row tile of one workgroup (4 waves x 64 rows).  Panels and A are padded to a multiple of it.
+constexpr int MV_ROWS = 256;
+// Pack k columns of a column-major panel into the transposed MFMA-B layout Xt[group][row][16]
+// (zero padded) for rows [0, nloc_pad) of this rank, written at row offset `row_off`.
+void launch_pack_xt(hipStream_t st, const double* src, int64_t ld, int64_t nloc, int64_t nslab, int k,
+                    double* xt, int64_t xt_group_stride, int64_t row_off);
+// Pad rows [n_valid, ncols_pad) of every group with zeros (called once at setup).
+// slab[s][col][row] = A[rows, chunk s] * X[chunk s, col]; ngroups = ceil(k/16) in {1,2,4}.
+void launch_matvec_dense(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad,
+                         const double* xt, int64_t xt_group_stride, int ngroups, double* slab,
+                         int nsplit, int jc);
+void launch_matvec_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t n,
+                        int64_t nrows_pad, int64_t ncols_pad, const double* xt, int64_t xt_group_stride,
+                        int ngroups, double* slab, int nsplit, int jc);
+// dst[i, c] = sum_s slab[s][c][i] for i < nloc_pad (rows >= nloc are written as 0), c < k.
+void launch_slab_reduce(hipStream_t st, const double* slab, int nsplit, int64_t nrows_pad, int ngroups,
+                        int64_t nloc, int k, double* dst, int64_t ldd);
+// scratch (in doubles) one matvec launch needs
+size_t matvec_slab_doubles(int64_t nrows_pad, int ngroups, int nsplit);
+void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc);
+
+// ---- K2: tall-skinny Gram ------------------------------------------------------------------------
+constexpr int GRAM_ROWS = 1024;   // rows per workgroup (4 waves x 256)
+// out (p x q, column-major ld = p) = P^T Q over nrows_pad rows (multiple of 16; pad rows are zero).
+// scratch must hold gram_scratch_doubles(...) doubles.  Deterministic two-stage reduction.
+void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
+                 int64_t nrows_pad, double* scratch, double* out_dev);
+size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
+
+// ---- K3/K4/K5: panel x small matrix ---------------------------------------------------------------
+struct PanelGemmArgs {
+  const double* P1; int64_t ld1; int p1; const double* M1; int64_t ldm1;   // term 1 (required)
+  const double* P2; int64_t ld2; int p2; const double* M2; int64_t ldm2;   // term 2 (p2 = 0: absent)
+  double* out; int64_t ldo; int q;          // out[:, 0:q]
+  int64_t nloc, nrows_pad;                  // valid rows / padded rows (multiple of 128)
+  // epilogue: 0 = store; 1 = DPR: out = acc / (theta[col] * dB[row] - dA[row]) plus column norms;
+  //           2 = store plus column norms
+  int epilogue;
+  const double* theta; const double* dA; const double* dB;   // dB == nullptr: B diagonal = 1
+  int nnorm; double* norm_partial;          // [gridDim.x][nnorm] partial sums of acc^2 (cols < nnorm)
+};
+constexpr int PG_ROWS = 128;
+void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a);
+// out[j] = sqrt(sum_b partial[b][j])
+void launch_norm_finish(hipStream_t st, const double* partial, int nblocks, int nnorm, double* out);
+
+// ---- setup / utilities ------------------------------------------------------------------------
+void launch_generate_dense(hipStream_t st, double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad,
+                           int64_t row0, int64_t nloc, int64_t n, uint64_t seed, double sparsity,
+                           int use_diag, double diag_val);
+void launch_diag_dense(hipStream_t st, const double* A, int64_t lda, int64_t row0, int64_t nloc, double* diag);
+void launch_diag_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, double* diag);
+// dst[i, c] = A[i, idx[c]] (column gather: A * unit vectors)
+void launch_gather_columns(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad,
+                           const int64_t* idx_dev, int k, double* dst, int64_t ldd);
+// dst[:, c] = e_{idx[c]} restricted to local rows
+void launch_unit_columns(hipStream_t st, const int64_t* idx_dev, int k, int64_t row0, int64_t nloc,
+                         int64_t nrows_pad, double* dst, int64_t ldd);
+void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd,
+                         int64_t nrows_pad, int k);
+// elementwise helpers for the GJD inner solver (k_gjd.hip)
+struct GjdArgs;

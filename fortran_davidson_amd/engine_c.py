@@ -1,0 +1,206 @@
+"""Thin ctypes view of the C ABI (include/davidson_hip.h) - used by the kernel-level parity tests
+and by bench.py for the roofline measurement.  One method per C entry point, numpy in/out."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import hip_lib
+
+OP_A, OP_B = 0, 1
+PANEL_V, PANEL_W, PANEL_BV, PANEL_X, PANEL_R, PANEL_S = range(6)
+METHOD_DPR, METHOD_GJD = 0, 1
+
+
+class DavidsonHipError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("n", C.c_int64), ("nloc", C.c_int64), ("nranks", C.c_int32), ("rank", C.c_int32),
+                ("m", C.c_int32), ("applies", C.c_int32), ("apply_cols", C.c_int64),
+                ("apply_ms", C.c_double), ("apply_bytes", C.c_double), ("last_apply_ms", C.c_double),
+                ("last_apply_bytes", C.c_double), ("gram_ms", C.c_double), ("panel_ms", C.c_double),
+                ("comm_ms", C.c_double)]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+class CEngine:
+    """RAII wrapper over dav_create/dav_destroy.  `handle` may be borrowed from the Fortran side."""
+
+    def __init__(self, n=None, max_cols=None, gev=False, device=0, rank=0, nranks=1, handle=None):
+        self.lib = hip_lib()
+        self.owned = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            self._chk(self.lib.dav_create(C.byref(h), C.c_int(device), C.c_int64(n), C.c_int(max_cols),
+                                          C.c_int(1 if gev else 0), C.c_int(rank), C.c_int(nranks)))
+            self.h = h
+        else:
+            self.h = C.c_void_p(handle)
+        st = self.stats()
+        self.n = st.n
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DavidsonHipError(self.lib.dav_last_error().decode())
+
+    def close(self):
+        if self.owned and self.h:
+            self.lib.dav_destroy(self.h)
+        self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- bookkeeping
+    def stats(self) -> Stats:
+        st = Stats()
+        self._chk(self.lib.dav_get_stats(self.h, C.byref(st)))
+        return st
+
+    def reset_stats(self):
+        self._chk(self.lib.dav_reset_stats(self.h))
+
+    def synchronize(self):
+        self._chk(self.lib.dav_synchronize(self.h))
+
+    def local_rows(self):
+        r0, nl = C.c_int64(), C.c_int64()
+        self._chk(self.lib.dav_local_rows(self.h, C.byref(r0), C.byref(nl)))
+        return r0.value, nl.value
+
+    def comm_init(self, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._chk(self.lib.dav_comm_init(self.h, buf))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = hip_lib()
+        buf = C.create_string_buffer(128)
+        if lib.dav_comm_unique_id(buf) != 0:
+            raise DavidsonHipError(lib.dav_last_error().decode())
+        return buf.raw
+
+    # -- operators
+    def set_dense_host(self, which, a):
+        a = _f(a)
+        self._chk(self.lib.dav_set_dense_host(self.h, C.c_int(which), _dp(a), C.c_int64(a.shape[0])))
+
+    def set_dense_generated(self, which, seed, sparsity, diag_val=None):
+        self._chk(self.lib.dav_set_dense_generated(self.h, C.c_int(which), C.c_uint64(seed), C.c_double(sparsity),
+                                                   C.c_int(0 if diag_val is None else 1),
+                                                   C.c_double(0.0 if diag_val is None else diag_val)))
+
+    def set_operator_hashed(self, which, seed, sparsity, diag_val=None):
+        self._chk(self.lib.dav_set_operator_hashed(self.h, C.c_int(which), C.c_uint64(seed), C.c_double(sparsity),
+                                                   C.c_int(0 if diag_val is None else 1),
+                                                   C.c_double(0.0 if diag_val is None else diag_val)))
+
+    def set_operator_harness(self, which, e_table):
+        e = np.ascontiguousarray(e_table, dtype=np.float64)
+        self._chk(self.lib.dav_set_operator_harness(self.h, C.c_int(which), _dp(e)))
+
+    def set_operator_identity(self, which):
+        self._chk(self.lib.dav_set_operator_identity(self.h, C.c_int(which)))
+
+    def set_operator_host(self, which, diag):
+        d = np.ascontiguousarray(diag, dtype=np.float64)
+        self._chk(self.lib.dav_set_operator_host(self.h, C.c_int(which), _dp(d)))
+
+    def get_diagonal(self, which):
+        d = np.zeros(self.n)
+        self._chk(self.lib.dav_get_diagonal(self.h, C.c_int(which), _dp(d)))
+        return d
+
+    # -- hot path
+    def init_basis(self, ncols):
+        idx = np.zeros(ncols, dtype=np.int64)
+        self._chk(self.lib.dav_init_basis(self.h, C.c_int(ncols), idx.ctypes.data_as(C.POINTER(C.c_int64))))
+        return idx
+
+    def apply(self, which, src_panel, c0, k, dst_panel, d0):
+        self._chk(self.lib.dav_apply(self.h, C.c_int(which), C.c_int(src_panel), C.c_int(c0), C.c_int(k),
+                                     C.c_int(dst_panel), C.c_int(d0)))
+
+    def gram(self, panel_p, p0, p, panel_q, q0, q):
+        out = np.zeros((p, q), order="F")
+        self._chk(self.lib.dav_gram(self.h, C.c_int(panel_p), C.c_int(p0), C.c_int(p), C.c_int(panel_q), C.c_int(q0),
+                                    C.c_int(q), _dp(out), C.c_int64(p)))
+        return out
+
+    def project(self, c0, k, H, S=None):
+        ld = H.shape[0]
+        sp = _dp(S) if S is not None else C.POINTER(C.c_double)()
+        self._chk(self.lib.dav_project(self.h, C.c_int(c0), C.c_int(k), _dp(H), C.c_int64(ld), sp, C.c_int64(ld)))
+
+    def ritz_residual_correction(self, m, lowest, Y, theta, method=METHOD_DPR):
+        Y = _f(Y)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        res = np.zeros(lowest)
+        self._chk(self.lib.dav_ritz_residual_correction(self.h, C.c_int(m), C.c_int(lowest), _dp(Y),
+                                                        C.c_int64(Y.shape[0]), _dp(theta), C.c_int(method), _dp(res)))
+        return res
+
+    def gjd_correction(self, m, theta, max_inner=500, inner_tol=1e-12):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        it = C.c_int(0)
+        self._chk(self.lib.dav_gjd_correction(self.h, C.c_int(m), _dp(theta), C.c_int(max_inner),
+                                              C.c_double(inner_tol), C.byref(it)))
+        return it.value
+
+    def ortho_gram(self, m, kt):
+        Cm = np.zeros((max(m, 1), kt), order="F")
+        G = np.zeros((kt, kt), order="F")
+        self._chk(self.lib.dav_ortho_gram(self.h, C.c_int(m), C.c_int(kt), _dp(Cm), C.c_int64(max(m, 1)), _dp(G),
+                                          C.c_int64(kt)))
+        return Cm[:m], G
+
+    def ortho_apply(self, m, kt, Cm, M):
+        Cm = _f(Cm) if m > 0 else np.zeros((1, kt), order="F")
+        M = _f(M)
+        self._chk(self.lib.dav_ortho_apply(self.h, C.c_int(m), C.c_int(kt), _dp(Cm), C.c_int64(Cm.shape[0]), _dp(M),
+                                           C.c_int64(M.shape[0])))
+
+    def expand(self, m, kt):
+        self._chk(self.lib.dav_expand(self.h, C.c_int(m), C.c_int(kt)))
+
+    def restart(self, m, keep, Yk):
+        Yk = _f(Yk)
+        self._chk(self.lib.dav_restart(self.h, C.c_int(m), C.c_int(keep), _dp(Yk), C.c_int64(Yk.shape[0])))
+
+    def panel_transform(self, src_panel, s0, p, M, dst_panel, d0):
+        M = _f(M)
+        self._chk(self.lib.dav_panel_transform(self.h, C.c_int(src_panel), C.c_int(s0), C.c_int(p), _dp(M),
+                                               C.c_int64(M.shape[0]), C.c_int(M.shape[1]), C.c_int(dst_panel),
+                                               C.c_int(d0)))
+
+    def panel_get(self, panel, c0, k):
+        out = np.zeros((self.n, k), order="F")
+        self._chk(self.lib.dav_panel_get(self.h, C.c_int(panel), C.c_int(c0), C.c_int(k), _dp(out), C.c_int64(self.n)))
+        return out
+
+    def panel_put(self, panel, c0, data):
+        data = _f(data)
+        self._chk(self.lib.dav_panel_put(self.h, C.c_int(panel), C.c_int(c0), C.c_int(data.shape[1]), _dp(data),
+                                         C.c_int64(data.shape[0])))
+
+    def set_width(self, m):
+        self._chk(self.lib.dav_set_width(self.h, C.c_int(m)))
+
+    def bench_apply(self, k, reps, which=OP_A):
+        ms, nbytes = C.c_double(), C.c_double()
+        self._chk(self.lib.dav_bench_apply(self.h, C.c_int(which), C.c_int(k), C.c_int(reps), C.byref(ms),
+                                           C.byref(nbytes)))
+        return ms.value, nbytes.value

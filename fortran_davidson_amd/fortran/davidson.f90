@@ -1,0 +1,602 @@
+!> MI355X-native block Davidson eigensolver behind the Fortran API of NLESC-JCER/Fortran_Davidson.
+!>
+!> Public surface (drop-in): module `davidson` with the generic `generalized_eigensolver`
+!> (reference: src/davidson.f90:599-625) whose dense and matrix-free specifics keep the reference's
+!> argument lists (src/davidson.f90:51-52, :277-278), plus `free_matmul` (src/davidson.f90:526).
+!> A third specific takes a `davidson_engine` handle so that a matrix already resident in HBM (or a
+!> built-in device operator) can be solved repeatedly without re-uploading.
+!>
+!> Design: the host keeps the control flow of the reference's outer loop (src/davidson.f90:138-229)
+!> and the m x m Rayleigh-Ritz problem (lapack_wrapper); everything N-long lives in HBM behind the
+!> C ABI of include/davidson_hip.h.  Per iteration the device does ONE block sweep of A (the new
+!> basis columns only) instead of the reference's (m+1) sweeps, residues come from the cached A*V
+!> panel, and Householder QR of the whole basis is replaced by a block Gram-Schmidt of the new
+!> columns (same span, hence the same Ritz values, residual norms and iteration counts).
+
+module davidson_device
+  use, intrinsic :: iso_c_binding
+  use numeric_kinds, only: dp
+  use davidson_hip_c
+  use lapack_wrapper, only: lapack_generalized_eigensolver
+  implicit none
+  private
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, &
+       engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
+       engine_set_identity, engine_comm_unique_id, engine_comm_init, &
+       generalized_eigensolver_device, davidson_device_loop, basis_capacity
+
+  !> Handle of a device-resident problem: operators A (and B) plus all work panels in HBM.
+  type :: davidson_engine
+     type(c_ptr) :: h = c_null_ptr
+     integer :: n = 0
+     integer :: max_cols = 0
+     logical :: gev = .false.
+     logical :: device_operators = .true.
+  end type davidson_engine
+
+  abstract interface
+     function block_operator(input_vect) result(output_vect)
+       import :: dp
+       real(dp), dimension(:, :), intent(in) :: input_vect
+       real(dp), dimension(size(input_vect, 1), size(input_vect, 2)) :: output_vect
+     end function block_operator
+  end interface
+
+contains
+
+  !> Widest basis the reference's policy can reach: m starts at 2*lowest and doubles while
+  !> m <= max_dim (src/davidson.f90:195-213), so it may overshoot max_dim once.
+  pure function basis_capacity(lowest, max_dim) result(cap)
+    integer, intent(in) :: lowest, max_dim
+    integer :: cap
+    cap = 2 * lowest
+    do while (cap <= max_dim)
+       cap = 2 * cap
+    end do
+  end function basis_capacity
+
+  subroutine engine_create(eng, n, lowest, max_dim_sub, gev, device, rank, nranks)
+    type(davidson_engine), intent(out) :: eng
+    integer, intent(in) :: n, lowest
+    integer, intent(in), optional :: max_dim_sub, device, rank, nranks
+    logical, intent(in), optional :: gev
+    integer :: max_dim, dev, rk, nr
+    max_dim = 10 * lowest
+    if (present(max_dim_sub)) max_dim = max_dim_sub
+    dev = 0; rk = 0; nr = 1
+    if (present(device)) dev = device
+    if (present(rank)) rk = rank
+    if (present(nranks)) nr = nranks
+    eng%n = n
+    eng%gev = .false.
+    if (present(gev)) eng%gev = gev
+    eng%max_cols = basis_capacity(lowest, max_dim)
+    call check_dav(dav_create(eng%h, int(dev, c_int), int(n, c_int64_t), int(eng%max_cols, c_int), &
+         merge(1_c_int, 0_c_int, eng%gev), int(rk, c_int), int(nr, c_int)), "dav_create")
+  end subroutine engine_create
+
+  subroutine engine_destroy(eng)
+    type(davidson_engine), intent(inout) :: eng
+    if (c_associated(eng%h)) call check_dav(dav_destroy(eng%h), "dav_destroy")
+    eng%h = c_null_ptr
+  end subroutine engine_destroy
+
+  subroutine engine_comm_unique_id(id)
+    character(kind=c_char), intent(out) :: id(128)
+    call check_dav(dav_comm_unique_id(id), "dav_comm_unique_id")
+  end subroutine engine_comm_unique_id
+
+  subroutine engine_comm_init(eng, id)
+    type(davidson_engine), intent(inout) :: eng
+    character(kind=c_char), intent(in) :: id(128)
+    call check_dav(dav_comm_init(eng%h, id), "dav_comm_init")
+  end subroutine engine_comm_init
+
+  !> Upload a host matrix (full storage) as operator A (which=1) or B (which=2).
+  subroutine engine_set_dense(eng, which, matrix)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    real(dp), dimension(:, :), intent(in) :: matrix
+    if (size(matrix, 1) /= eng%n .or. size(matrix, 2) /= eng%n) then
+       print *, "engine_set_dense: matrix must be ", eng%n, " x ", eng%n
+       error stop
+    end if
+    call check_dav(dav_set_dense_host(eng%h, int(which - 1, c_int), matrix, int(size(matrix, 1), c_int64_t)), &
+         "dav_set_dense_host")
+  end subroutine engine_set_dense
+
+  !> generate_diagonal_dominant(n, sparsity[, diag_val]) built directly in HBM (same entries as the
+  !> host function of array_utils with the same seed).
+  subroutine engine_generate_diagonal_dominant(eng, which, sparsity, diag_val, seed)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    real(dp), intent(in) :: sparsity
+    real(dp), intent(in), optional :: diag_val
+    integer, intent(in), optional :: seed
+    integer(c_int64_t) :: s
+    real(c_double) :: dv
+    s = 1
+    if (present(seed)) s = int(seed, c_int64_t)
+    dv = 0.0_dp
+    if (present(diag_val)) dv = diag_val
+    call check_dav(dav_set_dense_generated(eng%h, int(which - 1, c_int), s, sparsity, &
+         merge(1_c_int, 0_c_int, present(diag_val)), dv), "dav_set_dense_generated")
+  end subroutine engine_generate_diagonal_dominant
+
+  !> Same matrix as engine_generate_diagonal_dominant but never stored: entries are generated on
+  !> the fly inside the block matvec (matrix-free device operator).
+  subroutine engine_set_hashed_operator(eng, which, sparsity, diag_val, seed)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    real(dp), intent(in) :: sparsity
+    real(dp), intent(in), optional :: diag_val
+    integer, intent(in), optional :: seed
+    integer(c_int64_t) :: s
+    real(c_double) :: dv
+    s = 1
+    if (present(seed)) s = int(seed, c_int64_t)
+    dv = 0.0_dp
+    if (present(diag_val)) dv = diag_val
+    call check_dav(dav_set_operator_hashed(eng%h, int(which - 1, c_int), s, sparsity, &
+         merge(1_c_int, 0_c_int, present(diag_val)), dv), "dav_set_operator_hashed")
+  end subroutine engine_set_hashed_operator
+
+  !> The operators of the reference's matrix-free tests (src/tests/test_utils.f90:38-116) evaluated
+  !> on the device: which=1 -> cos generator + i on the diagonal, which=2 -> sin generator, unit diagonal.
+  subroutine engine_set_harness_operator(eng, which)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    real(dp), allocatable :: e(:)
+    integer :: i
+    allocate(e(eng%n))
+    do i = 1, eng%n
+       e(i) = exp(real(i) / real(eng%n))      ! single precision on purpose (test_utils.f90:82)
+    end do
+    call check_dav(dav_set_operator_harness(eng%h, int(which - 1, c_int), e), "dav_set_operator_harness")
+  end subroutine engine_set_harness_operator
+
+  subroutine engine_set_identity(eng, which)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    call check_dav(dav_set_operator_identity(eng%h, int(which - 1, c_int)), "dav_set_operator_identity")
+  end subroutine engine_set_identity
+
+  !> Solve with the operators already resident behind `eng` (third specific of the generic).
+  !> Argument meaning as generalized_eigensolver_dense; `eigenvectors` is optional so that a
+  !> benchmark can leave the Ritz vectors on the device.
+  subroutine generalized_eigensolver_device(eng, eigenvalues, eigenvectors, lowest, method, max_iterations, &
+       tolerance, iters, max_dim_sub)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: lowest
+    real(dp), dimension(lowest), intent(out) :: eigenvalues
+    real(dp), dimension(:, :), intent(out), optional :: eigenvectors
+    character(len=*), intent(in) :: method
+    integer, intent(in) :: max_iterations
+    real(dp), intent(in) :: tolerance
+    integer, intent(out) :: iters
+    integer, intent(in), optional :: max_dim_sub
+    integer :: max_dim
+    max_dim = 10 * lowest
+    if (present(max_dim_sub)) max_dim = max_dim_sub
+    if (basis_capacity(lowest, max_dim) > eng%max_cols) then
+       print *, "generalized_eigensolver: engine created for a narrower basis than lowest/max_dim_sub need"
+       error stop
+    end if
+    call davidson_device_loop(eng%h, eng%n, lowest, method, max_iterations, tolerance, iters, max_dim, &
+         eng%gev, .true., eigenvalues)
+    if (present(eigenvectors)) then
+       call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), eigenvectors, &
+            int(size(eigenvectors, 1), c_int64_t)), "dav_panel_get")
+    end if
+  end subroutine generalized_eigensolver_device
+
+  !> The outer loop (control flow of src/davidson.f90:138-229 / :375-441) on a prepared engine.
+  !> sticky = .true. reproduces the dense path's sticky convergence flags (:176), .false. the
+  !> matrix-free path's all-at-once test (:416).  fun_a/fun_b present = operators applied by the
+  !> host through callbacks (API-faithful matrix-free path).
+  subroutine davidson_device_loop(h, n, lowest, method, max_iterations, tolerance, iters, max_dim, gev, &
+       sticky, eigenvalues, fun_a, fun_b)
+    type(c_ptr), intent(in) :: h
+    integer, intent(in) :: n, lowest, max_iterations, max_dim
+    character(len=*), intent(in) :: method
+    real(dp), intent(in) :: tolerance
+    integer, intent(out) :: iters
+    logical, intent(in) :: gev, sticky
+    real(dp), dimension(lowest), intent(out) :: eigenvalues
+    procedure(block_operator), optional :: fun_a, fun_b
+
+    integer :: m, kt, i, j, cap, initial_dimension, meth, inner
+    integer(c_int64_t) :: ld
+    integer(c_int64_t), allocatable :: idx(:)
+    real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
+    logical, allocatable :: has_converged(:)
+    logical :: host_ops, done
+
+    select case (trim(method))
+    case ("DPR")
+       meth = DAV_METHOD_DPR
+    case ("GJD")
+       meth = DAV_METHOD_GJD
+    case default
+       ! the reference leaves the correction undefined here (src/davidson.f90:656-669)
+       print *, "generalized_eigensolver: unknown correction method '", trim(method), "' (DPR or GJD)"
+       error stop
+    end select
+    host_ops = present(fun_a)
+    if (host_ops .and. meth == DAV_METHOD_GJD) meth = DAV_METHOD_DPR    ! free path is DPR only (:428)
+
+    initial_dimension = 2 * lowest
+    cap = basis_capacity(lowest, max_dim)
+    ld = int(cap, c_int64_t)
+    allocate(hm(cap, cap), sm(cap, cap), idx(initial_dimension), errors(lowest), has_converged(lowest))
+    hm = 0.0_dp
+    sm = 0.0_dp
+    has_converged = .false.
+
+    ! 1. initial basis: unit vectors at the lowest diagonal entries; W0 = A*V0
+    m = initial_dimension
+    call check_dav(dav_init_basis(h, int(m, c_int), idx), "dav_init_basis")
+    if (host_ops) call apply_host_block(h, n, 0, m, fun_a, fun_b)
+    ! 2. projected matrices
+    call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
+
+    iters = max_iterations + 1
+    done = .false.
+    outer_loop: do i = 1, max_iterations
+       ! 3. Rayleigh-Ritz on the host (the only LAPACK call on the path)
+       if (allocated(theta)) deallocate(theta, y)
+       allocate(theta(m), y(m, m))
+       if (gev) then
+          call lapack_generalized_eigensolver(hm(1:m, 1:m), theta, y, sm(1:m, 1:m))
+       else
+          call lapack_generalized_eigensolver(hm(1:m, 1:m), theta, y)
+       end if
+
+       ! 4. Ritz vectors, residues, their norms and the DPR correction - one fused device phase
+       call check_dav(dav_ritz_residual_correction(h, int(m, c_int), int(lowest, c_int), y, int(m, c_int64_t), &
+            theta, int(meth, c_int), errors), "dav_ritz_residual_correction")
+       eigenvalues = theta(1:lowest)
+       if (sticky) then
+          do j = 1, lowest
+             if (errors(j) < tolerance) has_converged(j) = .true.
+          end do
+          done = all(has_converged)
+       else
+          done = all(errors < tolerance)
+       end if
+       if (done) then
+          iters = i
+          exit outer_loop
+       end if
+
+       if (m <= max_dim) then
+          ! 5. correction block T (m columns) -> orthonormalise against V and itself -> new basis columns
+          kt = m
+          if (meth == DAV_METHOD_GJD) then
+             call check_dav(dav_gjd_correction(h, int(m, c_int), theta, 500_c_int, 1.0e-12_dp, inner), &
+                  "dav_gjd_correction")
+          end if
+          call block_orthonormalise(h, n, m, kt)
+          ! 6. one block sweep of A over the new columns, then the new rows/columns of H (and S)
+          call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+          if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
+          call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          m = m + kt
+       else
+          ! collapse restart: V <- V*Y(:, 1:2L)   (src/davidson.f90:218)
+          kt = initial_dimension
+          call check_dav(dav_restart(h, int(m, c_int), int(kt, c_int), y, int(m, c_int64_t)), "dav_restart")
+          ! Y is S-orthonormal in the generalized case: make V Euclidean-orthonormal again (the
+          ! reference gets this from its next QR of the whole basis)
+          if (gev) call block_orthonormalise(h, n, 0, kt)
+          call check_dav(dav_expand(h, 0_c_int, int(kt, c_int)), "dav_expand")
+          if (host_ops) call apply_host_block(h, n, 0, kt, fun_a, fun_b)
+          hm = 0.0_dp
+          sm = 0.0_dp
+          call check_dav(dav_project(h, 0_c_int, int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          m = kt
+       end if
+    end do outer_loop
+
+    if (.not. done) then
+       iters = max_iterations + 1
+       print *, "Warning: Algorithm did not converge!!"
+    end if
+  end subroutine davidson_device_loop
+
+  !> Apply host callbacks to basis columns c0+1..c0+k: download the block, call, upload A*V and B*V.
+  subroutine apply_host_block(h, n, c0, k, fun_a, fun_b)
+    type(c_ptr), intent(in) :: h
+    integer, intent(in) :: n, c0, k
+    procedure(block_operator) :: fun_a, fun_b
+    real(dp), allocatable :: blk(:, :), img(:, :)
+    allocate(blk(n, k), img(n, k))
+    call check_dav(dav_panel_get(h, DAV_PANEL_V, int(c0, c_int), int(k, c_int), blk, int(n, c_int64_t)), &
+         "dav_panel_get")
+    img = fun_a(blk)
+    call check_dav(dav_panel_put(h, DAV_PANEL_W, int(c0, c_int), int(k, c_int), img, int(n, c_int64_t)), &
+         "dav_panel_put")
+    img = fun_b(blk)
+    call check_dav(dav_panel_put(h, DAV_PANEL_BV, int(c0, c_int), int(k, c_int), img, int(n, c_int64_t)), &
+         "dav_panel_put")
+  end subroutine apply_host_block
+
+  !> Orthonormalise the kt columns T = V(:, m+1:m+kt) against V(:, 1:m) and among themselves
+  !> (replaces concatenate + lapack_qr of the whole basis, src/davidson.f90:210-213).
+  !> Each pass: one device Gram [V T]^T T, a kt x kt symmetric eigen-decomposition on the host
+  !> (SVQB: T <- (T - V C) D U L^{-1/2}), one device block update.  Two passes give orthonormality to
+  !> rounding; a direction that is numerically dependent (e.g. the correction of an already converged
+  !> pair) is replaced by a deterministic pseudo-random vector, as Householder QR would complete the
+  !> basis with an arbitrary direction.
+  subroutine block_orthonormalise(h, n, m, kt)
+    type(c_ptr), intent(in) :: h
+    integer, intent(in) :: n, m, kt
+    integer, parameter :: max_pass = 6
+    real(dp), parameter :: floor_rel = 1.0e-14_dp
+    real(dp), allocatable :: c(:, :), g(:, :), gp(:, :), d(:), w(:), u(:, :), mm(:, :), vec(:)
+    integer :: pass, j, l, nrep
+    real(dp) :: wmax, wmin
+    logical :: clean
+
+    allocate(c(max(m, 1), kt), g(kt, kt), gp(kt, kt), d(kt), w(kt), u(kt, kt), mm(kt, kt))
+    clean = .false.
+    do pass = 1, max_pass
+       call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
+            int(kt, c_int64_t)), "dav_ortho_gram")
+       gp = g
+       if (m > 0) gp = gp - matmul(transpose(c(1:m, :)), c(1:m, :))
+       ! replace numerically null columns before factoring
+       nrep = 0
+       do j = 1, kt
+          if (.not. (gp(j, j) > tiny(1.0_dp) * 1.0e16_dp)) then
+             nrep = nrep + 1
+             allocate(vec(n))
+             call pseudo_random_vector(vec, m + j + 7919 * pass)
+             call check_dav(dav_panel_put(h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(n, c_int64_t)), &
+                  "dav_panel_put")
+             deallocate(vec)
+          end if
+       end do
+       if (nrep > 0) cycle
+       do j = 1, kt
+          d(j) = 1.0_dp / sqrt(gp(j, j))
+       end do
+       do j = 1, kt
+          do l = 1, kt
+             gp(l, j) = gp(l, j) * d(l) * d(j)
+          end do
+       end do
+       call lapack_generalized_eigensolver(gp, w, u)
+       wmax = maxval(w)
+       wmin = minval(w)
+       do j = 1, kt
+          w(j) = max(w(j), floor_rel * wmax)
+       end do
+       do j = 1, kt
+          do l = 1, kt
+             mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
+          end do
+       end do
+       call check_dav(dav_ortho_apply(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
+            int(kt, c_int64_t)), "dav_ortho_apply")
+       ! a pass that started from a nearly orthonormal block (all scaled Gram eigenvalues close to 1
+       ! and negligible overlap with V) leaves it orthonormal to rounding
+       if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) then
+          clean = .true.
+          exit
+       end if
+    end do
+    if (.not. clean) then
+       print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
+    end if
+  end subroutine block_orthonormalise
+
+  !> Deterministic filler direction (xorshift), entries in (-0.5, 0.5).
+  subroutine pseudo_random_vector(vec, salt)
+    real(dp), intent(out) :: vec(:)
+    integer, intent(in) :: salt
+    integer(c_int64_t) :: s
+    integer :: i
+    s = 88172645463325252_c_int64_t + int(salt, c_int64_t) * 2654435761_c_int64_t
+    do i = 1, size(vec)
+       s = ieor(s, shiftl(s, 13))
+       s = ieor(s, shiftr(s, 7))
+       s = ieor(s, shiftl(s, 17))
+       vec(i) = real(shiftr(s, 11), dp) / 9007199254740992.0_dp - 0.5_dp
+    end do
+  end subroutine pseudo_random_vector
+
+end module davidson_device
+
+
+module davidson_dense
+  use, intrinsic :: iso_c_binding
+  use numeric_kinds, only: dp
+  use davidson_hip_c
+  use davidson_device
+  implicit none
+  private
+  public :: generalized_eigensolver_dense
+
+contains
+
+  !> Dense front-end, argument list of the reference (src/davidson.f90:51-52, :74-83): the matrices
+  !> are uploaded to HBM, solved there and everything is released before returning (the reference
+  !> keeps no state across calls either, src/davidson.f90:238-244).
+  subroutine generalized_eigensolver_dense(matrix, eigenvalues, eigenvectors, lowest, method, max_iterations, &
+       tolerance, iters, max_dim_sub, second_matrix)
+    integer, intent(in) :: lowest
+    real(dp), dimension(:, :), intent(in) :: matrix
+    real(dp), dimension(:, :), intent(in), optional :: second_matrix
+    real(dp), dimension(lowest), intent(out) :: eigenvalues
+    real(dp), dimension(:, :), intent(out) :: eigenvectors
+    integer, intent(in) :: max_iterations
+    integer, intent(in), optional :: max_dim_sub
+    real(dp), intent(in) :: tolerance
+    character(len=*), intent(in) :: method
+    integer, intent(out) :: iters
+
+    type(davidson_engine) :: eng
+    integer :: max_dim
+
+    max_dim = 10 * lowest
+    if (present(max_dim_sub)) max_dim = max_dim_sub
+    call engine_create(eng, size(matrix, 1), lowest, max_dim, present(second_matrix), env_device())
+    call engine_set_dense(eng, 1, matrix)
+    if (present(second_matrix)) call engine_set_dense(eng, 2, second_matrix)
+    call generalized_eigensolver_device(eng, eigenvalues, eigenvectors, lowest, method, max_iterations, &
+         tolerance, iters, max_dim)
+    call engine_destroy(eng)
+  end subroutine generalized_eigensolver_dense
+
+  !> Device index from the environment (DAVIDSON_DEVICE, default 0): an engine knob that does not
+  !> touch the reference's argument lists.
+  function env_device() result(dev)
+    integer :: dev, stat, length
+    character(len=16) :: buf
+    dev = 0
+    call get_environment_variable("DAVIDSON_DEVICE", buf, length, stat)
+    if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) dev
+    if (stat /= 0) dev = 0
+  end function env_device
+
+end module davidson_dense
+
+
+module davidson_free
+  use, intrinsic :: iso_c_binding
+  use numeric_kinds, only: dp
+  use davidson_hip_c
+  use davidson_device
+  implicit none
+  private
+  public :: generalized_eigensolver_free, free_matmul
+
+contains
+
+  !> Matrix-free front-end, argument list of the reference (src/davidson.f90:277-278, :305-337):
+  !> A and B arrive as host callbacks that map a block of vectors.  The basis, A*V, B*V and every
+  !> N-long product live on the GPU; only the NEW basis columns travel to the host for the callback
+  !> (the reference re-applies both operators to the whole basis each iteration, :378-379).
+  !> As in the reference the problem is always generalized and the correction always DPR (:428),
+  !> and convergence is tested on all pairs at once (:416).
+  subroutine generalized_eigensolver_free(fun_matrix_gemv, eigenvalues, ritz_vectors, lowest, method, &
+       max_iterations, tolerance, iters, max_dim_sub, fun_second_matrix_gemv)
+    integer, intent(in) :: lowest
+    real(dp), dimension(lowest), intent(out) :: eigenvalues
+    real(dp), dimension(:, :), intent(out) :: ritz_vectors
+    integer, intent(in) :: max_iterations
+    integer, intent(in), optional :: max_dim_sub
+    real(dp), intent(in) :: tolerance
+    character(len=*), intent(in) :: method
+    integer, intent(out) :: iters
+    interface
+       function fun_matrix_gemv(input_vect) result(output_vect)
+         use numeric_kinds, only: dp
+         real(dp), dimension(:, :), intent(in) :: input_vect
+         real(dp), dimension(size(input_vect, 1), size(input_vect, 2)) :: output_vect
+       end function fun_matrix_gemv
+       function fun_second_matrix_gemv(input_vect) result(output_vect)
+         use numeric_kinds, only: dp
+         real(dp), dimension(:, :), intent(in) :: input_vect
+         real(dp), dimension(size(input_vect, 1), size(input_vect, 2)) :: output_vect
+       end function fun_second_matrix_gemv
+    end interface
+
+    type(davidson_engine) :: eng
+    real(dp), allocatable :: diag_a(:), diag_b(:)
+    integer :: n, max_dim
+
+    n = size(ritz_vectors, 1)
+    max_dim = 10 * lowest
+    if (present(max_dim_sub)) max_dim = max_dim_sub
+    allocate(diag_a(n), diag_b(n))
+    call extract_diagonal_blocked(fun_matrix_gemv, n, diag_a)
+    call extract_diagonal_blocked(fun_second_matrix_gemv, n, diag_b)
+
+    call engine_create(eng, n, lowest, max_dim, .true.)
+    eng%device_operators = .false.
+    call check_dav(dav_set_operator_host(eng%h, DAV_OP_A, diag_a), "dav_set_operator_host")
+    call check_dav(dav_set_operator_host(eng%h, DAV_OP_B, diag_b), "dav_set_operator_host")
+    call davidson_device_loop(eng%h, n, lowest, method, max_iterations, tolerance, iters, max_dim, .true., &
+         .false., eigenvalues, fun_matrix_gemv, fun_second_matrix_gemv)
+    call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), ritz_vectors, &
+         int(size(ritz_vectors, 1), c_int64_t)), "dav_panel_get")
+    call engine_destroy(eng)
+  end subroutine generalized_eigensolver_free
+
+  !> Diagonal of an operator known only through its block apply: same N unit-vector probes as
+  !> extract_diagonal_free (src/davidson.f90:490-523), sent through the callback 64 at a time.
+  subroutine extract_diagonal_blocked(fun, n, diag)
+    integer, intent(in) :: n
+    real(dp), intent(out) :: diag(n)
+    interface
+       function fun(input_vect) result(output_vect)
+         use numeric_kinds, only: dp
+         real(dp), dimension(:, :), intent(in) :: input_vect
+         real(dp), dimension(size(input_vect, 1), size(input_vect, 2)) :: output_vect
+       end function fun
+    end interface
+    integer, parameter :: chunk = 64
+    real(dp), allocatable :: probe(:, :), image(:, :)
+    integer :: i0, k, j
+    do i0 = 1, n, chunk
+       k = min(chunk, n - i0 + 1)
+       allocate(probe(n, k), image(n, k))
+       probe = 0.0_dp
+       do j = 1, k
+          probe(i0 + j - 1, j) = 1.0_dp
+       end do
+       image = fun(probe)
+       do j = 1, k
+          diag(i0 + j - 1) = image(i0 + j - 1, j)
+       end do
+       deallocate(probe, image)
+    end do
+  end subroutine extract_diagonal_blocked
+
+  !> Apply a matrix given by a row generator fun(i, dim) to a block (public helper of the reference,
+  !> src/davidson.f90:526-569).  Host code: it serves user callbacks; rows are independent.
+  function free_matmul(fun, array) result(matrix)
+    real(dp), dimension(:, :), intent(in) :: array
+    real(dp), dimension(size(array, 1), size(array, 2)) :: matrix
+    interface
+       function fun(i, dim) result(vec)
+         use numeric_kinds, only: dp
+         integer, intent(in) :: i
+         integer, intent(in) :: dim
+         real(dp), dimension(dim) :: vec
+       end function fun
+    end interface
+    real(dp), allocatable :: row(:)
+    integer :: i, n
+    n = size(array, 1)
+    !$OMP PARALLEL DO PRIVATE(i, row)
+    do i = 1, n
+       row = fun(i, n)
+       matrix(i, :) = matmul(row, array)
+    end do
+    !$OMP END PARALLEL DO
+  end function free_matmul
+
+end module davidson_free
+
+
+module davidson
+  use numeric_kinds, only: dp
+  use davidson_dense, only: generalized_eigensolver_dense
+  use davidson_free, only: generalized_eigensolver_free
+  use davidson_device, only: generalized_eigensolver_device
+  implicit none
+  private
+  public :: generalized_eigensolver
+
+  !> Generic of the reference (src/davidson.f90:601-625), resolved by the first argument: a matrix,
+  !> a block-apply procedure, or (new) a device-resident `davidson_engine`.
+  interface generalized_eigensolver
+     procedure generalized_eigensolver_dense
+     procedure generalized_eigensolver_free
+     procedure generalized_eigensolver_device
+  end interface generalized_eigensolver
+
+end module davidson

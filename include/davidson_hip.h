@@ -1,0 +1,165 @@
+/* davidson_hip.h - C ABI of the MI355X-native Davidson engine (libdavidson_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of NLESC-JCER/Fortran_Davidson: the body of the
+ * `outer_loop` of generalized_eigensolver_dense (src/davidson.f90:138-229) and
+ * generalized_eigensolver_free (src/davidson.f90:375-441).  The reference is pure Fortran and has
+ * no FFI of its own; these entry points are what its Fortran modules bind through ISO_C_BINDING
+ * (fortran_davidson_amd/fortran/davidson_hip_c.f90) in place of the
+ * BLAS/LAPACK wrapper calls cited on each function.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure (dav_last_error() gives
+ * the text; the Fortran shim prints it and `error stop`s like check_lapack_call,
+ * src/lapack_wrapper.f90:395-408).  All matrices are IEEE binary64, column-major, with explicit
+ * leading dimensions; pointers are HOST pointers unless the name says `_dev`; sizes that can exceed
+ * 2^31 are int64_t.  The engine owns all device memory behind the opaque handle; nothing survives
+ * dav_destroy.  Only the m x m Rayleigh-Ritz problem (DSYEV/DSYGV, src/lapack_wrapper.f90:14-91)
+ * and the k x k basis transforms stay on the host.
+ *
+ * Row-slab sharding (one process per GPU): rank r of P owns global rows [r*nloc, r*nloc+nloc) of A,
+ * B and of every N-long panel; the new basis block is exchanged with one RCCL all-gather, small
+ * Gram blocks with one RCCL all-reduce.  P = 1 uses the same code without communication.
+ */
+#ifndef DAVIDSON_HIP_H
+#define DAVIDSON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dav_engine* dav_handle_t;
+
+/* which operator */
+enum { DAV_OP_A = 0, DAV_OP_B = 1 };
+/* device panels (N-long, column-major, resident in HBM) */
+enum { DAV_PANEL_V = 0,   /* search-space basis V (and, in its tail columns, the correction block T) */
+       DAV_PANEL_W = 1,   /* A*V            (src/davidson.f90:131,223 inner DGEMM)                 */
+       DAV_PANEL_BV = 2,  /* B*V            (src/davidson.f90:134,226)                             */
+       DAV_PANEL_X = 3,   /* Ritz vectors   (src/davidson.f90:159)                                 */
+       DAV_PANEL_R = 4,   /* residues / scratch (src/davidson.f90:163-170)                         */
+       DAV_PANEL_S = 5 }; /* scratch for out-of-place block transforms                             */
+/* correction method (src/davidson.f90:656-669) */
+enum { DAV_METHOD_DPR = 0, DAV_METHOD_GJD = 1 };
+
+typedef struct dav_stats {
+  int64_t n;               /* global order                                                          */
+  int64_t nloc;            /* rows owned by this rank                                               */
+  int32_t nranks, rank;
+  int32_t m;               /* current basis width                                                   */
+  int32_t applies;         /* block applies of A so far                                             */
+  int64_t apply_cols;      /* total columns A was applied to                                        */
+  double apply_ms;         /* device time in the A*X block matvec kernels (HIP events)              */
+  double apply_bytes;      /* algorithmic bytes of those applies: 8*nloc*N + 16*N*k each            */
+  double last_apply_ms;    /* duration of the most recent A apply                                   */
+  double last_apply_bytes;
+  double gram_ms, panel_ms, comm_ms;
+} dav_stats;
+
+const char* dav_last_error(void);
+int dav_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* Create an engine for a problem of order n on `device`.  max_cols bounds the basis width
+ * (2*max_dim as the reference can reach, src/davidson.f90:195-213).  gev != 0 reserves the B*V
+ * panel.  rank/nranks describe the row-slab partition (0/1 for a single GPU). */
+int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, int gev, int rank, int nranks);
+int dav_destroy(dav_handle_t h);
+/* RCCL bootstrap: rank 0 fills a 128-byte id, the launcher (torch.distributed / MPI / a file)
+ * distributes it, every rank calls dav_comm_init.  Not needed when nranks == 1. */
+int dav_comm_unique_id(void* id128);
+int dav_comm_init(dav_handle_t h, const void* id128);
+int dav_synchronize(dav_handle_t h);
+int dav_get_stats(dav_handle_t h, dav_stats* out);
+int dav_reset_stats(dav_handle_t h);
+/* rows of this rank: [row0, row0+nloc) */
+int dav_local_rows(dav_handle_t h, int64_t* row0, int64_t* nloc);
+
+/* ---- operators (replace `matrix` / `second_matrix` / fun_matrix_gemv) ------------------------- */
+/* Dense matrix from host memory, full storage a(lda, n), the caller's array as passed to
+ * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and
+ * extracts the diagonal (replaces array_utils.f90:115-134). */
+int dav_set_dense_host(dav_handle_t h, int which, const double* a, int64_t lda);
+/* Dense matrix generated directly in HBM with the semantics of generate_diagonal_dominant
+ * (src/array_utils.f90:86-113) and the counter-based stream of oracle/davidson_oracle.py. */
+int dav_set_dense_generated(dav_handle_t h, int which, uint64_t seed, double sparsity,
+                            int use_diag_val, double diag_val);
+/* Matrix-free operators evaluated on the fly inside the block matvec (no N x N storage):
+ * the hashed diagonal-dominant operator (same entries as dav_set_dense_generated) ...          */
+int dav_set_operator_hashed(dav_handle_t h, int which, uint64_t seed, double sparsity,
+                            int use_diag_val, double diag_val);
+/* ... the reference test harness operators (src/tests/test_utils.f90:38-116): which==A gives the
+ * cos generator + i on the diagonal, which==B the sin generator with unit diagonal; e_table[n]
+ * holds exp(real(i)/real(n)) as the host evaluates it in single precision ...                   */
+int dav_set_operator_harness(dav_handle_t h, int which, const double* e_table);
+/* ... and B = I (src/benchmark_free.f90:65-76). */
+int dav_set_operator_identity(dav_handle_t h, int which);
+/* The operator is applied by the host (API-faithful callback path of generalized_eigensolver_free,
+ * src/davidson.f90:378-379): the driver moves blocks with dav_panel_get/put.  diag[n] is the
+ * operator's diagonal (what extract_diagonal_free, src/davidson.f90:490-523, computes). */
+int dav_set_operator_host(dav_handle_t h, int which, const double* diag);
+int dav_get_diagonal(dav_handle_t h, int which, double* diag_out /* n, global */);
+
+/* ---- the per-iteration hot path ---------------------------------------------------------------- */
+/* K6 - replaces diagonal + generate_preconditioner + lapack_sort (src/davidson.f90:127-128,
+ * array_utils.f90:136-160): V0 = unit vectors at the ncols smallest diagonal entries (stable order),
+ * W0 = A*V0 (and B*V0).  idx_out[ncols] receives the 1-based positions.  Sets m = ncols. */
+int dav_init_basis(dav_handle_t h, int ncols, int64_t* idx_out);
+/* K1 - replaces lapack_matmul('N','N', matrix, V) (src/davidson.f90:131,223 inner;
+ * lapack_wrapper.f90:279-328): dst[:, d0:d0+k] = Op(which) * src[:, c0:c0+k]. */
+int dav_apply(dav_handle_t h, int which, int src_panel, int c0, int k, int dst_panel, int d0);
+/* K2 - replaces lapack_matmul('T','N', V, .) (src/davidson.f90:131,223 outer):
+ * out(p x q) = P[:, p0:p0+p]^T * Q[:, q0:q0+q], summed over all ranks, returned on the host. */
+int dav_gram(dav_handle_t h, int panel_p, int p0, int p, int panel_q, int q0, int q,
+             double* out, int64_t ldo);
+/* New columns of the projected matrices after the basis grew from c0 to c0+k columns:
+ * H[0:c0+k, c0:c0+k] = V^T W[:, c0:c0+k]; S likewise with B*V when gev (S may be NULL). */
+int dav_project(dav_handle_t h, int c0, int k, double* H, int64_t ldh, double* S, int64_t lds);
+/* K3 - replaces the Ritz-vector DGEMM, the m residual DGEMVs, norm() and compute_DPR_*
+ * (src/davidson.f90:159-178, 673-698, 463-488): with Y (m x m) and theta (m) from the host
+ * eigensolver computes X = V*Y(:, 1:nx), R = W*Y - Z*Y*diag(theta) (Z = B*V when gev else V),
+ * resnorm[j] = ||R(:, j)||_2 for j < lowest and, for DPR, the correction block
+ * T = R ./ (theta_j * diagB_i - diagA_i) written into V[:, m:2m].  For GJD R and X (nx = m) are
+ * left in their panels for dav_gjd_correction. */
+int dav_ritz_residual_correction(dav_handle_t h, int m, int lowest, const double* Y, int64_t ldy,
+                                 const double* theta, int method, double* resnorm);
+/* K7 - replaces compute_GJD_generalized_dense (src/davidson.f90:700-734): solves
+ * (I - x x^T)(A - theta_k B)(I - x x^T) t_k = -r_k for all m Ritz pairs at once with a block
+ * preconditioned MINRES whose operator is the K1 block matvec; T goes to V[:, m:2m]. */
+int dav_gjd_correction(dav_handle_t h, int m, const double* theta, int max_inner, double inner_tol,
+                       int* inner_iters_out);
+/* K4 - replaces concatenate + lapack_qr (src/davidson.f90:210-213): block Gram-Schmidt of the
+ * k = kt correction columns T = V[:, m:m+kt] against V[:, 0:m] and among themselves.
+ * dav_ortho_gram returns C = V^T T (m x kt) and G = T^T T (kt x kt); the host factors
+ * G - C^T C and calls dav_ortho_apply with M (kt x kt): T <- (T - V*C) * M. */
+int dav_ortho_gram(dav_handle_t h, int m, int kt, double* C, int64_t ldc, double* G, int64_t ldg);
+int dav_ortho_apply(dav_handle_t h, int m, int kt, const double* C, int64_t ldc,
+                    const double* M, int64_t ldm);
+/* Commit T as basis columns m..m+kt-1 and apply the operators to them (device operators only):
+ * W[:, m:m+kt] = A*T (one block sweep of A - the only one per iteration), BV likewise. */
+int dav_expand(dav_handle_t h, int m, int kt);
+/* K5 - replaces V = V * Y(:, 1:keep) (src/davidson.f90:218): V, W and B*V are contracted with the
+ * same keep columns of Yk (m x keep); sets m = keep. */
+int dav_restart(dav_handle_t h, int m, int keep, const double* Yk, int64_t ldy);
+/* Generic block transform dst[:, d0:d0+q] = src[:, s0:s0+p] * M (p x q); used for the basis
+ * re-orthonormalisation after a generalized restart. */
+int dav_panel_transform(dav_handle_t h, int src_panel, int s0, int p, const double* M, int64_t ldm,
+                        int q, int dst_panel, int d0);
+
+/* ---- block movement (results, host-operator path, tests) --------------------------------------- */
+/* host(ld, k) <- panel[:, c0:c0+k]: all N rows (gathered over ranks) */
+int dav_panel_get(dav_handle_t h, int panel, int c0, int k, double* out, int64_t ld);
+/* panel[:, c0:c0+k] <- host(ld, k) holding all N rows (each rank keeps its slab) */
+int dav_panel_put(dav_handle_t h, int panel, int c0, int k, const double* in, int64_t ld);
+int dav_set_width(dav_handle_t h, int m);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Time `reps` launches of the A block matvec on k columns with HIP events on the engine's stream
+ * (inputs resident).  Returns average milliseconds per launch and the algorithmic bytes per launch
+ * (8*nloc*N + 16*N*k). */
+int dav_bench_apply(dav_handle_t h, int which, int k, int reps, double* avg_ms, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAVIDSON_HIP_H */

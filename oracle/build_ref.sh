@@ -42,7 +42,7 @@ sed '649s/size(residues, 2)/size(ritz_vectors, 2)/' "$REF/davidson.f90" \
 $FC $FFLAGS -c "$REF/tests/test_utils.f90" -o "$TMP/test_utils.o"
 $FC $FFLAGS -c "$HERE/ref_driver.f90"      -o "$TMP/ref_driver.o"
 
-$FC -shared -fopenmp=libiomp5 -o "$OUT/libref_davidson.so" \
+$FC -shared -Wl,-Bsymbolic -fopenmp=libiomp5 -o "$OUT/libref_davidson.so" \
   "$TMP/ref_driver.o" "$TMP/test_utils.o" "$TMP/davidson.o" "$TMP/array_utils.o" \
   "$TMP/lapack_wrapper.o" "$TMP/numeric_kinds.o" \
   -L"$MKL_DIR" -lmkl_rt -Wl,-rpath,"$MKL_DIR"

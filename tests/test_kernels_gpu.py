@@ -1,0 +1,206 @@
+"""GPU: every HIP kernel family against numpy on the same seeded inputs, through the C ABI."""
+import numpy as np
+import pytest
+
+import fortran_davidson_amd as fd
+from fortran_davidson_amd.engine_c import (OP_A, OP_B, PANEL_V, PANEL_W, PANEL_BV, PANEL_X, PANEL_R, PANEL_S,
+                                           METHOD_DPR, METHOD_GJD)
+from oracle import davidson_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-13      # fp64 products of O(1) data; contraction lengths <= 3000
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("n", [50, 257, 1000])
+def test_generated_matrix_is_bit_identical_to_oracle(n):
+    with fd.CEngine(n=n, max_cols=32) as e:
+        e.set_dense_generated(OP_A, seed=3, sparsity=1e-3)
+        A = O.generate_diagonal_dominant(n, 1e-3, seed=3)
+        assert np.array_equal(e.get_diagonal(OP_A), np.diag(A))
+        # A * e_j is column j exactly (every other product is an exact zero)
+        cols = [0, 1, n // 2, n - 1]
+        X = np.zeros((n, len(cols)))
+        X[cols, range(len(cols))] = 1.0
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, len(cols), PANEL_W, 0)
+        assert np.array_equal(e.panel_get(PANEL_W, 0, len(cols)), A[:, cols])
+        e.set_dense_generated(OP_B, seed=4, sparsity=1e-3, diag_val=1.0) if False else None
+
+
+@pytest.mark.parametrize("n,k", [(50, 1), (50, 6), (300, 8), (300, 16), (777, 17), (1000, 32), (1000, 48),
+                                 (1000, 64), (600, 100), (2500, 24)])
+def test_block_matvec_dense(n, k):
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    X = rng.standard_normal((n, k))
+    with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
+        e.set_dense_host(OP_A, A)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        W = e.panel_get(PANEL_W, 0, k)
+        assert relerr(W, A @ X) < RTOL * n
+        # column offsets on both sides
+        if k >= 6:
+            e.apply(OP_A, PANEL_V, 2, 3, PANEL_S, 1)
+            assert relerr(e.panel_get(PANEL_S, 1, 3), A @ X[:, 2:5]) < RTOL * n
+        st = e.stats()
+        assert st.applies >= 1 and st.apply_bytes > 0
+
+
+@pytest.mark.parametrize("kind", ["hashed", "harness"])
+def test_block_matvec_matrix_free(kind):
+    n, k = 300, 9
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, k))
+    with fd.CEngine(n=n, max_cols=16, gev=True) as e:
+        if kind == "hashed":
+            e.set_operator_hashed(OP_A, 11, 1e-3)
+            e.set_operator_hashed(OP_B, 12, 1e-3, 1.0)
+            A = O.generate_diagonal_dominant(n, 1e-3, seed=11)
+            B = O.generate_diagonal_dominant(n, 1e-3, 1.0, seed=12)
+        else:
+            tab = O.harness_exp_table(n)
+            e.set_operator_harness(OP_A, tab)
+            e.set_operator_harness(OP_B, tab)
+            A, B = O.harness_matrices(n)
+        assert np.allclose(e.get_diagonal(OP_A), np.diag(A), rtol=1e-14)
+        assert np.allclose(e.get_diagonal(OP_B), np.diag(B), rtol=1e-14)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        e.apply(OP_B, PANEL_V, 0, k, PANEL_BV, 0)
+        assert relerr(e.panel_get(PANEL_W, 0, k), A @ X) < 1e-12
+        assert relerr(e.panel_get(PANEL_BV, 0, k), B @ X) < 1e-12
+
+
+def test_identity_operator_and_edge_shapes():
+    n = 40
+    X = np.random.default_rng(1).standard_normal((n, 5))
+    with fd.CEngine(n=n, max_cols=16, gev=True) as e:
+        e.set_operator_identity(OP_B)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_B, PANEL_V, 0, 5, PANEL_BV, 0)
+        assert np.array_equal(e.panel_get(PANEL_BV, 0, 5), X)
+        with pytest.raises(fd.DavidsonHipError):
+            e.apply(OP_A, PANEL_V, 0, 5, PANEL_W, 0)       # operator A not set
+        with pytest.raises(fd.DavidsonHipError):
+            e.panel_get(PANEL_V, 0, 10_000)                # out of range
+
+
+@pytest.mark.parametrize("n,p,q", [(50, 6, 6), (300, 12, 6), (1000, 16, 16), (1000, 40, 24), (2100, 128, 64),
+                                   (999, 33, 17)])
+def test_gram(n, p, q):
+    rng = np.random.default_rng(p * q)
+    P = rng.standard_normal((n, p))
+    Q = rng.standard_normal((n, q))
+    with fd.CEngine(n=n, max_cols=max(p, q)) as e:
+        e.panel_put(PANEL_V, 0, P)
+        e.panel_put(PANEL_W, 0, Q)
+        G = e.gram(PANEL_V, 0, p, PANEL_W, 0, q)
+        assert relerr(G, P.T @ Q) < RTOL * n
+        # run-to-run reproducible (fixed-order reduction, no atomics)
+        assert np.array_equal(G, e.gram(PANEL_V, 0, p, PANEL_W, 0, q))
+        if p > 4 and q > 3:
+            G2 = e.gram(PANEL_V, 2, p - 4, PANEL_W, 1, q - 3)
+            assert relerr(G2, P[:, 2:p - 2].T @ Q[:, 1:q - 2]) < RTOL * n
+
+
+@pytest.mark.parametrize("n,p,q", [(50, 6, 6), (300, 12, 3), (1000, 64, 64), (777, 30, 18), (1500, 128, 16)])
+def test_panel_transform(n, p, q):
+    rng = np.random.default_rng(p + q)
+    P = rng.standard_normal((n, p))
+    M = rng.standard_normal((p, q))
+    with fd.CEngine(n=n, max_cols=max(p, q)) as e:
+        e.panel_put(PANEL_V, 0, P)
+        e.panel_transform(PANEL_V, 0, p, M, PANEL_X, 0)
+        assert relerr(e.panel_get(PANEL_X, 0, q), P @ M) < RTOL * p
+        e.panel_transform(PANEL_V, 0, p, M, PANEL_V, 0)          # in place (restart shape)
+        assert relerr(e.panel_get(PANEL_V, 0, q), P @ M) < RTOL * p
+
+
+@pytest.mark.parametrize("gev", [False, True])
+@pytest.mark.parametrize("n,m,L", [(50, 6, 3), (400, 12, 3), (1000, 32, 8), (1300, 64, 8)])
+def test_ritz_residual_dpr_phase(n, m, L, gev):
+    rng = np.random.default_rng(n + m)
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=2)
+    B = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=3) if gev else None
+    V = np.linalg.qr(rng.standard_normal((n, m)))[0]
+    W = A @ V
+    BV = B @ V if gev else V
+    H = V.T @ W
+    S = V.T @ BV if gev else None
+    theta, Y = O.lapack_generalized_eigensolver(H, S)
+    with fd.CEngine(n=n, max_cols=2 * m, gev=gev) as e:
+        e.set_dense_host(OP_A, A)
+        if gev:
+            e.set_dense_host(OP_B, B)
+        e.panel_put(PANEL_V, 0, V)
+        e.panel_put(PANEL_W, 0, W)
+        if gev:
+            e.panel_put(PANEL_BV, 0, BV)
+        res = e.ritz_residual_correction(m, L, Y, theta, METHOD_DPR)
+        X = V @ Y
+        R = W @ Y - (BV @ Y) * theta[None, :]
+        assert relerr(e.panel_get(PANEL_X, 0, L), X[:, :L]) < 1e-12
+        assert np.allclose(res, np.linalg.norm(R[:, :L], axis=0), rtol=1e-9, atol=1e-13)
+        T = O.compute_DPR_generalized_dense(A, theta, R, B)
+        Tdev = e.panel_get(PANEL_V, m, m)
+        assert relerr(Tdev, T) < 1e-9            # R carries cancellation; compare at residual accuracy
+        # GJD mode leaves raw residues and all m Ritz vectors
+        res2 = e.ritz_residual_correction(m, L, Y, theta, METHOD_GJD)
+        assert np.allclose(res2, res, rtol=1e-12)
+        assert relerr(e.panel_get(PANEL_R, 0, m), R) < 1e-11
+        assert relerr(e.panel_get(PANEL_X, 0, m), X) < 1e-12
+
+
+@pytest.mark.parametrize("n,m,kt", [(60, 6, 6), (500, 16, 16), (1200, 64, 64), (300, 0, 8)])
+def test_block_gram_schmidt_phase(n, m, kt):
+    rng = np.random.default_rng(m + kt)
+    V = np.linalg.qr(rng.standard_normal((n, max(m, 1))))[0][:, :m]
+    T = rng.standard_normal((n, kt)) + (V @ rng.standard_normal((m, kt)) if m else 0)
+    with fd.CEngine(n=n, max_cols=m + kt) as e:
+        if m:
+            e.panel_put(PANEL_V, 0, V)
+        e.panel_put(PANEL_V, m, T)
+        for _ in range(2):
+            Cm, G = e.ortho_gram(m, kt)
+            Gp = G - Cm.T @ Cm
+            w, U = np.linalg.eigh(Gp)
+            M = U / np.sqrt(w)[None, :]
+            e.ortho_apply(m, kt, Cm, M)
+        Q = e.panel_get(PANEL_V, 0, m + kt)
+        assert np.abs(Q.T @ Q - np.eye(m + kt)).max() < 1e-13
+        # same span as [V, T]
+        full = np.hstack([V, T])
+        assert np.linalg.norm(full - Q @ (Q.T @ full)) < 1e-10 * np.linalg.norm(full)
+
+
+def test_init_basis_expand_project_restart():
+    n, L = 500, 4
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=6)
+    A[np.arange(n), np.arange(n)] = np.random.default_rng(0).permutation(n) + 1.0   # scrambled diagonal
+    with fd.CEngine(n=n, max_cols=32) as e:
+        e.set_dense_host(OP_A, A)
+        idx = e.init_basis(2 * L)
+        assert np.array_equal(idx - 1, O.lowest_diagonal_indices(np.diag(A), 2 * L))
+        V0 = e.panel_get(PANEL_V, 0, 2 * L)
+        assert np.array_equal(V0, O.generate_preconditioner(np.diag(A).copy(), 2 * L))
+        assert np.array_equal(e.panel_get(PANEL_W, 0, 2 * L), A[:, idx - 1])
+        H = np.zeros((32, 32), order="F")
+        e.project(0, 2 * L, H)
+        assert np.allclose(H[:8, :8], V0.T @ A @ V0, atol=1e-13)
+        # grow by a random orthonormal block
+        T = np.linalg.qr(np.random.default_rng(1).standard_normal((n, 8)))[0]
+        e.panel_put(PANEL_V, 8, T)
+        e.expand(8, 8)
+        e.project(8, 8, H)
+        V = e.panel_get(PANEL_V, 0, 16)
+        assert np.allclose(H[:16, :16], V.T @ A @ V, atol=1e-12)
+        assert np.allclose(e.panel_get(PANEL_W, 0, 16), A @ V, atol=1e-12)
+        Y = np.linalg.qr(np.random.default_rng(2).standard_normal((16, 16)))[0]
+        e.restart(16, 8, Y)
+        assert np.allclose(e.panel_get(PANEL_V, 0, 8), V @ Y[:, :8], atol=1e-13)
