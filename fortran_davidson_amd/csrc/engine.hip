@@ -625,7 +625,7 @@ extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, c
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
   // X = V * Y(:, 1:nx)
-  int nx = method == DAV_METHOD_GJD ? m : lowest;
+  int nx = method == DAV_METHOD_DPR ? lowest : (method == DAV_METHOD_GJD ? m : lowest);
   PanelGemmArgs a{};
   a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = e->sm[0].dev; a.ldm1 = ldm_y;
   a.p2 = 0;

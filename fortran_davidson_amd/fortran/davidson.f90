@@ -205,7 +205,7 @@ contains
     real(dp), dimension(lowest), intent(out) :: eigenvalues
     procedure(block_operator), optional :: fun_a, fun_b
 
-    integer :: m, kt, i, j, cap, initial_dimension, meth, inner
+    integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase
     integer(c_int64_t) :: ld
     integer(c_int64_t), allocatable :: idx(:)
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
@@ -253,8 +253,10 @@ contains
        end if
 
        ! 4. Ritz vectors, residues, their norms and the DPR correction - one fused device phase
+       phase = meth
+       if (m > max_dim) phase = DAV_METHOD_NONE      ! this iteration ends in a restart: no correction block
        call check_dav(dav_ritz_residual_correction(h, int(m, c_int), int(lowest, c_int), y, int(m, c_int64_t), &
-            theta, int(meth, c_int), errors), "dav_ritz_residual_correction")
+            theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
        eigenvalues = theta(1:lowest)
        if (sticky) then
           do j = 1, lowest

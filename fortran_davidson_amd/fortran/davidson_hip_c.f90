@@ -8,7 +8,7 @@ module davidson_hip_c
   integer(c_int), parameter :: DAV_OP_A = 0, DAV_OP_B = 1
   integer(c_int), parameter :: DAV_PANEL_V = 0, DAV_PANEL_W = 1, DAV_PANEL_BV = 2, DAV_PANEL_X = 3, &
        DAV_PANEL_R = 4, DAV_PANEL_S = 5
-  integer(c_int), parameter :: DAV_METHOD_DPR = 0, DAV_METHOD_GJD = 1
+  integer(c_int), parameter :: DAV_METHOD_DPR = 0, DAV_METHOD_GJD = 1, DAV_METHOD_NONE = 2
 
   type, bind(C) :: dav_stats
      integer(c_int64_t) :: n, nloc

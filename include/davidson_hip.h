@@ -40,7 +40,8 @@ enum { DAV_PANEL_V = 0,   /* search-space basis V (and, in its tail columns, the
        DAV_PANEL_R = 4,   /* residues / scratch (src/davidson.f90:163-170)                         */
        DAV_PANEL_S = 5 }; /* scratch for out-of-place block transforms                             */
 /* correction method (src/davidson.f90:656-669) */
-enum { DAV_METHOD_DPR = 0, DAV_METHOD_GJD = 1 };
+enum { DAV_METHOD_DPR = 0, DAV_METHOD_GJD = 1,
+       DAV_METHOD_NONE = 2 /* residues and norms only: the iteration will restart, no correction */ };
 
 typedef struct dav_stats {
   int64_t n;               /* global order                                                          */
