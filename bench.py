@@ -52,15 +52,15 @@ CPU_CHILD = r"""
 import ctypes, json, os, sys, time
 sys.path.insert(0, {root!r})
 import numpy as np
-n, lowest, sparsity, tol = {n}, {lowest}, {sparsity}, {tol}
-import fortran_davidson_amd as fd            # host-side generator only (no GPU call)
-A = fd.generate_diagonal_dominant(n, sparsity, None, 1)
-from oracle import ref, davidson_oracle as O
-out = dict(n=n)
+lowest, tol = {lowest}, {tol}
+A = np.load({path!r}, mmap_mode="r")
+A = np.asfortranarray(A)
+from oracle import ref, davidson_oracle as O        # never imports the product, never touches the GPU
+out = dict(n=int(A.shape[0]))
 if ref.available():
+    ref.lib()
     try:
-        mkl = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so")
-        threads = int(mkl.mkl_get_max_threads())
+        threads = int(ctypes.CDLL("/opt/conda/lib/libmkl_rt.so").mkl_get_max_threads())
     except Exception:
         threads = os.cpu_count()
     t = time.perf_counter(); lam, vec, it = ref.dense_solve(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
@@ -74,12 +74,19 @@ print("CPU_BASELINE " + json.dumps(out))
 
 def cpu_baseline(n, lowest, sparsity, tol):
     """The reference's own CPU+LAPACK path (oracle/_ref = the reference compiled with flang + MKL) on
-    the same generate_diagonal_dominant input, timed in a child process that never touches the GPU
-    (and never imports torch, whose libgomp breaks threaded MKL)."""
-    code = CPU_CHILD.format(root=ROOT, n=n, lowest=lowest, sparsity=sparsity, tol=tol)
-    env = dict(os.environ)
-    env["HIP_VISIBLE_DEVICES"] = ""
+    the same generate_diagonal_dominant input, timed in a child process that never touches the GPU,
+    never imports torch (its libgomp breaks threaded MKL) and never loads the product libraries
+    (they pin MKL to its sequential layer).  The input is written by the host-side Fortran generator
+    of the product (bit-identical to the device generator) to a scratch file."""
+    import tempfile
+    import numpy as np
+    import fortran_davidson_amd as fd
+    path = os.path.join(tempfile.gettempdir(), f"davidson_cpu_baseline_{os.getpid()}.npy")
     try:
+        np.save(path, fd.generate_diagonal_dominant(n, sparsity, None, 1))
+        code = CPU_CHILD.format(root=ROOT, lowest=lowest, tol=tol, path=path)
+        env = dict(os.environ)
+        env["HIP_VISIBLE_DEVICES"] = ""
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
         for line in res.stdout.splitlines():
             if line.startswith("CPU_BASELINE "):
@@ -87,6 +94,23 @@ def cpu_baseline(n, lowest, sparsity, tol):
         return {"error": (res.stderr or res.stdout)[-400:]}
     except Exception as exc:       # noqa: BLE001
         return {"error": repr(exc)}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+
+
+def pmc_traffic(n):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/), which
+    was collected with rocprofv3 on this same command; None when no summary matches the workload."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_n{n}.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+        vals = [k[name]["hbm_bytes_per_launch_corrected"] for name in ("matvec_dense_kernel<1>", "matvec_dense_kernel<2>")
+                if name in k]
+        return round(sum(vals) / len(vals), 0) if vals else None
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def main():
@@ -154,7 +178,7 @@ def main():
     ach = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "matvec_dense_kernel<NT> (A*V block matvec, full storage)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": None, "launches": int(st.applies), "avg_launch_ms": round(st.apply_ms / max(st.applies, 1), 4),
+                "traffic": pmc_traffic(n) if world == 1 else None, "launches": int(st.applies), "avg_launch_ms": round(st.apply_ms / max(st.applies, 1), 4),
                 "algorithmic_bytes_per_launch": round(st.apply_bytes / max(st.applies, 1), 0),
                 "note": "per-rank; bytes = 8*nloc*N + 16*N*k per launch (SURVEY 8d)"}
     phase = {"apply_ms": round(st.apply_ms / args.steps, 4), "gram_ms": round(st.gram_ms / args.steps, 4),
