@@ -101,14 +101,19 @@ void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a) {
   }
 }
 
-__global__ void norm_finish_kernel(const double* __restrict__ partial, int nblocks, int nnorm, double* __restrict__ out) {
-  int j = threadIdx.x;
+// out[j] = sum_b partial[b][j]: one wave per output column, lanes stride over the blocks, fixed
+// shuffle tree -> reproducible.  (A single-thread serial sum cost 20 us at 157 blocks.)
+__global__ __launch_bounds__(256) void norm_finish_kernel(const double* __restrict__ partial, int nblocks, int nnorm,
+                                                          double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= nnorm) return;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * nnorm + j];
-  out[j] = s;     // squared norm; the all-reduce (multi-GPU) and sqrt happen on the host side
+  for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * nnorm + j];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) out[j] = s;     // squared norm / dot; all-reduce (multi-GPU) and sqrt happen on the host side
 }
 
 void launch_norm_finish(hipStream_t st, const double* partial, int nblocks, int nnorm, double* out) {
-  hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, nnorm, out);
+  hipLaunchKernelGGL(norm_finish_kernel, dim3((nnorm + 3) / 4), dim3(256), 0, st, partial, nblocks, nnorm, out);
 }

@@ -64,5 +64,19 @@ void launch_unit_columns(hipStream_t st, const int64_t* idx_dev, int k, int64_t 
                          int64_t nrows_pad, double* dst, int64_t ldd);
 void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd,
                          int64_t nrows_pad, int k);
-// elementwise helpers for the GJD inner solver (k_gjd.hip)
-struct GjdArgs;
+
+
+
+// ---- K7 helpers (k_gjd.hip) ------------------------------------------------------------------------
+struct LincombArgs {      // out[:, j] = sum_t coef[t*ldc + j] * in[t][:, j]
+  const double* in[4]; const double* coef; int ldc; int nterms;
+  double* out; int64_t ld; int64_t nrows_pad; int m;
+};
+void launch_lincomb(hipStream_t st, const LincombArgs& a);
+void launch_precond(hipStream_t st, const double* in, double* out, int64_t ld, int64_t nloc, int64_t nrows_pad, int m,
+                    const double* theta, const double* dA, const double* dB, const double* active);
+struct DotsArgs {         // partial[block][s*m + j] = <a[s][:, j], b[s][:, j]> over the block's rows
+  const double* a[4]; const double* b[4]; int npairs; int64_t ld; int64_t nrows_pad; int m; double* partial;
+};
+int coldots_blocks(int64_t nrows_pad);
+void launch_coldots(hipStream_t st, const DotsArgs& a);

@@ -275,7 +275,7 @@ contains
           ! 5. correction block T (m columns) -> orthonormalise against V and itself -> new basis columns
           kt = m
           if (meth == DAV_METHOD_GJD) then
-             call check_dav(dav_gjd_correction(h, int(m, c_int), theta, 500_c_int, 1.0e-12_dp, inner), &
+             call check_dav(dav_gjd_correction(h, int(m, c_int), theta, 300_c_int, 1.0e-10_dp, inner), &
                   "dav_gjd_correction")
           end if
           call block_orthonormalise(h, n, m, kt)
