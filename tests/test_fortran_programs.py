@@ -1,0 +1,96 @@
+"""The Fortran boundary as a Fortran user sees it: programs that `use davidson` compile and link
+against our modules (CPU), run on the GPU and agree with the golden values of the reference.
+Where /root/reference is present (build container only) the reference's OWN test programs are
+compiled, unchanged, against our modules - the source-compatibility proof of the drop-in API."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FC = "/opt/rocm/lib/llvm/bin/flang"
+MODDIR = os.path.join(ROOT, "fortran_davidson_amd", "fortran", "build")
+LIBDIR = os.path.join(ROOT, "fortran_davidson_amd", "lib")
+SRC = os.path.join(ROOT, "tests", "fortran")
+REF_TESTS = "/root/reference/src/tests"
+
+needs_flang = pytest.mark.skipif(not os.path.exists(FC), reason="flang not available")
+
+
+def compile_link(sources, exe, workdir):
+    cmd = [FC, "-O1", "-fopenmp=libiomp5", f"-I{MODDIR}", "-module-dir", str(workdir), *sources,
+           f"-L{LIBDIR}", "-lfortran_davidson_amd", "-ldavidson_hip", f"-Wl,-rpath,{LIBDIR}",
+           "-L/opt/conda/lib", "-Wl,-rpath,/opt/conda/lib", "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=workdir)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return exe
+
+
+def build_programs(tmp_path):
+    # the build travels: binaries are created under tests/fortran/_bin (git-ignored)
+    bindir = os.path.join(SRC, "_bin")
+    os.makedirs(bindir, exist_ok=True)
+    dense = compile_link([os.path.join(SRC, "prog_dense.f90")], os.path.join(bindir, "prog_dense"), tmp_path)
+    free = compile_link([os.path.join(SRC, "harness_ops.f90"), os.path.join(SRC, "prog_free.f90")],
+                        os.path.join(bindir, "prog_free"), tmp_path)
+    return dense, free
+
+
+@needs_flang
+def test_user_programs_compile_and_link(tmp_path):
+    if not os.path.isdir(MODDIR):
+        pytest.skip("module files not built")
+    dense, free = build_programs(tmp_path)
+    assert os.path.exists(dense) and os.path.exists(free)
+
+
+@needs_flang
+@pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="reference sources only exist in the build container")
+@pytest.mark.parametrize("prog", ["test_dense_properties", "test_free_properties", "test_dense_numpy",
+                                  "test_free_numpy", "test_call_lapack"])
+def test_reference_test_programs_compile_against_our_modules(tmp_path, prog):
+    """Unmodified reference test sources + OUR modules: must compile and link (they run on a GPU box)."""
+    srcs = [os.path.join(REF_TESTS, "test_utils.f90"), os.path.join(REF_TESTS, prog + ".f90")]
+    compile_link(srcs, str(tmp_path / prog), tmp_path)
+
+
+def _run(exe):
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    return res.returncode, res.stdout + res.stderr
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_dense_program_runs_on_gpu(golden, tmp_path):
+    manifest, arrays = golden
+    dense, _ = build_programs(tmp_path)
+    rc, out = _run(dense)
+    assert rc == 0, out
+    checks = re.findall(r"CHECK (\S+) ([TF])", out)
+    assert len(checks) >= 10 and all(v == "T" for _, v in checks), out
+    iters = [int(x) for x in re.search(r"ITERS\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)", out).groups()]
+    gold = manifest["dense"]
+    assert iters == [gold["c1_n50_std_dpr"]["iters"], gold["c1_n50_std_gjd"]["iters"],
+                     gold["c1_n50_gev_dpr"]["iters"], gold["c1_n50_gev_gjd"]["iters"]]
+    ev = np.array([float(x) for x in re.search(r"EVALS_DPR(.*)", out).group(1).split()])
+    assert np.abs(ev - arrays["c1_n50_std_dpr__evals"]).max() < 1e-8
+    ev = np.array([float(x) for x in re.search(r"EVALS_GEN(.*)", out).group(1).split()])
+    assert np.abs(ev - arrays["c1_n50_gev_dpr__evals"]).max() < 1e-8
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_free_program_runs_on_gpu(golden, tmp_path):
+    manifest, arrays = golden
+    _, free = build_programs(tmp_path)
+    rc, out = _run(free)
+    assert rc == 0, out
+    checks = re.findall(r"CHECK (\S+) ([TF])", out)
+    assert len(checks) >= 4 and all(v == "T" for _, v in checks), out
+    ev = np.array([float(x) for x in re.search(r"EVALS_FREE(.*)", out).group(1).split()])
+    assert np.abs(ev - arrays["free_n50__evals"]).max() < 1e-8
+    iters = [int(x) for x in re.search(r"ITERS\s+(\d+)\s+(\d+)", out).groups()]
+    assert iters[0] == manifest["free"]["free_n50"]["iters"]

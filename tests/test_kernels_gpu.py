@@ -204,3 +204,12 @@ def test_init_basis_expand_project_restart():
         Y = np.linalg.qr(np.random.default_rng(2).standard_normal((16, 16)))[0]
         e.restart(16, 8, Y)
         assert np.allclose(e.panel_get(PANEL_V, 0, 8), V @ Y[:, :8], atol=1e-13)
+
+
+def test_row_partition_matches_engine():
+    from fortran_davidson_amd.distributed import RowPartition
+    for n, p in [(1000, 1), (1000, 3), (50, 2), (20000, 8)]:
+        for r in range(p):
+            with fd.CEngine(n=n, max_cols=16, rank=r, nranks=p) as e:
+                part = RowPartition(n, p, r)
+                assert e.local_rows() == (part.row0, part.nloc)
