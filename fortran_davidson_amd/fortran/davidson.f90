@@ -34,6 +34,12 @@ module davidson_device
      logical :: device_operators = .true.
   end type davidson_engine
 
+  !> Wall time of the last solve by phase (seconds): 1 setup (init basis + first projection),
+  !> 2 host Rayleigh-Ritz (DSYEV/DSYGV), 3 Ritz/residue/correction phase, 4 orthonormalisation,
+  !> 5 operator apply (expand), 6 projection, 7 restart, 8 GJD inner solves.  Printed when the
+  !> environment variable DAVIDSON_VERBOSE is set; never printed otherwise (drop-in silence).
+  real(dp), save, public :: last_phase_seconds(8) = 0.0_dp
+
   abstract interface
      function block_operator(input_vect) result(output_vect)
        import :: dp
@@ -211,7 +217,9 @@ contains
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
     logical, allocatable :: has_converged(:)
     logical :: host_ops, done
+    real(dp) :: t0, t1
 
+    last_phase_seconds = 0.0_dp
     select case (trim(method))
     case ("DPR")
        meth = DAV_METHOD_DPR
@@ -235,10 +243,12 @@ contains
 
     ! 1. initial basis: unit vectors at the lowest diagonal entries; W0 = A*V0
     m = initial_dimension
+    t0 = tick()
     call check_dav(dav_init_basis(h, int(m, c_int), idx), "dav_init_basis")
     if (host_ops) call apply_host_block(h, n, 0, m, fun_a, fun_b)
     ! 2. projected matrices
     call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
+    call lap(1)
 
     iters = max_iterations + 1
     done = .false.
@@ -251,12 +261,14 @@ contains
        else
           call lapack_generalized_eigensolver(hm(1:m, 1:m), theta, y)
        end if
+       call lap(2)
 
        ! 4. Ritz vectors, residues, their norms and the DPR correction - one fused device phase
        phase = meth
        if (m > max_dim) phase = DAV_METHOD_NONE      ! this iteration ends in a restart: no correction block
        call check_dav(dav_ritz_residual_correction(h, int(m, c_int), int(lowest, c_int), y, int(m, c_int64_t), &
             theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
+       call lap(3)
        eigenvalues = theta(1:lowest)
        if (sticky) then
           do j = 1, lowest
@@ -277,12 +289,16 @@ contains
           if (meth == DAV_METHOD_GJD) then
              call check_dav(dav_gjd_correction(h, int(m, c_int), theta, 300_c_int, 1.0e-10_dp, inner), &
                   "dav_gjd_correction")
+             call lap(8)
           end if
           call block_orthonormalise(h, n, m, kt)
+          call lap(4)
           ! 6. one block sweep of A over the new columns, then the new rows/columns of H (and S)
           call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
           if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
+          call lap(5)
           call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          call lap(6)
           m = m + kt
        else
           ! collapse restart: V <- V*Y(:, 1:2L)   (src/davidson.f90:218)
@@ -291,11 +307,14 @@ contains
           ! Y is S-orthonormal in the generalized case: make V Euclidean-orthonormal again (the
           ! reference gets this from its next QR of the whole basis)
           if (gev) call block_orthonormalise(h, n, 0, kt)
+          call lap(7)
           call check_dav(dav_expand(h, 0_c_int, int(kt, c_int)), "dav_expand")
           if (host_ops) call apply_host_block(h, n, 0, kt, fun_a, fun_b)
+          call lap(5)
           hm = 0.0_dp
           sm = 0.0_dp
           call check_dav(dav_project(h, 0_c_int, int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          call lap(6)
           m = kt
        end if
     end do outer_loop
@@ -304,7 +323,36 @@ contains
        iters = max_iterations + 1
        print *, "Warning: Algorithm did not converge!!"
     end if
+    if (verbose()) then
+       print "(a, i0, a, i0, a, 8f9.3)", "davidson: n=", n, " iters=", iters, &
+            " ms[setup rr ritz ortho apply project restart gjd]=", last_phase_seconds * 1.0e3_dp
+    end if
+
+  contains
+
+    subroutine lap(slot)
+      integer, intent(in) :: slot
+      t1 = tick()
+      last_phase_seconds(slot) = last_phase_seconds(slot) + (t1 - t0)
+      t0 = t1
+    end subroutine lap
+
   end subroutine davidson_device_loop
+
+  function tick() result(t)
+    real(dp) :: t
+    integer(c_int64_t) :: count, rate
+    call system_clock(count, rate)
+    t = real(count, dp) / real(rate, dp)
+  end function tick
+
+  function verbose() result(on)
+    logical :: on
+    integer :: stat, length
+    character(len=8) :: buf
+    call get_environment_variable("DAVIDSON_VERBOSE", buf, length, stat)
+    on = (stat == 0 .and. length > 0)
+  end function verbose
 
   !> Apply host callbacks to basis columns c0+1..c0+k: download the block, call, upload A*V and B*V.
   subroutine apply_host_block(h, n, c0, k, fun_a, fun_b)

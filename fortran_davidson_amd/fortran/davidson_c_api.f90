@@ -195,6 +195,11 @@ contains
     iters = it
   end subroutine fd_engine_solve
 
+  subroutine fd_last_phase_seconds(out) bind(C, name="fd_last_phase_seconds")
+    real(c_double), intent(out) :: out(8)
+    out = last_phase_seconds
+  end subroutine fd_last_phase_seconds
+
   ! ---- helper modules (unit tests mirror src/tests/test_call_lapack.f90) ----------------------------
   subroutine fd_lapack_eigensolver(n, mtx, has_stx, stx, evals, evecs) bind(C, name="fd_lapack_eigensolver")
     integer(c_int), value :: n, has_stx
