@@ -85,6 +85,7 @@ struct OpDesc {
   int trig = 0;
   double* e_table = nullptr; // device
   double* diag = nullptr;    // device, nloc_pad (local rows)
+  int storage = 0;           // dense: 0 = full, 1 = symmetric-tiled (lower block triangle)
 };
 
 struct SmallBuf {            // device small matrix + pinned staging
@@ -117,6 +118,12 @@ struct dav_engine {
   int64_t* idx_dev = nullptr;
   double* norm_partial = nullptr;
   double* gjd_ws = nullptr;       // GJD inner-solver workspace (lazy)
+  int storage = 0;                // storage mode for dense operators set after dav_set_storage
+  int sym_nb = 0, sym_nitems = 0; // symmetric-tiled sweep: block rows, work items (runs of tiles)
+  int* sym_items = nullptr;       // device: (I, J0, J1) per item
+  int* sym_row_begin = nullptr;   // device: first item of each block row (nb + 1)
+  double* sym_slab = nullptr;     // device: direct slabs (per item) followed by transposed slabs (per tile)
+  size_t sym_slabD_doubles = 0, sym_slab_doubles = 0;
   SmallBuf sm[N_SMALL];
   size_t small_doubles = 0;
   ncclComm_t comm = nullptr;
@@ -236,7 +243,7 @@ extern "C" int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, 
     HIPCHK(hipMalloc(&e->panel[p], pbytes));
     HIPCHK(hipMemsetAsync(e->panel[p], 0, pbytes, e->stream));
   }
-  e->xt_group_stride = e->ncols_pad * 16;
+  e->xt_group_stride = std::max(e->ncols_pad, e->nloc_pad) * 16;   // sym-tiled sweeps index whole 256-row blocks
   HIPCHK(hipMalloc(&e->xt, sizeof(double) * e->xt_group_stride * 4));
   HIPCHK(hipMemsetAsync(e->xt, 0, sizeof(double) * e->xt_group_stride * 4, e->stream));
   int nsplit, jc;
@@ -284,6 +291,9 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->idx_dev);
   hipFree(e->norm_partial);
   hipFree(e->gjd_ws);
+  hipFree(e->sym_items);
+  hipFree(e->sym_row_begin);
+  hipFree(e->sym_slab);
   for (int i = 0; i < N_SMALL; ++i) {
     hipFree(e->sm[i].dev);
     if (e->sm[i].host) hipHostFree(e->sm[i].host);
@@ -372,14 +382,58 @@ static int refresh_diag_host(E* e, int which) {
   return 0;
 }
 
+static int sym_setup(E* e) {
+  // work list of the symmetric sweep: runs of <= C consecutive tiles of one block row
+  if (e->sym_items) return 0;
+  int nb = (int)(e->nloc_pad / SYM_TB);
+  int64_t ntiles = (int64_t)nb * (nb + 1) / 2;
+  int64_t C = std::max<int64_t>(1, (ntiles + 2047) / 2048);
+  std::vector<int> items, row_begin(nb + 1, 0);
+  for (int I = 0; I < nb; ++I) {
+    row_begin[I] = (int)(items.size() / 3);
+    for (int J0 = 0; J0 <= I; J0 += (int)C) {
+      items.push_back(I); items.push_back(J0); items.push_back((int)std::min<int64_t>(I + 1, J0 + C));
+    }
+  }
+  row_begin[nb] = (int)(items.size() / 3);
+  e->sym_nb = nb;
+  e->sym_nitems = row_begin[nb];
+  HIPCHK(hipMalloc(&e->sym_items, sizeof(int) * items.size()));
+  HIPCHK(hipMalloc(&e->sym_row_begin, sizeof(int) * row_begin.size()));
+  HIPCHK(hipMemcpy(e->sym_items, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->sym_row_begin, row_begin.data(), sizeof(int) * row_begin.size(), hipMemcpyHostToDevice));
+  e->sym_slabD_doubles = (size_t)e->sym_nitems * 32 * SYM_TB;                      // up to 32 block columns per pass
+  size_t slabT = (size_t)((int64_t)nb * (nb - 1) / 2) * 32 * SYM_TB;
+  e->sym_slab_doubles = e->sym_slabD_doubles + slabT;
+  hipError_t r = hipMalloc(&e->sym_slab, sizeof(double) * e->sym_slab_doubles);
+  if (r != hipSuccess) return fail("hipMalloc of the symmetric sweep slabs failed: " + std::string(hipGetErrorString(r)));
+  return 0;
+}
+
 static int alloc_dense(E* e, int which) {
   OpDesc& o = e->op[which];
+  if (o.a && o.storage != e->storage) { hipFree(o.a); o.a = nullptr; }
+  o.storage = e->storage;
   if (!o.a) {
-    size_t bytes = sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
+    size_t bytes;
+    if (o.storage == 1) {
+      int64_t nb = e->nloc_pad / SYM_TB;
+      bytes = sizeof(double) * (size_t)(nb * (nb + 1) / 2) * SYM_TB * SYM_TB;
+    } else {
+      bytes = sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
+    }
     hipError_t r = hipMalloc(&o.a, bytes);
     if (r != hipSuccess)
-      return fail("hipMalloc of the dense matrix slab (" + std::to_string(bytes >> 20) + " MiB) failed: " + hipGetErrorString(r));
+      return fail("hipMalloc of the dense matrix (" + std::to_string(bytes >> 20) + " MiB) failed: " + hipGetErrorString(r));
   }
+  if (o.storage == 1) CHK(sym_setup(e));
+  return 0;
+}
+
+extern "C" int dav_set_storage(dav_handle_t e, int mode) {
+  if (mode != 0 && mode != 1) return fail("dav_set_storage: mode must be 0 (full) or 1 (symmetric-tiled)");
+  if (mode == 1 && e->nranks != 1) return fail("dav_set_storage: symmetric-tiled storage needs a single rank (row slabs use full storage)");
+  e->storage = mode;
   return 0;
 }
 
@@ -389,6 +443,23 @@ extern "C" int dav_set_dense_host(dav_handle_t e, int which, const double* a, in
   CHK(alloc_dense(e, which));
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_DENSE;
+  if (o.storage == 1) {
+    // lower block triangle, tile by tile (edge tiles zero padded)
+    int nb = e->sym_nb;
+    HIPCHK(hipMemsetAsync(o.a, 0, sizeof(double) * (size_t)((int64_t)nb * (nb + 1) / 2) * SYM_TB * SYM_TB, e->stream));
+    for (int I = 0; I < nb; ++I)
+      for (int J = 0; J <= I; ++J) {
+        int64_t r0 = (int64_t)I * SYM_TB, c0 = (int64_t)J * SYM_TB;
+        int64_t nr = std::min<int64_t>(SYM_TB, e->n - r0), nc = std::min<int64_t>(SYM_TB, e->n - c0);
+        if (nr <= 0 || nc <= 0) continue;
+        double* tile = o.a + ((int64_t)I * (I + 1) / 2 + J) * (int64_t)(SYM_TB * SYM_TB);
+        HIPCHK(hipMemcpy2DAsync(tile, sizeof(double) * SYM_TB, a + r0 + c0 * lda, sizeof(double) * lda, sizeof(double) * nr,
+                                (size_t)nc, hipMemcpyHostToDevice, e->stream));
+      }
+    launch_diag_sym(e->stream, o.a, e->n, o.diag);
+    CHK(refresh_diag_host(e, which));
+    return 0;
+  }
   HIPCHK(hipMemsetAsync(o.a, 0, sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad, e->stream));
   if (e->nloc > 0)
     HIPCHK(hipMemcpy2DAsync(o.a, sizeof(double) * e->nloc_pad, a + e->row0, sizeof(double) * lda,
@@ -405,9 +476,14 @@ extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed,
   CHK(alloc_dense(e, which));
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_DENSE;
-  launch_generate_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->row0, e->nloc, e->n, seed, sparsity,
-                        use_diag_val, diag_val);
-  launch_diag_dense(e->stream, o.a, e->nloc_pad, e->row0, e->nloc, o.diag);
+  if (o.storage == 1) {
+    launch_generate_sym_tiles(e->stream, o.a, (int64_t)e->sym_nb * (e->sym_nb + 1) / 2, e->n, seed, sparsity, use_diag_val, diag_val);
+    launch_diag_sym(e->stream, o.a, e->n, o.diag);
+  } else {
+    launch_generate_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->row0, e->nloc, e->n, seed, sparsity,
+                          use_diag_val, diag_val);
+    launch_diag_dense(e->stream, o.a, e->nloc_pad, e->row0, e->nloc, o.diag);
+  }
   CHK(refresh_diag_host(e, which));
   return 0;
 }
@@ -482,6 +558,28 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     return 0;
   }
   CHK(need_comm(e));
+  if (o.kind == DAV_KIND_DENSE && o.storage == 1) {
+    // symmetric-tiled sweep: 16 columns per pass; every off-diagonal tile read once, used twice
+    for (int c = 0; c < k; c += 16) {
+      int kk = std::min(16, k - c);
+      int ngroups = (kk + 15) / 16;
+      launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
+      int slot = -1;
+      double bytes = 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) + 16.0 * (double)e->n * kk;
+      if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
+      launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, e->xt_group_stride, ngroups, e->sym_slab,
+                        e->sym_slab + e->sym_slabD_doubles);
+      if (timed) CHK(timed_end(e, slot));
+      launch_sym_reduce(e->stream, e->sym_slab, e->sym_slab + e->sym_slabD_doubles, e->sym_row_begin, e->sym_nb, ngroups,
+                        e->nloc, kk, dst + (int64_t)c * e->ldp, e->ldp);
+      if (which == DAV_OP_A) {
+        e->st.applies += 1;
+        e->st.apply_cols += kk;
+      }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   for (int c = 0; c < k; c += 64) {
     int kk = std::min(64, k - c);
     int groups = (kk + 15) / 16;
@@ -600,7 +698,9 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
   for (int w = 0; w < (e->gev ? 2 : 1); ++w) {
     OpDesc& o = e->op[w];
     int dst = w == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
-    if (o.kind == DAV_KIND_DENSE)
+    if (o.kind == DAV_KIND_DENSE && o.storage == 1)
+      launch_gather_columns_sym(e->stream, o.a, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
+    else if (o.kind == DAV_KIND_DENSE)
       launch_gather_columns(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
     else if (o.kind == DAV_KIND_HOST) {
       /* the driver fills W / BV through dav_panel_put */
@@ -813,7 +913,8 @@ extern "C" int dav_bench_apply(dav_handle_t e, int which, int k, int reps, doubl
     done += batch;
   }
   *avg_ms = total / reps;
-  *bytes = 8.0 * (double)e->nloc * (double)e->n + 16.0 * (double)e->n * k;
+  *bytes = (e->op[which].storage == 1 ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0)
+                                      : 8.0 * (double)e->nloc * (double)e->n) + 16.0 * (double)e->n * k;
   e->st = saved;
   return 0;
 }

@@ -9,6 +9,7 @@
 // The column range is split over blockIdx.y (>>256 workgroups); partial tiles go to a slab that a
 // second, tiny kernel sums in a fixed order (bitwise reproducible, no fp64 atomics).
 #include "kernels.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_xt_kernel(const double* __restrict__ src, int64_t ld, int64_t nloc,
@@ -163,8 +164,15 @@ __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t r
 
 void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc) {
   int64_t rowblocks = nrows_pad / MV_ROWS;
-  int64_t target = 2048;                       // ~8 workgroups per CU
-  int64_t s = (target + rowblocks - 1) / rowblocks;
+  static int64_t target = 0;                   // ~8 workgroups per CU (DAV_MV_TARGET overrides, for tuning)
+  if (target == 0) {
+    const char* env = getenv("DAV_MV_TARGET");
+    target = env ? atoll(env) : -1;
+    if (target == 0) target = -1;
+  }
+  // measured on MI355X: ~2048 workgroups is best at N=20000 (5.6 TB/s), ~1024 for N>=60000 (6.0 TB/s)
+  int64_t want = target > 0 ? target : (rowblocks >= 200 ? 1024 : 2048);
+  int64_t s = (want + rowblocks - 1) / rowblocks;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   int64_t chunk = (ncols_pad + s - 1) / s;

@@ -94,6 +94,10 @@ class CEngine:
         return buf.raw
 
     # -- operators
+    def set_storage(self, mode):
+        """0 = full storage, 1 = symmetric-tiled (lower block triangle only)."""
+        self._chk(self.lib.dav_set_storage(self.h, C.c_int(mode)))
+
     def set_dense_host(self, which, a):
         a = _f(a)
         self._chk(self.lib.dav_set_dense_host(self.h, C.c_int(which), _dp(a), C.c_int64(a.shape[0])))

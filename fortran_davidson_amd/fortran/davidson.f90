@@ -20,7 +20,7 @@ module davidson_device
   use lapack_wrapper, only: lapack_generalized_eigensolver
   implicit none
   private
-  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, &
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
        engine_set_identity, engine_comm_unique_id, engine_comm_init, &
        generalized_eigensolver_device, davidson_device_loop, basis_capacity
@@ -97,6 +97,25 @@ contains
     character(kind=c_char), intent(in) :: id(128)
     call check_dav(dav_comm_init(eng%h, id), "dav_comm_init")
   end subroutine engine_comm_init
+
+  !> Storage of the dense operators set afterwards: "full" (default) or "symmetric" = only the lower
+  !> block triangle is kept in HBM (N(N+1)/2 entries: N = 200000 fits one MI355X) and every
+  !> off-diagonal tile is used twice per sweep.  Single GPU only.
+  subroutine engine_set_storage(eng, storage)
+    type(davidson_engine), intent(inout) :: eng
+    character(len=*), intent(in) :: storage
+    integer(c_int) :: mode
+    select case (trim(storage))
+    case ("full")
+       mode = 0
+    case ("symmetric")
+       mode = 1
+    case default
+       print *, "engine_set_storage: storage must be 'full' or 'symmetric'"
+       error stop
+    end select
+    call check_dav(dav_set_storage(eng%h, mode), "dav_set_storage")
+  end subroutine engine_set_storage
 
   !> Upload a host matrix (full storage) as operator A (which=1) or B (which=2).
   subroutine engine_set_dense(eng, which, matrix)

@@ -131,6 +131,18 @@ contains
     call engine_comm_init(eng, id)
   end subroutine fd_engine_comm_init
 
+  subroutine fd_engine_set_storage(p, mode) bind(C, name="fd_engine_set_storage")
+    type(c_ptr), value :: p
+    integer(c_int), value :: mode
+    type(davidson_engine), pointer :: eng
+    call c_f_pointer(p, eng)
+    if (mode == 1) then
+       call engine_set_storage(eng, "symmetric")
+    else
+       call engine_set_storage(eng, "full")
+    end if
+  end subroutine fd_engine_set_storage
+
   subroutine fd_engine_set_dense(p, which, a) bind(C, name="fd_engine_set_dense")
     type(c_ptr), value :: p
     integer(c_int), value :: which

@@ -56,6 +56,12 @@ module davidson_hip_c
        type(dav_stats), intent(out) :: st
        integer(c_int) :: ierr
      end function
+     function dav_set_storage(h, mode) bind(C, name="dav_set_storage") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: mode
+       integer(c_int) :: ierr
+     end function
      function dav_set_dense_host(h, which, a, lda) bind(C, name="dav_set_dense_host") result(ierr)
        import :: c_ptr, c_int, c_int64_t, c_double
        type(c_ptr), value :: h

@@ -78,7 +78,7 @@ class DavidsonEngine:
     lowest, method, max_iterations, tolerance, iters, max_dim_sub)`.
     """
 
-    def __init__(self, n, lowest, max_dim_sub=None, gev=False, device=0, rank=0, nranks=1):
+    def __init__(self, n, lowest, max_dim_sub=None, gev=False, device=0, rank=0, nranks=1, storage="full"):
         self.lib = fortran_lib()
         self.n, self.lowest = n, lowest
         self.max_dim = 10 * lowest if max_dim_sub is None else max_dim_sub
@@ -87,6 +87,8 @@ class DavidsonEngine:
                                                       C.c_int(1 if gev else 0), C.c_int(device), C.c_int(rank),
                                                       C.c_int(nranks)))
         self.c = CEngine(handle=self.lib.fd_engine_handle(self.p))
+        if storage != "full":
+            self.lib.fd_engine_set_storage(self.p, C.c_int({"full": 0, "symmetric": 1}[storage]))
 
     def close(self):
         if self.p:

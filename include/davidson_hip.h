@@ -77,6 +77,11 @@ int dav_reset_stats(dav_handle_t h);
 int dav_local_rows(dav_handle_t h, int64_t* row0, int64_t* nloc);
 
 /* ---- operators (replace `matrix` / `second_matrix` / fun_matrix_gemv) ------------------------- */
+/* Storage of dense operators set AFTER this call: 0 = full (default; required for nranks > 1),
+ * 1 = symmetric-tiled: only the lower block triangle (256 x 256 tiles) is kept in HBM - N(N+1)/2
+ * entries, e.g. 160 GB instead of 320 GB at N = 200000 - and the block matvec uses every
+ * off-diagonal tile twice (A is assumed symmetric, as the reference assumes). */
+int dav_set_storage(dav_handle_t h, int mode);
 /* Dense matrix from host memory, full storage a(lda, n), the caller's array as passed to
  * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and
  * extracts the diagonal (replaces array_utils.f90:115-134). */

@@ -101,6 +101,33 @@ def test_device_resident_engine_and_generator(golden):
         assert none is None and np.array_equal(lam2, lam)
 
 
+@pytest.mark.parametrize("name", ["n2000_std_dpr", "n1000_gev_restart_dpr", "n3000_hard_dpr"])
+def test_symmetric_tiled_storage_solves_match_golden(golden, name):
+    """Same solves with only the lower block triangle resident (K1s sweep)."""
+    manifest, arrays = golden
+    case = manifest["dense"][name]
+    with fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=case["gev"], storage="symmetric") as eng:
+        eng.generate_diagonal_dominant(1, case["sparsity"], seed=case["seed_a"])
+        if case["gev"]:
+            eng.generate_diagonal_dominant(2, case["sparsity"], 1.0, seed=case["seed_b"])
+        lam, vec, iters = eng.solve(case["method"], case["max_it"], case["tol"])
+    assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
+    assert iters == case["iters"]
+    A, B = case_matrices(case, arrays)
+    assert (residuals(A, B, lam, vec) < case["tol"]).all()
+
+
+def test_symmetric_storage_upload_and_gjd(golden):
+    manifest, arrays = golden
+    case = manifest["dense"]["n400_std_gjd"]
+    A, _ = case_matrices(case, arrays)
+    with fd.DavidsonEngine(case["n"], case["lowest"], storage="symmetric") as eng:
+        eng.set_dense(1, A)
+        lam, vec, iters = eng.solve("GJD", case["max_it"], case["tol"])
+    assert np.abs(lam - arrays["n400_std_gjd__evals"]).max() < EV_TOL
+    assert iters == case["iters"]
+
+
 def test_gev_engine_hashed_operator_equals_dense(golden):
     manifest, arrays = golden
     case = manifest["dense"]["n1000_gev_restart_dpr"]
