@@ -322,7 +322,13 @@ extern "C" int dav_comm_unique_id(void* id128) {
 }
 
 extern "C" int dav_comm_init(dav_handle_t e, const void* id128) {
-  if (e->nranks == 1) return 0;
+  // A single rank needs no communicator.  DAVIDSON_FORCE_RCCL=1 builds a 1-rank communicator anyway so
+  // that every collective of the sharded path (all-gather of the packed block, all-reduce of the Gram
+  // blocks and norms) runs through RCCL on a single-GPU box - used by the GPU tests.
+  if (e->nranks == 1) {
+    const char* force = getenv("DAVIDSON_FORCE_RCCL");
+    if (!force || force[0] != '1') return 0;
+  }
   CHK(rccl_load());
   CHK(bind(e));
   ncclUniqueId id;
@@ -370,7 +376,7 @@ static int refresh_diag_host(E* e, int which) {
   // global diagonal on the host (stable top-k selection, dav_get_diagonal)
   std::vector<double>& d = e->diag_host[which];
   d.assign((size_t)e->n, 0.0);
-  if (e->nranks == 1) {
+  if (!e->comm) {
     HIPCHK(hipMemcpyAsync(d.data(), e->op[which].diag, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   } else {
@@ -585,7 +591,7 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     int groups = (kk + 15) / 16;
     int ngroups = groups == 3 ? 4 : groups;
     launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
-    if (e->nranks > 1) {
+    if (e->comm) {
       int slot;
       CHK(timed_begin(e, 3, 0, &slot));
       NCCLCHK(g_rccl.GroupStart());
@@ -640,7 +646,7 @@ static int gram_impl(E* e, const double* P, int p, const double* Q, int q) {
   CHK(timed_begin(e, 1, 0, &slot));
   launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, e->gram_dev);
   CHK(timed_end(e, slot));
-  if (e->nranks > 1) {
+  if (e->comm) {
     CHK(need_comm(e));
     NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)p * q, ncclDouble, ncclSum, e->comm, e->stream));
   }
@@ -754,7 +760,7 @@ extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, c
   launch_panel_gemm(e->stream, r);
   launch_norm_finish(e->stream, e->norm_partial, (int)(e->nloc_pad / PG_ROWS), lowest, e->gram_dev);
   CHK(timed_end(e, slot));
-  if (e->nranks > 1) {
+  if (e->comm) {
     CHK(need_comm(e));
     NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)lowest, ncclDouble, ncclSum, e->comm, e->stream));
   }
@@ -859,7 +865,7 @@ extern "C" int dav_panel_get(dav_handle_t e, int panel, int c0, int k, double* o
   CHK(bind(e));
   CHK(check_panel(e, panel, c0, k));
   if (ld < e->n) return fail("dav_panel_get: leading dimension too small");
-  if (e->nranks == 1) {
+  if (!e->comm) {
     HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * ld, panel_ptr(e, panel, c0), sizeof(double) * e->ldp,
                             sizeof(double) * e->n, (size_t)k, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -977,7 +983,7 @@ static int gjd_dots(Gjd& g, int npairs, const double* const* a, const double* co
   int total = npairs * g.m;
   launch_coldots(e->stream, d);
   launch_norm_finish(e->stream, e->norm_partial, nb, total, e->gram_dev);
-  if (e->nranks > 1) NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)total, ncclDouble, ncclSum, e->comm, e->stream));
+  if (e->comm) NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)total, ncclDouble, ncclSum, e->comm, e->stream));
   HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * total, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   for (int s = 0; s < npairs; ++s) res[s].assign(e->gram_host + (size_t)s * g.m, e->gram_host + (size_t)(s + 1) * g.m);

@@ -195,3 +195,23 @@ def test_against_oracle_on_fresh_inputs():
         assert it == it_o
         assert np.abs(lam - lam_o).max() < EV_TOL
         assert (residuals(A, None, lam, vec) < 1e-8).all()
+
+
+def test_sharded_code_path_through_rccl_single_rank(golden, monkeypatch):
+    """DAVIDSON_FORCE_RCCL=1: a 1-rank RCCL communicator, so the all-gather of the packed basis block,
+    the all-reduces of Gram blocks / norms and the gathered panel download all run through RCCL."""
+    monkeypatch.setenv("DAVIDSON_FORCE_RCCL", "1")
+    manifest, arrays = golden
+    for name in ("n2000_std_dpr", "n1000_gev_restart_dpr"):
+        case = manifest["dense"][name]
+        with fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=case["gev"]) as eng:
+            eng.comm_init(fd.CEngine.comm_unique_id())
+            eng.generate_diagonal_dominant(1, case["sparsity"], seed=case["seed_a"])
+            if case["gev"]:
+                eng.generate_diagonal_dominant(2, case["sparsity"], 1.0, seed=case["seed_b"])
+            lam, vec, iters = eng.solve("DPR", case["max_it"], case["tol"])
+            assert eng.c.stats().comm_ms > 0
+        assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
+        assert iters == case["iters"]
+        A, B = case_matrices(case, arrays)
+        assert (residuals(A, B, lam, vec) < case["tol"]).all()
