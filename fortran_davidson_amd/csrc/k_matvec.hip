@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void matvec_dense_kernel(const double* __restr
 }
 
 // Matrix-free variant: the A entries of the same register tile are generated in place.
-template <int NT>
+template <int NT, int KIND>
 __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t row0, int64_t nloc, int64_t n,
                                                           int64_t ncols_pad, const double* __restrict__ xt,
                                                           int64_t group_stride, double* __restrict__ slab,
@@ -132,9 +132,8 @@ __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t r
       double v = 0.0;
       if (li[rt] < nloc && gj < n) {
         int64_t gi = row0 + li[rt];
-        v = (op.kind == DAV_KIND_HASHED)
-                ? dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj)
-                : dav_harness_entry(op.e_table, op.trig, gi, gj);
+        if (KIND == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
+        else v = dav_harness_entry(op.e_table, op.trig, gi, gj);
       }
       a[rt] = v;
     }
@@ -197,15 +196,25 @@ void launch_matvec_dense(hipStream_t st, const double* A, int64_t lda, int64_t n
   }
 }
 
+template <int KIND>
+static void launch_free_kind(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t n, int64_t nrows_pad,
+                             int64_t ncols_pad, const double* xt, int64_t xt_group_stride, int ngroups, double* slab,
+                             int nsplit, int jc) {
+  dim3 grid((unsigned)(nrows_pad / MV_ROWS), nsplit);
+  switch (ngroups) {
+    case 1: hipLaunchKernelGGL((matvec_free_kernel<1, KIND>), grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    case 2: hipLaunchKernelGGL((matvec_free_kernel<2, KIND>), grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    default: hipLaunchKernelGGL((matvec_free_kernel<4, KIND>), grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+  }
+}
+
 void launch_matvec_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t n, int64_t nrows_pad,
                         int64_t ncols_pad, const double* xt, int64_t xt_group_stride, int ngroups, double* slab,
                         int nsplit, int jc) {
-  dim3 grid((unsigned)(nrows_pad / MV_ROWS), nsplit);
-  switch (ngroups) {
-    case 1: hipLaunchKernelGGL(matvec_free_kernel<1>, grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
-    case 2: hipLaunchKernelGGL(matvec_free_kernel<2>, grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
-    default: hipLaunchKernelGGL(matvec_free_kernel<4>, grid, dim3(256), 0, st, op, row0, nloc, n, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
-  }
+  if (op.kind == DAV_KIND_HASHED)
+    launch_free_kind<DAV_KIND_HASHED>(st, op, row0, nloc, n, nrows_pad, ncols_pad, xt, xt_group_stride, ngroups, slab, nsplit, jc);
+  else
+    launch_free_kind<DAV_KIND_HARNESS>(st, op, row0, nloc, n, nrows_pad, ncols_pad, xt, xt_group_stride, ngroups, slab, nsplit, jc);
 }
 
 // ---------------------------------------------------------------------------------------------
