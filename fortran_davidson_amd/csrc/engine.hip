@@ -112,7 +112,8 @@ struct dav_engine {
   double* scratch = nullptr;
   size_t scratch_doubles = 0;
   double* gram_dev = nullptr;     // result of gram / norms on device
-  double* gram_host = nullptr;    // pinned
+  double* gram_host = nullptr;    // pinned, device-visible (zero-copy target of the reduction kernels)
+  double* gram_host_dev = nullptr;  // device address of gram_host
   size_t gram_doubles = 0;
   double* gather_dev = nullptr;   // nranks*nslab staging for panel_get / diagonal gather
   int64_t* idx_dev = nullptr;
@@ -197,6 +198,38 @@ static int small_upload(E* e, int i, const double* src, int64_t ld, int p, int q
   return 0;
 }
 
+// several small matrices in ONE staging buffer and ONE host-to-device copy (each H2D command costs
+// ~10 us of launch latency, which is what the small phases are made of)
+struct SmallMat {
+  const double* src; int64_t ld; int p, q;   // in
+  double* dev; int64_t ldm;                  // out
+};
+static int small_upload_multi(E* e, int i, SmallMat* mats, int n) {
+  SmallBuf& b = e->sm[i];
+  size_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    mats[k].ldm = roundup(std::max(mats[k].p, 1), 4);
+    total += (size_t)mats[k].ldm * roundup(std::max(mats[k].q, 1), 64);
+  }
+  if (total > e->small_doubles) return fail("small matrices exceed engine capacity");
+  if (b.pending) {
+    HIPCHK(hipEventSynchronize(b.done));
+    b.pending = false;
+  }
+  std::memset(b.host, 0, sizeof(double) * total);
+  size_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    SmallMat& mt = mats[k];
+    for (int j = 0; j < mt.q; ++j) std::memcpy(b.host + off + j * mt.ldm, mt.src + j * mt.ld, sizeof(double) * mt.p);
+    mt.dev = b.dev + off;
+    off += (size_t)mt.ldm * roundup(std::max(mt.q, 1), 64);
+  }
+  HIPCHK(hipMemcpyAsync(b.dev, b.host, sizeof(double) * total, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipEventRecord(b.done, e->stream));
+  b.pending = true;
+  return 0;
+}
+
 static double* panel_ptr(E* e, int panel, int col) {
   return e->panel[panel] + (int64_t)col * e->ldp;
 }
@@ -254,11 +287,12 @@ extern "C" int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, 
   HIPCHK(hipMalloc(&e->scratch, sizeof(double) * e->scratch_doubles));
   e->gram_doubles = (size_t)e->cols_alloc * e->cols_alloc;
   HIPCHK(hipMalloc(&e->gram_dev, sizeof(double) * e->gram_doubles));
-  HIPCHK(hipHostMalloc(&e->gram_host, sizeof(double) * e->gram_doubles, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&e->gram_host, sizeof(double) * e->gram_doubles, hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&e->gram_host_dev, e->gram_host, 0));
   HIPCHK(hipMalloc(&e->gather_dev, sizeof(double) * (size_t)e->ncols_pad));
   HIPCHK(hipMalloc(&e->idx_dev, sizeof(int64_t) * e->cols_alloc));
   HIPCHK(hipMalloc(&e->norm_partial, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc));
-  e->small_doubles = (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
+  e->small_doubles = 3 * (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
   for (int i = 0; i < N_SMALL; ++i) {
     HIPCHK(hipMalloc(&e->sm[i].dev, sizeof(double) * e->small_doubles));
     HIPCHK(hipHostMalloc(&e->sm[i].host, sizeof(double) * e->small_doubles, hipHostMallocDefault));
@@ -638,20 +672,29 @@ extern "C" int dav_apply(dav_handle_t e, int which, int src_panel, int c0, int k
 }
 
 // ---- K2 -----------------------------------------------------------------------------------------
+// Small results (Gram blocks, norms, dots) reach the host without a copy command: a single rank lets
+// the final reduction kernel write straight into device-visible pinned memory and only synchronises
+// the stream; with a communicator the partial result is all-reduced in HBM first and then copied.
+static double* result_target(E* e) { return e->comm ? e->gram_dev : e->gram_host_dev; }
+static int result_fetch(E* e, size_t count) {
+  if (e->comm) {
+    NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, count, ncclDouble, ncclSum, e->comm, e->stream));
+    HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 // result left in e->gram_host (p x q, ld = p) after the call
 static int gram_impl(E* e, const double* P, int p, const double* Q, int q) {
   if ((size_t)p * q > e->gram_doubles) return fail("gram result exceeds engine capacity");
   if (gram_scratch_doubles(p, q, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
-  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, e->gram_dev);
+  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, result_target(e));
   CHK(timed_end(e, slot));
-  if (e->comm) {
-    CHK(need_comm(e));
-    NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)p * q, ncclDouble, ncclSum, e->comm, e->stream));
-  }
-  HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * p * q, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->nranks > 1) CHK(need_comm(e));
+  CHK(result_fetch(e, (size_t)p * q));
   return 0;
 }
 
@@ -727,30 +770,30 @@ extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, c
   if (m <= 0 || lowest <= 0 || lowest > m || ldy < m) return fail("dav_ritz_residual_correction: bad shape");
   if (method == DAV_METHOD_DPR && 2 * m > e->cols_alloc) return fail("basis panel too narrow for the correction block");
   CHK(check_panel(e, DAV_PANEL_V, 0, m));
-  int64_t ldm_y, ldm_y2, ldm_t;
-  CHK(small_upload(e, 0, Y, ldy, m, m, &ldm_y));
   std::vector<double> y2((size_t)m * m);
   for (int j = 0; j < m; ++j)
     for (int i = 0; i < m; ++i) y2[(size_t)j * m + i] = -Y[j * ldy + i] * theta[j];
-  CHK(small_upload(e, 1, y2.data(), m, m, m, &ldm_y2));
-  CHK(small_upload(e, 2, theta, m, m, 1, &ldm_t));
+  SmallMat sm3[3] = {{Y, ldy, m, m, nullptr, 0}, {y2.data(), m, m, m, nullptr, 0}, {theta, m, m, 1, nullptr, 0}};
+  CHK(small_upload_multi(e, 0, sm3, 3));
+  const double* dY = sm3[0].dev; const double* dY2 = sm3[1].dev; const double* dTheta = sm3[2].dev;
+  const int64_t ldm_y = sm3[0].ldm, ldm_y2 = sm3[1].ldm;
 
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
   // X = V * Y(:, 1:nx)
   int nx = method == DAV_METHOD_DPR ? lowest : (method == DAV_METHOD_GJD ? m : lowest);
   PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = e->sm[0].dev; a.ldm1 = ldm_y;
+  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = dY; a.ldm1 = ldm_y;
   a.p2 = 0;
   a.out = panel_ptr(e, DAV_PANEL_X, 0); a.ldo = e->ldp; a.q = nx;
   a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
   launch_panel_gemm(e->stream, a);
   // R = W*Y + Z*(-Y*diag(theta)), norms, (DPR) T
   PanelGemmArgs r{};
-  r.P1 = panel_ptr(e, DAV_PANEL_W, 0); r.ld1 = e->ldp; r.p1 = m; r.M1 = e->sm[0].dev; r.ldm1 = ldm_y;
-  r.P2 = panel_ptr(e, e->gev ? DAV_PANEL_BV : DAV_PANEL_V, 0); r.ld2 = e->ldp; r.p2 = m; r.M2 = e->sm[1].dev; r.ldm2 = ldm_y2;
+  r.P1 = panel_ptr(e, DAV_PANEL_W, 0); r.ld1 = e->ldp; r.p1 = m; r.M1 = dY; r.ldm1 = ldm_y;
+  r.P2 = panel_ptr(e, e->gev ? DAV_PANEL_BV : DAV_PANEL_V, 0); r.ld2 = e->ldp; r.p2 = m; r.M2 = dY2; r.ldm2 = ldm_y2;
   r.q = m; r.nloc = e->nloc; r.nrows_pad = e->nloc_pad;
-  r.theta = e->sm[2].dev; r.dA = e->op[DAV_OP_A].diag; r.dB = e->gev ? e->op[DAV_OP_B].diag : nullptr;
+  r.theta = dTheta; r.dA = e->op[DAV_OP_A].diag; r.dB = e->gev ? e->op[DAV_OP_B].diag : nullptr;
   r.nnorm = lowest; r.norm_partial = e->norm_partial;
   if (method == DAV_METHOD_DPR) {
     r.out = panel_ptr(e, DAV_PANEL_V, m); r.ldo = e->ldp; r.epilogue = 1;
@@ -758,14 +801,10 @@ extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, c
     r.out = panel_ptr(e, DAV_PANEL_R, 0); r.ldo = e->ldp; r.epilogue = 2;
   }
   launch_panel_gemm(e->stream, r);
-  launch_norm_finish(e->stream, e->norm_partial, (int)(e->nloc_pad / PG_ROWS), lowest, e->gram_dev);
+  launch_norm_finish(e->stream, e->norm_partial, (int)(e->nloc_pad / PG_ROWS), lowest, result_target(e));
   CHK(timed_end(e, slot));
-  if (e->comm) {
-    CHK(need_comm(e));
-    NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)lowest, ncclDouble, ncclSum, e->comm, e->stream));
-  }
-  HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * lowest, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->nranks > 1) CHK(need_comm(e));
+  CHK(result_fetch(e, (size_t)lowest));
   for (int j = 0; j < lowest; ++j) resnorm[j] = std::sqrt(e->gram_host[j]);
   HIPCHK(hipGetLastError());
   return 0;
@@ -789,23 +828,21 @@ extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, i
   CHK(bind(e));
   if (m < 0 || kt <= 0 || ldm < kt) return fail("dav_ortho_apply: bad shape");
   CHK(check_panel(e, DAV_PANEL_V, 0, m + kt));
-  int64_t ld_m, ld_cm = 4;
-  CHK(small_upload(e, 0, M, ldm, kt, kt, &ld_m));
-  if (m > 0) {
-    std::vector<double> cm((size_t)m * kt, 0.0);       // -(C*M)
-    for (int j = 0; j < kt; ++j)
-      for (int l = 0; l < kt; ++l) {
-        double mlj = M[j * ldm + l];
-        if (mlj == 0.0) continue;
-        for (int i = 0; i < m; ++i) cm[(size_t)j * m + i] -= C[l * ldc + i] * mlj;
-      }
-    CHK(small_upload(e, 1, cm.data(), m, m, kt, &ld_cm));
-  }
+  std::vector<double> cm((size_t)std::max(m, 1) * kt, 0.0);       // -(C*M)
+  for (int j = 0; j < kt && m > 0; ++j)
+    for (int l = 0; l < kt; ++l) {
+      double mlj = M[j * ldm + l];
+      if (mlj == 0.0) continue;
+      for (int i = 0; i < m; ++i) cm[(size_t)j * m + i] -= C[l * ldc + i] * mlj;
+    }
+  SmallMat sm2[2] = {{M, ldm, kt, kt, nullptr, 0}, {cm.data(), std::max(m, 1), m, kt, nullptr, 0}};
+  CHK(small_upload_multi(e, 1, sm2, m > 0 ? 2 : 1));
+  const int64_t ld_m = sm2[0].ldm, ld_cm = m > 0 ? sm2[1].ldm : 4;
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
   PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = e->sm[0].dev; a.ldm1 = ld_m;
-  a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = e->sm[1].dev; a.ldm2 = ld_cm;
+  a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.ldm1 = ld_m;
+  a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.ldm2 = ld_cm;
   a.out = panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
   a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
   launch_panel_gemm(e->stream, a);
@@ -982,10 +1019,8 @@ static int gjd_dots(Gjd& g, int npairs, const double* const* a, const double* co
   int nb = coldots_blocks(e->nloc_pad);
   int total = npairs * g.m;
   launch_coldots(e->stream, d);
-  launch_norm_finish(e->stream, e->norm_partial, nb, total, e->gram_dev);
-  if (e->comm) NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, (size_t)total, ncclDouble, ncclSum, e->comm, e->stream));
-  HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * total, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  launch_norm_finish(e->stream, e->norm_partial, nb, total, result_target(e));
+  CHK(result_fetch(e, (size_t)total));
   for (int s = 0; s < npairs; ++s) res[s].assign(e->gram_host + (size_t)s * g.m, e->gram_host + (size_t)(s + 1) * g.m);
   return 0;
 }

@@ -14,14 +14,14 @@ template <int PT, int QT>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P, int64_t ldp, int p,
                                                    const double* __restrict__ Q, int64_t ldq, int q,
                                                    int64_t nrows_pad, int qtiles, double* __restrict__ slab,
-                                                   int ppad, int qpad) {
+                                                   int ppad, int qpad, int rows_per_wg) {
   __shared__ double red[4][PT * QT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int tp = blockIdx.x / qtiles, tq = blockIdx.x % qtiles;
   const int pc0 = tp * 16 * PT, qc0 = tq * 16 * QT;
-  int64_t n0 = (int64_t)blockIdx.y * GRAM_ROWS + wave * (GRAM_ROWS / 4);
-  int64_t n1 = n0 + GRAM_ROWS / 4;
+  int64_t n0 = (int64_t)blockIdx.y * rows_per_wg + wave * (rows_per_wg / 4);
+  int64_t n1 = n0 + rows_per_wg / 4;
   if (n1 > nrows_pad) n1 = nrows_pad;
 
   // column pointers; columns past the panel width are clamped (their results are discarded)
@@ -101,29 +101,33 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restri
 static inline int pad16(int x) { return (x + 15) / 16 * 16; }
 
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
-  int64_t nchunks = (nrows_pad + GRAM_ROWS - 1) / GRAM_ROWS;
+  int64_t nchunks = (nrows_pad + GRAM_MIN_ROWS - 1) / GRAM_MIN_ROWS;      // worst case of gram_rows_per_wg
   return (size_t)nchunks * pad16(p) * pad16(q);
 }
 
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
                  int64_t nrows_pad, double* scratch, double* out_dev) {
-  int nchunks = (int)((nrows_pad + GRAM_ROWS - 1) / GRAM_ROWS);
   int ppad = pad16(p), qpad = pad16(q);
+  // rows per workgroup: as tall as possible (fewer partial tiles) while the grid still fills the chip
+  int64_t tilegroups = (int64_t)((p + 31) / 32) * ((q + 31) / 32);
+  int rows_per_wg = GRAM_ROWS;
+  while (rows_per_wg > GRAM_MIN_ROWS && tilegroups * ((nrows_pad + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg /= 2;
+  int nchunks = (int)((nrows_pad + rows_per_wg - 1) / rows_per_wg);
   if (p > 16 && q > 16) {
     constexpr int PT = 2, QT = 2;
     int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
     dim3 grid(ptiles * qtiles, nchunks);
-    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad);
+    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad, rows_per_wg);
   } else if (p > 16) {
     constexpr int PT = 2, QT = 1;
     int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
     dim3 grid(ptiles * qtiles, nchunks);
-    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad);
+    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad, rows_per_wg);
   } else {
     constexpr int PT = 1, QT = 1;
     int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
     dim3 grid(ptiles * qtiles, nchunks);
-    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad);
+    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad, rows_per_wg);
   }
   int total = p * q;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, nchunks, p, q, ppad, qpad, out_dev);

@@ -26,7 +26,8 @@ size_t matvec_slab_doubles(int64_t nrows_pad, int ngroups, int nsplit);
 void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc);
 
 // ---- K2: tall-skinny Gram ------------------------------------------------------------------------
-constexpr int GRAM_ROWS = 1024;   // rows per workgroup (4 waves x 256)
+constexpr int GRAM_ROWS = 1024;   // rows per workgroup at most (4 waves x 256) ...
+constexpr int GRAM_MIN_ROWS = 256; // ... and at least (small problems: more, shorter workgroups)
 // out (p x q, column-major ld = p) = P^T Q over nrows_pad rows (multiple of 16; pad rows are zero).
 // scratch must hold gram_scratch_doubles(...) doubles.  Deterministic two-stage reduction.
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
