@@ -404,7 +404,7 @@ contains
     real(dp), parameter :: floor_rel = 1.0e-14_dp
     real(dp), allocatable :: c(:, :), g(:, :), gp(:, :), d(:), w(:), u(:, :), mm(:, :), vec(:)
     integer :: pass, j, l, nrep
-    real(dp) :: wmax, wmin
+    real(dp) :: wmax, wmin, dev
     logical :: clean
 
     allocate(c(max(m, 1), kt), g(kt, kt), gp(kt, kt), d(kt), w(kt), u(kt, kt), mm(kt, kt))
@@ -435,17 +435,41 @@ contains
              gp(l, j) = gp(l, j) * d(l) * d(j)
           end do
        end do
-       call lapack_generalized_eigensolver(gp, w, u)
-       wmax = maxval(w)
-       wmin = minval(w)
-       do j = 1, kt
-          w(j) = max(w(j), floor_rel * wmax)
-       end do
+       ! deviation of the scaled Gram block from the identity
+       dev = 0.0_dp
        do j = 1, kt
           do l = 1, kt
-             mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
+             if (l == j) then
+                dev = max(dev, abs(gp(l, j) - 1.0_dp))
+             else
+                dev = max(dev, abs(gp(l, j)))
+             end if
           end do
        end do
+       if (pass >= 2 .and. dev * real(kt, dp) < 1.0e-7_dp) then
+          ! already orthonormal to ~1e-7: G^(-1/2) = I - E/2 + O(E^2) is exact to rounding, no
+          ! eigen-decomposition needed (the usual state of the second pass)
+          do j = 1, kt
+             do l = 1, kt
+                mm(l, j) = -0.5_dp * gp(l, j) * d(l)
+             end do
+             mm(j, j) = (1.5_dp - 0.5_dp * gp(j, j)) * d(j)
+          end do
+          wmin = 1.0_dp - dev * real(kt, dp)
+          wmax = 1.0_dp + dev * real(kt, dp)
+       else
+          call lapack_generalized_eigensolver(gp, w, u)
+          wmax = maxval(w)
+          wmin = minval(w)
+          do j = 1, kt
+             w(j) = max(w(j), floor_rel * wmax)
+          end do
+          do j = 1, kt
+             do l = 1, kt
+                mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
+             end do
+          end do
+       end if
        call check_dav(dav_ortho_apply(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
             int(kt, c_int64_t)), "dav_ortho_apply")
        ! a pass that started from a nearly orthonormal block (all scaled Gram eigenvalues close to 1
