@@ -215,3 +215,47 @@ def test_sharded_code_path_through_rccl_single_rank(golden, monkeypatch):
         assert iters == case["iters"]
         A, B = case_matrices(case, arrays)
         assert (residuals(A, B, lam, vec) < case["tol"]).all()
+
+
+@pytest.mark.parametrize("n,L,sp,md", [(17, 1, 1e-2, None), (33, 2, 1e-2, None), (64, 3, 1e-2, 4), (130, 5, 5e-2, 12),
+                                       (257, 1, 1e-1, 3), (500, 16, 1e-2, None)])
+def test_edge_shapes_against_oracle(n, L, sp, md):
+    """Tiny and ragged orders, lowest=1, max_dim_sub below the initial width (restart every iteration),
+    width not a multiple of the MFMA tile: same eigenvalues, iteration counts and width policy."""
+    A = O.generate_diagonal_dominant(n, sp, seed=31)
+    tr = O.Trace()
+    lam_o, vec_o, it_o = O.generalized_eigensolver_dense(A, L, "DPR", 60, 1e-8, md, trace=tr)
+    lam, vec, it = fd.generalized_eigensolver(A, L, "DPR", 60, 1e-8, md)
+    assert it == it_o, (it, it_o, tr.widths)
+    assert np.abs(lam - lam_o).max() < EV_TOL
+    if tr.converged:
+        assert (residuals(A, None, lam, vec) < 1e-8).all()
+
+
+def test_duplicate_diagonal_entries_use_stable_order():
+    """Ties in the diagonal: the reference's key search is undefined; engine and
+    oracle both take the stable order."""
+    n, L = 200, 3
+    A = O.generate_diagonal_dominant(n, 1e-3, seed=9)
+    d = np.arange(1, n + 1, dtype=float)
+    d[:8] = [2.0, 1.0, 2.0, 1.0, 3.0, 3.0, 1.0, 2.0]
+    A[np.arange(n), np.arange(n)] = d
+    lam_o, _, it_o = O.generalized_eigensolver_dense(A, L, "DPR", 100, 1e-8)
+    lam, vec, it = fd.generalized_eigensolver(A, L, "DPR", 100, 1e-8)
+    assert it == it_o and np.abs(lam - lam_o).max() < EV_TOL
+    assert (residuals(A, None, lam, vec) < 1e-8).all()
+
+
+def test_generalized_matrix_free_with_callbacks_and_general_b():
+    """Host callbacks with a non-trivial B (dense numpy operators), checked against scipy."""
+    import scipy.linalg
+    n, L = 300, 4
+    A = O.generate_diagonal_dominant(n, 5e-3, seed=41)
+    B = O.generate_diagonal_dominant(n, 5e-3, 1.0, seed=42)
+    lam, vec, it = generalized_eigensolver_free(lambda x: A @ x, n, L, "DPR", 200, 1e-8, 40, lambda x: B @ x)
+    ref = scipy.linalg.eigh(A, B, eigvals_only=True, subset_by_index=[0, L - 1])
+    assert np.abs(lam - ref).max() < 1e-8
+    assert (residuals(A, B, lam, vec) < 1e-8).all()
+    lam_o, _, it_o = O.generalized_eigensolver_free(lambda x: A @ x, n, L, 200, 1e-8, 40, lambda x: B @ x,
+                                                    diag_matrix=np.diag(A).copy(), diag_second_matrix=np.diag(B).copy())
+    assert it == it_o
