@@ -17,7 +17,7 @@ module davidson_device
   use, intrinsic :: iso_c_binding
   use numeric_kinds, only: dp
   use davidson_hip_c
-  use lapack_wrapper, only: lapack_generalized_eigensolver
+  use lapack_wrapper, only: lapack_generalized_eigensolver, lapack_cholesky_inverse
   implicit none
   private
   public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, &
@@ -403,7 +403,8 @@ contains
     integer, parameter :: max_pass = 6
     real(dp), parameter :: floor_rel = 1.0e-14_dp
     real(dp), allocatable :: c(:, :), g(:, :), gp(:, :), d(:), w(:), u(:, :), mm(:, :), vec(:)
-    integer :: pass, j, l, nrep
+    integer :: pass, j, l, nrep, info
+    logical :: chol_ok
     real(dp) :: wmax, wmin, dev
     logical :: clean
 
@@ -458,17 +459,43 @@ contains
           wmin = 1.0_dp - dev * real(kt, dp)
           wmax = 1.0_dp + dev * real(kt, dp)
        else
-          call lapack_generalized_eigensolver(gp, w, u)
-          wmax = maxval(w)
-          wmin = minval(w)
-          do j = 1, kt
-             w(j) = max(w(j), floor_rel * wmax)
-          end do
-          do j = 1, kt
-             do l = 1, kt
-                mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
+          ! Cholesky route first (CholQR: M = D R^-1 with D G' D = R^T R): a k x k DPOTRF + DTRTRI costs a
+          ! fraction of a symmetric eigen-decomposition.  It is accepted only when the factor is well
+          ! conditioned (diagonal ratio); otherwise - rank deficiency, clustered corrections - the
+          ! eigen-decomposition route (SVQB) with its eigenvalue floor takes over.
+          call lapack_cholesky_inverse(gp, u, info)
+          chol_ok = .false.
+          if (info == 0) then
+             wmin = huge(1.0_dp)
+             wmax = 0.0_dp
+             do j = 1, kt
+                wmin = min(wmin, abs(u(j, j)))
+                wmax = max(wmax, abs(u(j, j)))
              end do
-          end do
+             chol_ok = wmax < 1.0e4_dp * wmin          ! cond(R) estimate below 1e4 => cond(G') below 1e8
+          end if
+          if (chol_ok) then
+             do j = 1, kt
+                do l = 1, kt
+                   mm(l, j) = d(l) * u(l, j)
+                end do
+             end do
+             ! report the conditioning in the same terms as the eigenvalue route (1/r_jj^2 ~ eigenvalues)
+             wmin = 1.0_dp / (wmax * wmax)
+             wmax = wmin * 1.0e8_dp
+          else
+             call lapack_generalized_eigensolver(gp, w, u)
+             wmax = maxval(w)
+             wmin = minval(w)
+             do j = 1, kt
+                w(j) = max(w(j), floor_rel * wmax)
+             end do
+             do j = 1, kt
+                do l = 1, kt
+                   mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
+                end do
+             end do
+          end if
        end if
        call check_dav(dav_ortho_apply(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
             int(kt, c_int64_t)), "dav_ortho_apply")

@@ -10,7 +10,8 @@ module lapack_wrapper
   implicit none
   private
   public :: lapack_generalized_eigensolver, lapack_generalized_eigensolver_lowest, &
-       lapack_matmul, lapack_matrix_vector, lapack_qr, lapack_solver, lapack_sort
+       lapack_matmul, lapack_matrix_vector, lapack_qr, lapack_solver, lapack_sort, &
+       lapack_cholesky_inverse
 
   interface
      subroutine dsyev(jobz, uplo, n, a, lda, w, work, lwork, info)
@@ -47,6 +48,18 @@ module lapack_wrapper
        character :: uplo
        integer :: n, nrhs, lda, ldb, lwork, info, ipiv(*)
        real(dp) :: a(lda, *), b(ldb, *), work(*)
+     end subroutine
+     subroutine dpotrf(uplo, n, a, lda, info)
+       import :: dp
+       character :: uplo
+       integer :: n, lda, info
+       real(dp) :: a(lda, *)
+     end subroutine
+     subroutine dtrtri(uplo, diag, n, a, lda, info)
+       import :: dp
+       character :: uplo, diag
+       integer :: n, lda, info
+       real(dp) :: a(lda, *)
      end subroutine
      subroutine dgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc)
        import :: dp
@@ -265,6 +278,28 @@ contains
     end do
     vector = sorted
   end function lapack_sort
+
+  !> Upper-triangular rinv with rinv^T * g * rinv = I (g = R^T R by DPOTRF, rinv = R^-1 by DTRTRI).
+  !> info /= 0 (g not numerically positive definite) is returned to the caller, not fatal: the block
+  !> orthonormalisation then falls back to the eigen-decomposition route.  Not part of the reference's
+  !> wrapper set; used by the device driver for the k x k basis transforms.
+  subroutine lapack_cholesky_inverse(g, rinv, info)
+    real(dp), dimension(:, :), intent(in) :: g
+    real(dp), dimension(size(g, 1), size(g, 2)), intent(out) :: rinv
+    integer, intent(out) :: info
+    integer :: n, i, j
+    n = size(g, 1)
+    rinv = g
+    call dpotrf("U", n, rinv, n, info)
+    if (info /= 0) return
+    call dtrtri("U", "N", n, rinv, n, info)
+    if (info /= 0) return
+    do j = 1, n
+       do i = j + 1, n
+          rinv(i, j) = 0.0_dp
+       end do
+    end do
+  end subroutine lapack_cholesky_inverse
 
   subroutine check_lapack_call(info, name)
     integer, intent(in) :: info
