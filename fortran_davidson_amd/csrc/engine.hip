@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <dlfcn.h>
+#include <pthread.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -74,6 +75,17 @@ static int rccl_load() {
     if (r_ != ncclSuccess) return fail(std::string(#call) + " failed: " + g_rccl.GetErrorString(r_)); \
   } while (0)
 
+// ---- loopback transport: several ranks of one problem as threads of ONE process on ONE GPU ----------
+// Same collective semantics as the RCCL path (in-place all-gather of equal slabs, sum all-reduce with
+// a rank-ordered, hence identical, result on every rank).  It exists so that the row-slab logic of a
+// multi-rank engine (offsets, padding, gathered indices) can be verified on a single-GPU box; the
+// multi-GPU data path is RCCL.
+struct LocalGroup {
+  int n = 0;
+  pthread_barrier_t bar;
+  const double* send[16] = {nullptr};
+};
+
 // ------------------------------------------------------------------------------------------------
 struct OpDesc {
   int kind = DAV_KIND_NONE;
@@ -128,6 +140,7 @@ struct dav_engine {
   SmallBuf sm[N_SMALL];
   size_t small_doubles = 0;
   ncclComm_t comm = nullptr;
+  LocalGroup* lg = nullptr;       // loopback transport (tests); owned by rank 0
   OpDesc op[2];
   std::vector<double> diag_host[2];
   // statistics
@@ -401,8 +414,59 @@ extern "C" int dav_local_rows(dav_handle_t e, int64_t* row0, int64_t* nloc) {
 }
 
 // ---- operators ---------------------------------------------------------------------------------
+static bool has_comm(E* e) { return e->comm != nullptr || e->lg != nullptr; }
 static int need_comm(E* e) {
-  if (e->nranks > 1 && !e->comm) return fail("multi-rank engine used before dav_comm_init");
+  if (e->nranks > 1 && !has_comm(e)) return fail("multi-rank engine used before dav_comm_init");
+  return 0;
+}
+
+// recv[p*count .. (p+1)*count) = send of rank p, for every rank (send may alias recv + rank*count)
+static int coll_allgather(E* e, const double* send, double* recv, size_t count) {
+  if (e->lg) {
+    LocalGroup* g = e->lg;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    g->send[e->rank] = send;
+    pthread_barrier_wait(&g->bar);
+    for (int p = 0; p < g->n; ++p)
+      if (recv + (size_t)p * count != g->send[p])
+        HIPCHK(hipMemcpyAsync(recv + (size_t)p * count, g->send[p], sizeof(double) * count, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->bar);
+    return 0;
+  }
+  NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
+  return 0;
+}
+
+// buf <- sum over ranks of buf (same bits on every rank)
+static int coll_allreduce(E* e, double* buf, size_t count) {
+  if (e->lg) {
+    LocalGroup* g = e->lg;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    g->send[e->rank] = buf;
+    pthread_barrier_wait(&g->bar);
+    std::vector<double> sum(count, 0.0), tmp(count);
+    for (int p = 0; p < g->n; ++p) {
+      HIPCHK(hipMemcpy(tmp.data(), g->send[p], sizeof(double) * count, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < count; ++i) sum[i] += tmp[i];
+    }
+    pthread_barrier_wait(&g->bar);            // everyone has read every buffer
+    HIPCHK(hipMemcpy(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
+  NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
+  return 0;
+}
+
+extern "C" int dav_local_group_join(dav_handle_t* handles, int n) {
+  if (!handles || n < 1 || n > 16) return fail("dav_local_group_join: 1..16 engines");
+  for (int r = 0; r < n; ++r)
+    if (!handles[r] || handles[r]->nranks != n || handles[r]->rank != r || handles[r]->lg || handles[r]->comm)
+      return fail("dav_local_group_join: engine r must be created with rank r of n and have no transport yet");
+  LocalGroup* g = new LocalGroup();
+  g->n = n;
+  pthread_barrier_init(&g->bar, nullptr, (unsigned)n);
+  for (int r = 0; r < n; ++r) handles[r]->lg = g;
   return 0;
 }
 
@@ -410,12 +474,12 @@ static int refresh_diag_host(E* e, int which) {
   // global diagonal on the host (stable top-k selection, dav_get_diagonal)
   std::vector<double>& d = e->diag_host[which];
   d.assign((size_t)e->n, 0.0);
-  if (!e->comm) {
+  if (!has_comm(e)) {
+    CHK(need_comm(e));
     HIPCHK(hipMemcpyAsync(d.data(), e->op[which].diag, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   } else {
-    CHK(need_comm(e));
-    NCCLCHK(g_rccl.AllGather(e->op[which].diag, e->gather_dev, (size_t)e->nslab, ncclDouble, e->comm, e->stream));
+    CHK(coll_allgather(e, e->op[which].diag, e->gather_dev, (size_t)e->nslab));
     HIPCHK(hipMemcpyAsync(d.data(), e->gather_dev, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }
@@ -625,15 +689,15 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     int groups = (kk + 15) / 16;
     int ngroups = groups == 3 ? 4 : groups;
     launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
-    if (e->comm) {
+    if (has_comm(e)) {
       int slot;
       CHK(timed_begin(e, 3, 0, &slot));
-      NCCLCHK(g_rccl.GroupStart());
+      if (e->comm) NCCLCHK(g_rccl.GroupStart());
       for (int g = 0; g < groups; ++g) {
         double* base = e->xt + g * e->xt_group_stride;
-        NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, e->stream));
+        CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
       }
-      NCCLCHK(g_rccl.GroupEnd());
+      if (e->comm) NCCLCHK(g_rccl.GroupEnd());
       CHK(timed_end(e, slot));
     }
     int nsplit, jc;
@@ -675,10 +739,10 @@ extern "C" int dav_apply(dav_handle_t e, int which, int src_panel, int c0, int k
 // Small results (Gram blocks, norms, dots) reach the host without a copy command: a single rank lets
 // the final reduction kernel write straight into device-visible pinned memory and only synchronises
 // the stream; with a communicator the partial result is all-reduced in HBM first and then copied.
-static double* result_target(E* e) { return e->comm ? e->gram_dev : e->gram_host_dev; }
+static double* result_target(E* e) { return has_comm(e) ? e->gram_dev : e->gram_host_dev; }
 static int result_fetch(E* e, size_t count) {
-  if (e->comm) {
-    NCCLCHK(g_rccl.AllReduce(e->gram_dev, e->gram_dev, count, ncclDouble, ncclSum, e->comm, e->stream));
+  if (has_comm(e)) {
+    CHK(coll_allreduce(e, e->gram_dev, count));
     HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
   }
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -902,7 +966,8 @@ extern "C" int dav_panel_get(dav_handle_t e, int panel, int c0, int k, double* o
   CHK(bind(e));
   CHK(check_panel(e, panel, c0, k));
   if (ld < e->n) return fail("dav_panel_get: leading dimension too small");
-  if (!e->comm) {
+  if (!has_comm(e)) {
+    CHK(need_comm(e));
     HIPCHK(hipMemcpy2DAsync(out, sizeof(double) * ld, panel_ptr(e, panel, c0), sizeof(double) * e->ldp,
                             sizeof(double) * e->n, (size_t)k, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -910,7 +975,7 @@ extern "C" int dav_panel_get(dav_handle_t e, int panel, int c0, int k, double* o
   }
   CHK(need_comm(e));
   for (int j = 0; j < k; ++j) {
-    NCCLCHK(g_rccl.AllGather(panel_ptr(e, panel, c0 + j), e->gather_dev, (size_t)e->nslab, ncclDouble, e->comm, e->stream));
+    CHK(coll_allgather(e, panel_ptr(e, panel, c0 + j), e->gather_dev, (size_t)e->nslab));
     HIPCHK(hipMemcpyAsync(out + j * ld, e->gather_dev, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
   }

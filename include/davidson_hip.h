@@ -70,6 +70,9 @@ int dav_destroy(dav_handle_t h);
  * distributes it, every rank calls dav_comm_init.  Not needed when nranks == 1. */
 int dav_comm_unique_id(void* id128);
 int dav_comm_init(dav_handle_t h, const void* id128);
+/* Test transport: the n engines (created with rank r of n, same process, same GPU) exchange through
+ * device copies and thread barriers instead of RCCL; each rank must then be driven by its own thread. */
+int dav_local_group_join(dav_handle_t* handles, int n);
 int dav_synchronize(dav_handle_t h);
 int dav_get_stats(dav_handle_t h, dav_stats* out);
 int dav_reset_stats(dav_handle_t h);
