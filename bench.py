@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--large-n", type=int, default=200000, help="order of the configs[2] solve (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--control-plane-only", action="store_true",
+                    help="exercise the launch plumbing (rendezvous, id broadcast, barrier, max over ranks) without a GPU")
     ap.add_argument("--cpu-n", type=int, default=0, help="order for the CPU baseline (0 = same as --n)")
     return ap.parse_args()
 
@@ -129,6 +131,23 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if args.control_plane_only:
+        # CPU-testable part of the multi-GPU launch: what bench.py does around the engine
+        ident = [bytes(range(128)) if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+            dist.barrier()
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert float(t.item()) == float(world)
+        assert ident[0] == bytes(range(128))
+        from fortran_davidson_amd.distributed import RowPartition
+        part = RowPartition(args.n, world, rank)
+        if rank == 0:
+            print(json.dumps({"control_plane": "ok", "world": world, "rows_rank0": list(part.rows())}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -69,3 +69,19 @@ def test_sharded_three_ranks_uneven_rows(tmp_path):
     assert int(res["iters"]) == it_o
     r = np.linalg.norm(A @ res["vec"] - res["vec"] * res["lam"][None, :], axis=0)
     assert (r < 1e-8).all()
+
+
+def test_bench_launch_plumbing_world_size_2():
+    """bench.py under torch.distributed.run with 2 ranks on CPU: rendezvous on 127.0.0.1, gloo group,
+    unique-id broadcast, barrier, max over ranks (the control plane around the RCCL engine)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--control-plane-only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["control_plane"] == "ok" and out["world"] == 2 and out["rows_rank0"] == [0, 10000]
