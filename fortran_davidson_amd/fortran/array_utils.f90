@@ -50,7 +50,9 @@ contains
   !> Symmetric test matrix: off-diagonal entries uniform in [0, sparsity), diagonal = row index or
   !> diag_val (semantics of src/array_utils.f90:86-113).  The uniform stream is the counter-based
   !> splitmix64 hash shared bit for bit with the device generator (csrc/common.h) and the oracle, so
-  !> host and GPU build the same matrix; `seed` selects the stream (default 1).
+  !> host and GPU build the same matrix.  `seed` selects the stream; without it successive calls use
+  !> streams 1, 2, 3, ... - like the reference, whose `random_number` stream advances, two calls in
+  !> one program give two different matrices, but here reproducibly.
   function generate_diagonal_dominant(m, sparsity, diag_val, seed) result(arr)
     integer, intent(in) :: m
     real(dp) :: sparsity
@@ -59,8 +61,13 @@ contains
     real(dp), dimension(m, m) :: arr
     integer(int64) :: s, key, lo, hi
     integer :: i, j
-    s = 1_int64
-    if (present(seed)) s = int(seed, int64)
+    integer, save :: calls_without_seed = 0
+    if (present(seed)) then
+       s = int(seed, int64)
+    else
+       calls_without_seed = calls_without_seed + 1
+       s = int(calls_without_seed, int64)
+    end if
     do j = 1, m
        do i = 1, j - 1
           lo = int(i - 1, int64)

@@ -47,3 +47,18 @@ $FC -shared -Wl,-Bsymbolic -fopenmp=libiomp5 -o "$OUT/libref_davidson.so" \
   "$TMP/lapack_wrapper.o" "$TMP/numeric_kinds.o" \
   -L"$MKL_DIR" -lmkl_rt -Wl,-rpath,"$MKL_DIR"
 echo "build_ref: wrote $OUT/libref_davidson.so"
+
+# ---- the reference's own test programs, UNCHANGED, linked against OUR modules/libraries ---------------
+# (drop-in proof: they run on the MI355X engine in `pytest -m gpu`, see tests/test_reference_programs_gpu.py)
+OURS="$HERE/../fortran_davidson_amd"
+if [ -e "$OURS/lib/libfortran_davidson_amd.so" ] && [ -d "$OURS/fortran/build" ]; then
+  mkdir -p "$OUT/ref_tests"
+  T2="$(mktemp -d)"
+  for prog in test_dense_properties test_free_properties test_dense_numpy test_free_numpy test_call_lapack; do
+    $FC -O1 -fopenmp=libiomp5 -I"$OURS/fortran/build" -module-dir "$T2" "$REF/tests/test_utils.f90" "$REF/tests/$prog.f90" \
+      -L"$OURS/lib" -lfortran_davidson_amd -ldavidson_hip -Wl,-rpath,'$ORIGIN/../../../fortran_davidson_amd/lib' \
+      -L"$MKL_DIR" -Wl,-rpath,"$MKL_DIR" -o "$OUT/ref_tests/$prog"
+  done
+  rm -rf "$T2"
+  echo "build_ref: wrote $OUT/ref_tests/ (reference test programs on our libraries)"
+fi
