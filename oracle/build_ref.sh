@@ -59,6 +59,14 @@ if [ -e "$OURS/lib/libfortran_davidson_amd.so" ] && [ -d "$OURS/fortran/build" ]
       -L"$OURS/lib" -lfortran_davidson_amd -ldavidson_hip -Wl,-rpath,'$ORIGIN/../../../fortran_davidson_amd/lib' \
       -L"$MKL_DIR" -Wl,-rpath,"$MKL_DIR" -o "$OUT/ref_tests/$prog"
   done
+  # the two demo drivers (each carries its own copy of the helper module)
+  for prog in main benchmark_free; do
+    T3="$(mktemp -d)"
+    $FC -O1 -fopenmp=libiomp5 -I"$OURS/fortran/build" -module-dir "$T3" "$REF/$prog.f90" \
+      -L"$OURS/lib" -lfortran_davidson_amd -ldavidson_hip -Wl,-rpath,'$ORIGIN/../../../fortran_davidson_amd/lib' \
+      -L"$MKL_DIR" -Wl,-rpath,"$MKL_DIR" -o "$OUT/ref_tests/$prog"
+    rm -rf "$T3"
+  done
   rm -rf "$T2"
   echo "build_ref: wrote $OUT/ref_tests/ (reference test programs on our libraries)"
 fi

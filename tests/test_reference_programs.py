@@ -21,7 +21,8 @@ def run(prog, cwd):
     exe = os.path.join(BIN, prog)
     if not os.path.exists(exe):
         pytest.skip(f"{exe} not built (oracle/build_ref.sh needs /root/reference)")
-    res = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=cwd)
+    env = dict(os.environ, OMP_NUM_THREADS="8")       # the callbacks' OpenMP loop (free_matmul) on a 256-thread host
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=cwd, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
     return res.stdout
 
@@ -89,3 +90,22 @@ def test_reference_free_numpy_program(tmp_path):
     vs = load(tmp_path, "eigenvectors_DPR_free.txt", (50, 3))
     assert np.allclose(es, scipy.linalg.eigh(mtx, b=stx)[0][:3])
     assert (np.linalg.norm(mtx @ vs - (stx @ vs) * es[None, :], axis=0) < 1e-8).all()
+
+
+@pytest.mark.gpu
+def test_reference_demo_program_main(tmp_path):
+    """src/main.f90: N=100 generalized problem, GJD vs DPR, tol 1e-5, max_dim 10."""
+    out = run("main", tmp_path)
+    assert re.search(r"computed by different methods are the same:\s+T", out), out
+    errs = [float(x) for x in re.findall(r"\|\|Error\|\|:\s+([0-9.Ee+-]+)", out)]
+    assert len(errs) == 6 and max(errs) < 1e-5, out          # tolerance of the demo (main.f90:52-54)
+    its = [int(x) for x in re.findall(r"converged in:\s+(\d+)", out)]
+    assert len(its) == 2 and all(0 < i <= 1000 for i in its)
+
+
+@pytest.mark.gpu
+def test_reference_benchmark_free_program(tmp_path):
+    """src/benchmark_free.f90: N=1000 matrix-free through host callbacks (free_matmul), B = I."""
+    out = run("benchmark_free", tmp_path)
+    flags = re.findall(r"succeeded:\s*([TF])", out)
+    assert len(flags) == 3 and all(f == "T" for f in flags), out
