@@ -177,9 +177,7 @@ static int collect_events(E* e) {
   e->ev_used = 0;
   return 0;
 }
-struct Timed {   // RAII-less helper: begin/end record an event pair on the stream
-  E* e; int slot;
-};
+// begin/end record an event pair on the stream; collect_events() turns pairs into milliseconds
 static int timed_begin(E* e, int kind, double bytes, int* slot) {
   if (e->ev_used == N_EVPAIRS) CHK(collect_events(e));
   *slot = e->ev_used++;

@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
   for (int bt = 0; bt < nbatch; ++bt) {
     const int J = J0 + (bt >> 2), cb = bt & 3;
     const bool offdiag = (J != I);
-    f64x4 z[4], z2[4];            // two accumulator chains per step: a dependent MFMA never follows its producer
+    f64x4 z[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) z[jt] = z2[jt] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int jt = 0; jt < 4; ++jt) z[jt] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       f64x2 (&a)[4][2] = ra[jt];
@@ -112,14 +112,21 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
         acc[3] = mfma_f64(a[u][1].y, b[u], acc[3]);
       }
       if (offdiag) {
+        // four independent accumulator chains (as in the direct product): a dependent f64 MFMA issued
+        // fewer than ~4 slots behind its producer stalls the pipe (SQ_WAIT_INST_ANY was 51 % of wave time
+        // with one or two chains)
+        f64x4 zc[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
           const int xr = (wave * 64 + 16 * ib + 4 * g) * XS + c;
-          z[jt] = mfma_f64(p[ib][0].x, xs[xr], z[jt]);
-          z2[jt] = mfma_f64(p[ib][0].y, xs[xr + XS], z2[jt]);
-          z[jt] = mfma_f64(p[ib][1].x, xs[xr + 2 * XS], z[jt]);
-          z2[jt] = mfma_f64(p[ib][1].y, xs[xr + 3 * XS], z2[jt]);
+          zc[0] = mfma_f64(p[ib][0].x, xs[xr], zc[0]);
+          zc[1] = mfma_f64(p[ib][0].y, xs[xr + XS], zc[1]);
+          zc[2] = mfma_f64(p[ib][1].x, xs[xr + 2 * XS], zc[2]);
+          zc[3] = mfma_f64(p[ib][1].y, xs[xr + 3 * XS], zc[3]);
         }
+        z[jt] = (zc[0] + zc[1]) + (zc[2] + zc[3]);
       }
     }
     if (offdiag) {
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) red[wave][c * RS + jt * 16 + g + 4 * reg] = z[jt][reg] + z2[jt][reg];
+        for (int reg = 0; reg < 4; ++reg) red[wave][c * RS + jt * 16 + g + 4 * reg] = z[jt][reg];
       __syncthreads();
       // slabT tile (I, J): [16 block columns][256 tile columns]
       double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16) * SYM_TB + cb * 64;

@@ -10,7 +10,6 @@ constexpr int MV_ROWS = 256;
 // (zero padded) for rows [0, nloc_pad) of this rank, written at row offset `row_off`.
 void launch_pack_xt(hipStream_t st, const double* src, int64_t ld, int64_t nloc, int64_t nslab, int k,
                     double* xt, int64_t xt_group_stride, int64_t row_off);
-// Pad rows [n_valid, ncols_pad) of every group with zeros (called once at setup).
 // slab[s][col][row] = A[rows, chunk s] * X[chunk s, col]; ngroups = ceil(k/16) in {1,2,4}.
 void launch_matvec_dense(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad,
                          const double* xt, int64_t xt_group_stride, int ngroups, double* slab,

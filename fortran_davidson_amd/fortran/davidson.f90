@@ -31,7 +31,6 @@ module davidson_device
      integer :: n = 0
      integer :: max_cols = 0
      logical :: gev = .false.
-     logical :: device_operators = .true.
   end type davidson_engine
 
   !> Wall time of the last solve by phase (seconds): 1 setup (init basis + first projection),
@@ -635,7 +634,6 @@ contains
     call extract_diagonal_blocked(fun_second_matrix_gemv, n, diag_b)
 
     call engine_create(eng, n, lowest, max_dim, .true.)
-    eng%device_operators = .false.
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_A, diag_a), "dav_set_operator_host")
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_B, diag_b), "dav_set_operator_host")
     call davidson_device_loop(eng%h, n, lowest, method, max_iterations, tolerance, iters, max_dim, .true., &
