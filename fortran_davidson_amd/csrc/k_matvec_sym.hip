@@ -22,7 +22,11 @@
 // memory in the Gram layout (late: misses L2 and doubles HBM traffic; early: as many registers as the
 // LDS scheme and twice the TA work); interleaving the dependent transposed MFMAs with the direct ones
 // (9 % slower); two 16-column groups per pass (registers/LDS exceed 2 waves per SIMD, slower than two
-// passes).
+// passes); producing the Gram-layout operand one step ahead with sched_group_barrier interleaving (same
+// speed: hipcc keeps the DS writes in one block).  Counters (profiles/r01_pmc_mfma_clock_n40000.json,
+// N=40000): matrix pipe 43 % busy at 2.34 GHz, wave time = 51 % MFMA issue-blocked + 26 % s_waitcnt/barrier
+// + 20 % issuing the ~80 VALU / 30 DS / 13 VMEM instructions per step; HBM fetch = tile bytes.  What is
+// left is the per-64-column cross-wave reduction and the un-overlapped non-MFMA issue at one wave per SIMD.
 #include "kernels.h"
 
 // tile (I, J), J <= I, at tiles + (I (I+1)/2 + J) * TB*TB, column-major with leading dimension TB
