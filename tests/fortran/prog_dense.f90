@@ -11,6 +11,8 @@ program prog_dense
   real(dp) :: ev_dpr(lowest), ev_gjd(lowest), ev_gen(lowest), ev_gen_gjd(lowest)
   real(dp) :: x_dpr(dim, lowest), x_gjd(dim, lowest), x_gen(dim, lowest), x_gen_gjd(dim, lowest)
   real(dp) :: r(dim)
+  real(dp) :: big(dim + 7, dim + 3), ev_sec(lowest), x_sec(dim + 2, lowest)
+  integer :: it_sec
   integer :: it_dpr, it_gjd, it_gen, it_gen_gjd, j, nfail
 
   nfail = 0
@@ -36,6 +38,17 @@ program prog_dense
      call check("unit_norm", abs(norm(x_dpr(:, j)) - 1d0) < 1d-10)
   end do
   call check("ascending", ev_dpr(1) < ev_dpr(2) .and. ev_dpr(2) < ev_dpr(3))
+
+  ! non-contiguous array sections and keyword arguments, as any assumed-shape API must accept
+  big = -1.0_dp
+  big(4:dim + 3, 2:dim + 1) = mtx
+  x_sec = 0.0_dp
+  call generalized_eigensolver(big(4:dim + 3, 2:dim + 1), ev_sec, x_sec(2:dim + 1, :), lowest, "DPR", &
+       max_iterations=1000, tolerance=1d-8, iters=it_sec, max_dim_sub=12)
+  call check("section_input_same_eigenvalues", norm(ev_sec - ev_dpr) < 1d-8)
+  call check("section_output_untouched_border", all(x_sec(1, :) == 0.0_dp) .and. all(x_sec(dim + 2, :) == 0.0_dp))
+  r = matmul(mtx, x_sec(2:dim + 1, 1)) - ev_sec(1) * x_sec(2:dim + 1, 1)
+  call check("section_residual", norm(r) < 1d-8)
   print "(a, 4i4)", "ITERS", it_dpr, it_gjd, it_gen, it_gen_gjd
   print "(a, 3es24.16)", "EVALS_DPR", ev_dpr
   print "(a, 3es24.16)", "EVALS_GEN", ev_gen
