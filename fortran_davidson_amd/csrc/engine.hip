@@ -539,8 +539,8 @@ extern "C" int dav_set_storage(dav_handle_t e, int mode) {
   return 0;
 }
 
-extern "C" int dav_set_dense_host(dav_handle_t e, int which, const double* a, int64_t lda) {
-  if (which < 0 || which > 1 || !a || lda < e->n) return fail("dav_set_dense_host: bad arguments");
+static int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind kind) {
+  if (which < 0 || which > 1 || !a || lda < e->n) return fail("dav_set_dense: bad arguments");
   CHK(bind(e));
   CHK(alloc_dense(e, which));
   OpDesc& o = e->op[which];
@@ -556,7 +556,7 @@ extern "C" int dav_set_dense_host(dav_handle_t e, int which, const double* a, in
         if (nr <= 0 || nc <= 0) continue;
         double* tile = o.a + ((int64_t)I * (I + 1) / 2 + J) * (int64_t)(SYM_TB * SYM_TB);
         HIPCHK(hipMemcpy2DAsync(tile, sizeof(double) * SYM_TB, a + r0 + c0 * lda, sizeof(double) * lda, sizeof(double) * nr,
-                                (size_t)nc, hipMemcpyHostToDevice, e->stream));
+                                (size_t)nc, kind, e->stream));
       }
     launch_diag_sym(e->stream, o.a, e->n, o.diag);
     CHK(refresh_diag_host(e, which));
@@ -565,10 +565,18 @@ extern "C" int dav_set_dense_host(dav_handle_t e, int which, const double* a, in
   HIPCHK(hipMemsetAsync(o.a, 0, sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad, e->stream));
   if (e->nloc > 0)
     HIPCHK(hipMemcpy2DAsync(o.a, sizeof(double) * e->nloc_pad, a + e->row0, sizeof(double) * lda,
-                            sizeof(double) * e->nloc, (size_t)e->n, hipMemcpyHostToDevice, e->stream));
+                            sizeof(double) * e->nloc, (size_t)e->n, kind, e->stream));
   launch_diag_dense(e->stream, o.a, e->nloc_pad, e->row0, e->nloc, o.diag);
   CHK(refresh_diag_host(e, which));
   return 0;
+}
+
+extern "C" int dav_set_dense_host(dav_handle_t e, int which, const double* a, int64_t lda) {
+  return set_dense_from(e, which, a, lda, hipMemcpyHostToDevice);
+}
+
+extern "C" int dav_set_dense_dev(dav_handle_t e, int which, const double* a_dev, int64_t lda) {
+  return set_dense_from(e, which, a_dev, lda, hipMemcpyDeviceToDevice);
 }
 
 extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed, double sparsity, int use_diag_val,

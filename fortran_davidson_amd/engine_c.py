@@ -102,6 +102,10 @@ class CEngine:
         a = _f(a)
         self._chk(self.lib.dav_set_dense_host(self.h, C.c_int(which), _dp(a), C.c_int64(a.shape[0])))
 
+    def set_dense_dev(self, which, dev_ptr, lda):
+        """a(lda, n) column-major in device memory (e.g. a torch tensor's data_ptr())."""
+        self._chk(self.lib.dav_set_dense_dev(self.h, C.c_int(which), C.c_void_p(dev_ptr), C.c_int64(lda)))
+
     def set_dense_generated(self, which, seed, sparsity, diag_val=None):
         self._chk(self.lib.dav_set_dense_generated(self.h, C.c_int(which), C.c_uint64(seed), C.c_double(sparsity),
                                                    C.c_int(0 if diag_val is None else 1),

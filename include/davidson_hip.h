@@ -89,6 +89,9 @@ int dav_set_storage(dav_handle_t h, int mode);
  * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and
  * extracts the diagonal (replaces array_utils.f90:115-134). */
 int dav_set_dense_host(dav_handle_t h, int which, const double* a, int64_t lda);
+/* Same with a(lda, n) already in device memory (e.g. produced by an upstream GPU stage): copied once
+ * into the engine's padded slab / tile layout, the caller's buffer is not referenced afterwards. */
+int dav_set_dense_dev(dav_handle_t h, int which, const double* a_dev, int64_t lda);
 /* Dense matrix generated directly in HBM with the semantics of generate_diagonal_dominant
  * (src/array_utils.f90:86-113) and the counter-based stream of oracle/davidson_oracle.py. */
 int dav_set_dense_generated(dav_handle_t h, int which, uint64_t seed, double sparsity,

@@ -250,3 +250,24 @@ def test_symmetric_tiled_generated_matrix_and_solver_phases():
         assert relerr(e.panel_get(PANEL_R, 0, 5), A @ X) < 1e-12
         with pytest.raises(fd.DavidsonHipError):
             fd.CEngine(n=100, max_cols=16, rank=0, nranks=2).set_storage(1)
+
+
+@pytest.mark.parametrize("storage", [0, 1])
+def test_dense_matrix_from_device_memory(storage):
+    """dav_set_dense_dev: the matrix comes from a device buffer owned by someone else (a torch tensor)."""
+    import torch
+    n, k = 600, 7
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    X = rng.standard_normal((n, k))
+    t = torch.from_numpy(np.ascontiguousarray(A.T)).cuda()          # row-major of A^T == column-major of A
+    with fd.CEngine(n=n, max_cols=16) as e:
+        e.set_storage(storage)
+        e.set_dense_dev(OP_A, t.data_ptr(), n)
+        del t
+        torch.cuda.empty_cache()
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        assert relerr(e.panel_get(PANEL_W, 0, k), A @ X) < RTOL * n
+        assert np.array_equal(e.get_diagonal(OP_A), np.diag(A))
