@@ -325,3 +325,17 @@ def test_multi_rank_matrix_free_operator_through_loopback_transport():
         assert (residuals(A, None, lam, vec) < 1e-8).all()
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("n,L,sp,md,gev", [(200, 3, 5e-2, None, False), (300, 4, 1e-1, None, False),
+                                           (200, 3, 5e-2, 10, True), (400, 5, 2e-2, None, True), (150, 2, 3e-1, 8, False)])
+def test_gjd_on_harder_matrices_matches_oracle_iteration_counts(n, L, sp, md, gev):
+    """Strong off-diagonals, generalized problems and restarts: the device MINRES corrections must drive
+    the outer iteration exactly like the reference's dense DSYSV solves."""
+    A = O.generate_diagonal_dominant(n, sp, seed=5)
+    B = O.generate_diagonal_dominant(n, sp * 0.1, 1.0, seed=6) if gev else None
+    lam_o, _, it_o = O.generalized_eigensolver_dense(A, L, "GJD", 40, 1e-8, md, B)
+    lam, vec, it = fd.generalized_eigensolver(A, L, "GJD", 40, 1e-8, md, B)
+    assert it == it_o
+    assert np.abs(lam - lam_o).max() < EV_TOL
+    assert (residuals(A, B, lam, vec) < 1e-8).all()
