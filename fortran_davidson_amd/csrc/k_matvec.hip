@@ -169,9 +169,26 @@ void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit,
     target = env ? atoll(env) : -1;
     if (target == 0) target = -1;
   }
-  // measured on MI355X: ~2048 workgroups is best at N=20000 (5.6 TB/s), ~1024 for N>=60000 (6.0 TB/s)
-  int64_t want = target > 0 ? target : (rowblocks >= 200 ? 1024 : 2048);
-  int64_t s = (want + rowblocks - 1) / rowblocks;
+  // Measured on MI355X (N=20000, 79 row blocks, split count swept 12..64): the sweep is fastest when the
+  // grid just fills the resident capacity once (256 CUs x 5 workgroups = 1280): 16 splits = 1264
+  // workgroups gives 5.6 TB/s, 17 splits (1343, a second sparsely filled round) 5.37, 26 splits 5.35.
+  // So: the largest split count whose grid does not exceed one full round; for tall matrices (few
+  // splits possible) fall back to ~1024 workgroups.
+  int64_t s;
+  if (target > 0) {
+    s = (target + rowblocks - 1) / rowblocks;
+  } else {
+    s = 1280 / rowblocks;
+    if (s < 1 || rowblocks * s < 900) s = (1024 + rowblocks - 1) / rowblocks;
+  }
+  {
+    static int64_t forced = -1;                // DAV_MV_NSPLIT: exact split count (tuning)
+    if (forced < 0) {
+      const char* env = getenv("DAV_MV_NSPLIT");
+      forced = env ? atoll(env) : 0;
+    }
+    if (forced > 0) s = forced;
+  }
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   int64_t chunk = (ncols_pad + s - 1) / s;
