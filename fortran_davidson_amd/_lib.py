@@ -7,7 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_LIB = os.path.join(LIB_DIR, "libdavidson_hip.so")
+HIP_LIB = os.environ.get("DAVIDSON_HIP_LIB", os.path.join(LIB_DIR, "libdavidson_hip.so"))   # override: A/B builds
 FORTRAN_LIB = os.path.join(LIB_DIR, "libfortran_davidson_amd.so")
 
 _hip = None

@@ -3,31 +3,38 @@
 // entries, which is what makes N = 200000 (160 GB) fit one MI355X - and every off-diagonal tile is
 // used twice per sweep:   W_I += A_IJ X_J   (direct)   and   W_J += A_IJ^T X_I   (transposed).
 //
-// Workgroup = 4 waves, one run of tiles (I, J0..J1) of block row I.  Wave w owns rows 64w..64w+63 of
-// the block row.  Per 16-column step it holds its 64 x 16 sub-block in registers in the "direct" lane
-// layout (16 B = 2 rows of one column per lane; MFMA contraction over columns, accumulators 64 rows x
-// 16 stay in registers for the whole run); the "Gram" lane layout the transposed product needs
-// (4 consecutive rows of one column per lane; MFMA contraction over rows) is made through a
-// wave-private LDS scratch (8 x ds_write_b128 + 8 x ds_read_b128, no barrier: a wave's DS operations
-// complete in order).  The transposed partials of the four waves are summed through LDS once per 64
-// columns and written to a per-tile slab; direct partials go to a per-run slab; a second kernel adds,
-// in fixed order, the slabs that belong to each output block (bitwise reproducible, no fp64 atomics).
+// Workgroup = 4 waves, one run of tiles (I, J0..J1) of block row I.  Inside every 64-column batch of a
+// tile wave w owns the 16 tile columns 16w..16w+15 over ALL 256 rows ("unit" = 256 x 16, processed as four
+// 64-row steps).  That choice makes the transposed partial Z (16 tile columns x 16 block columns, summed
+// over the 256 rows) complete inside one wave - it goes from the accumulators straight to the per-tile
+// slab, with no cross-wave exchange and no barrier anywhere in the main loop - while the direct partials
+// (256 rows x 16 block columns = 128 accumulator registers per wave) stay in registers for the whole run
+// and are summed over the four waves once, at the end of the run.  Per step the 64 x 16 sub-block sits in
+// registers in the "direct" lane layout (16 B = 2 rows of one column per lane; MFMA contraction over
+// columns); the "Gram" lane layout the transposed product needs (4 consecutive rows of one column per
+// lane; MFMA contraction over rows) is made through a wave-private LDS scratch (8 x ds_write_b128 +
+// 8 x ds_read_b128, no barrier: a wave's DS operations complete in order).  A second kernel adds, in fixed
+// order, the slabs that belong to each output block (bitwise reproducible, no fp64 atomics).
 //
-// Load pipeline: a 4-slot register ring indexed by the (compile-time) step number inside a 64-column
-// batch; the loads of step q+3 are issued before the MFMAs of step q, with no register moves (a rotating
-// buffer with moves makes the compiler wait for the newest loads at the end of every step, which is what
-// the first versions of this kernel did).  One wave per SIMD, up to 24 KB in flight per wave.
+// Load pipeline: a 4-slot register ring indexed by the (compile-time) 64-row group of the step; the loads
+// of step s+3 are issued before the MFMAs of step s, with no register moves (a rotating buffer with moves
+// makes the compiler wait for the newest loads at the end of every step, which is what the first versions
+// of this kernel did).  One wave per SIMD, up to 24 KB in flight per wave.
 //
-// Measured dead ends, kept here so they are not retried blindly: re-reading the sub-block from global
-// memory in the Gram layout (late: misses L2 and doubles HBM traffic; early: as many registers as the
-// LDS scheme and twice the TA work); interleaving the dependent transposed MFMAs with the direct ones
-// (9 % slower); two 16-column groups per pass (registers/LDS exceed 2 waves per SIMD, slower than two
-// passes); producing the Gram-layout operand one step ahead with sched_group_barrier interleaving (same
-// speed: hipcc keeps the DS writes in one block).  Counters (profiles/r01_pmc_mfma_clock_n40000.json,
-// N=40000): matrix pipe 43 % busy at 2.34 GHz, wave time = 51 % MFMA issue-blocked + 26 % s_waitcnt/barrier
-// + 20 % issuing the ~80 VALU / 30 DS / 13 VMEM instructions per step; HBM fetch = tile bytes.  What is
-// left is the per-64-column cross-wave reduction and the un-overlapped non-MFMA issue at one wave per SIMD.
+// History, so that measured dead ends are not retried blindly.  v5 gave each wave 64 rows of every
+// 16-column step and summed the transposed partials of the four waves through LDS once per 64 columns
+// (two barriers each); same box, N=60000 / N=200000, k=16: v5 3.38 / 34.6 ms, the same with a branch-free
+// body and X_I kept in registers 3.36 ms, this version 3.34 / 32.9 ms.  Also tried on v5: re-reading the
+// sub-block from global memory in the Gram layout (late: misses L2 and doubles HBM traffic; early: as many
+// registers as the LDS scheme and twice the TA work); interleaving the dependent transposed MFMAs with the
+// direct ones (9 % slower); two 16-column groups per pass (slower than two passes); producing the Gram
+// operand one step ahead with sched_group_barrier (same speed); summing the waves once per 128 columns
+// (1 %); runs of 4..14 tiles per workgroup (within 2 %; a workgroup costs ~7 us to start and drain).
+// Counters (profiles/r01_pmc_mfma_clock_n40000.json, v5, N=40000): matrix pipe 43 % busy at 2.34 GHz, HBM
+// fetch = tile bytes.  Traffic per sweep: the stored half matrix once, plus 1/16 of it written as per-tile
+// Z slabs and read back by the reduction kernel (8 % of the sweep time) - the price of a deterministic sum.
 #include "kernels.h"
+#include <type_traits>
 
 // tile (I, J), J <= I, at tiles + (I (I+1)/2 + J) * TB*TB, column-major with leading dimension TB
 __device__ __forceinline__ const double* sym_tile(const double* tiles, int I, int J) {
@@ -39,124 +46,152 @@ constexpr int SYM_DEPTH = 3;      // steps of load lookahead (ring of 4 slots)
 __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
                                                             const double* __restrict__ xt, double* __restrict__ slabD,
                                                             double* __restrict__ slabT) {
-  constexpr int RS = 65;          // padded stride of the Z-partial exchange: block columns on different banks
+  constexpr int RS = 65;          // padded stride of the end-of-run exchange of the direct partials
   constexpr int TRS = 66;         // padded column stride of the transposition scratch (528 B)
-  constexpr int XS = 17;          // padded row stride of the X_I copy
-  __shared__ double red[4][RS * 16];
+  constexpr int XT = 258;         // padded column stride of the transposed X_I copy (b128 reads conflict free)
   __shared__ __attribute__((aligned(16))) double tr[4][16 * TRS];
-  __shared__ double xs[SYM_TB * XS];
+  __shared__ __attribute__((aligned(16))) double xsT[16 * XT];
+  static_assert(16 * TRS >= 16 * RS, "the end-of-run exchange reuses the transposition scratch");
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int I = items[3 * blockIdx.x], J0 = items[3 * blockIdx.x + 1], J1 = items[3 * blockIdx.x + 2];
 
-  // B operand of the transposed product: the X_I rows of this block row (LDS, padded rows)
+  // B operand of the transposed product: X_I, stored transposed ([block column][row]) so that the four
+  // consecutive rows a lane needs are one 32-byte run
   for (int e = threadIdx.x; e < SYM_TB * 16; e += 256)
-    xs[(e >> 4) * XS + (e & 15)] = xt[((int64_t)I * SYM_TB + (e >> 4)) * 16 + (e & 15)];
+    xsT[(e & 15) * XT + (e >> 4)] = xt[((int64_t)I * SYM_TB + (e >> 4)) * 16 + (e & 15)];
   __syncthreads();
 
-  f64x4 acc[4];
+  // direct partials: all 256 rows of the block row x 16 block columns, for the tile columns this wave owns
+  f64x4 acc[4][4];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) acc[rt] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rg][rt] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  const int nbatch = (J1 - J0) * 4;                 // 64-column batches
-  const int nsteps = nbatch * 4;                    // 16-column steps
-  const int64_t dlane = wave * 64 + 2 * c + (int64_t)g * SYM_TB;
+  const int nunits = (J1 - J0) * 4;                 // 16-column units of this wave (one per 64-column batch)
+  const int nsteps = nunits * 4;                    // (unit, 64-row group) steps
+  const int64_t dlane = 2 * c + (int64_t)g * SYM_TB;
   double* tw = tr[wave];
 
-  // ring slot of step q is q & 3 (= jt inside a batch): A sub-block in the direct layout + B operand
+  // ring slot of step s is s & 3 (= the row group): the 64 x 16 sub-block in the direct layout
   f64x2 ra[4][4][2];
-  double rb[4][4];
-  auto load_step = [&](int q, f64x2 (&a)[4][2], double (&b)[4]) {
-    q = q < nsteps ? q : nsteps - 1;                // clamped at the end of the run: a harmless re-read
-    const int J = J0 + (q >> 4), col = (q & 15) * 16;
-    const double* ad = sym_tile(tiles, I, J) + (int64_t)col * SYM_TB + dlane;
-    const double* xj = xt + ((int64_t)J * SYM_TB + col + g) * 16 + c;
+  auto load_step = [&](int s, f64x2 (&a)[4][2]) {
+    s = s < nsteps ? s : nsteps - 1;                // clamped at the end of the run: a harmless re-read
+    const int q = s >> 2, rg = s & 3;
+    const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
+    const double* ad = sym_tile(tiles, I, J) + (int64_t)col * SYM_TB + rg * 64 + dlane;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       a[u][0] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
       a[u][1] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB + 32);
-      b[u] = xj[(4 * u) * 16];
     }
   };
+  // B operand of the direct product for unit q: X_J rows (tile columns) of the unit
+  auto load_b = [&](int q, double (&b)[4]) {
+    q = q < nunits ? q : nunits - 1;
+    const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
+    const double* xj = xt + ((int64_t)J * SYM_TB + col + g) * 16 + c;
 #pragma unroll
-  for (int d = 0; d < SYM_DEPTH; ++d) load_step(d, ra[d], rb[d]);
+    for (int u = 0; u < 4; ++u) b[u] = xj[(4 * u) * 16];
+  };
+  double b[4], bn[4];
+  load_b(0, b);
+#pragma unroll
+  for (int d = 0; d < SYM_DEPTH; ++d) load_step(d, ra[d]);
 
-  for (int bt = 0; bt < nbatch; ++bt) {
-    const int J = J0 + (bt >> 2), cb = bt & 3;
-    const bool offdiag = (J != I);
-    f64x4 z[4];
+  // One unit = 256 rows x 16 columns of tile (I, J).  OFF = off-diagonal tile (direct + transposed product);
+  // the diagonal tile, always the last of a run, only has the direct product.  Two instantiations instead
+  // of a run-time test keep the body one basic block.
+  auto unit = [&](auto off_tag, int q) {
+    constexpr bool OFF = decltype(off_tag)::value;
+    load_b(q + 1, bn);
+    // X_I is read from LDS again for every unit: as registers its 128 values would not fit.  The opaque
+    // zero keeps the compiler from hoisting the (loop invariant) reads out of the unit loop.
+    int xoff = c * XT + 4 * g;
+    asm volatile("" : "+v"(xoff));
+    const double* xw = xsT + xoff;
+    f64x4 zc[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) z[jt] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int s4 = 0; s4 < 4; ++s4) zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      f64x2 (&a)[4][2] = ra[jt];
-      double (&b)[4] = rb[jt];
-      load_step(bt * 4 + jt + SYM_DEPTH, ra[(jt + SYM_DEPTH) & 3], rb[(jt + SYM_DEPTH) & 3]);
-      f64x2 p[4][2];
-      if (offdiag) {
+    for (int rg = 0; rg < 4; ++rg) {
+      f64x2 (&a)[4][2] = ra[rg];
+      load_step(q * 4 + rg + SYM_DEPTH, ra[(rg + SYM_DEPTH) & 3]);
+      f64x2 p[4][2], xb[4][2];
+      if constexpr (OFF) {
         // direct layout -> LDS: lane (c, g) owns rows 2c, 2c+1 (+32) of column 4u + g
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c) = a[u][0];
           *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c + 32) = a[u][1];
         }
-        // LDS -> Gram layout: lane (c, g) owns rows 16 ib + 4g .. +3 of column c
+        // LDS -> Gram layout: lane (c, g) owns rows 16 ib + 4g .. +3 of column c; same rows of X_I
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
           p[ib][0] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g);
           p[ib][1] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g + 2);
+          xb[ib][0] = *reinterpret_cast<const f64x2*>(xw + rg * 64 + 16 * ib);
+          xb[ib][1] = *reinterpret_cast<const f64x2*>(xw + rg * 64 + 16 * ib + 2);
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        acc[0] = mfma_f64(a[u][0].x, b[u], acc[0]);
-        acc[1] = mfma_f64(a[u][0].y, b[u], acc[1]);
-        acc[2] = mfma_f64(a[u][1].x, b[u], acc[2]);
-        acc[3] = mfma_f64(a[u][1].y, b[u], acc[3]);
+        acc[rg][0] = mfma_f64(a[u][0].x, b[u], acc[rg][0]);
+        acc[rg][1] = mfma_f64(a[u][0].y, b[u], acc[rg][1]);
+        acc[rg][2] = mfma_f64(a[u][1].x, b[u], acc[rg][2]);
+        acc[rg][3] = mfma_f64(a[u][1].y, b[u], acc[rg][3]);
       }
-      if (offdiag) {
-        // four independent accumulator chains (as in the direct product): a dependent f64 MFMA issued
-        // fewer than ~4 slots behind its producer stalls the pipe (SQ_WAIT_INST_ANY was 51 % of wave time
-        // with one or two chains)
-        f64x4 zc[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0};
+      if constexpr (OFF) {
+        // four independent accumulator chains: a dependent f64 MFMA issued fewer than ~4 slots behind its
+        // producer stalls the pipe
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
-          const int xr = (wave * 64 + 16 * ib + 4 * g) * XS + c;
-          zc[0] = mfma_f64(p[ib][0].x, xs[xr], zc[0]);
-          zc[1] = mfma_f64(p[ib][0].y, xs[xr + XS], zc[1]);
-          zc[2] = mfma_f64(p[ib][1].x, xs[xr + 2 * XS], zc[2]);
-          zc[3] = mfma_f64(p[ib][1].y, xs[xr + 3 * XS], zc[3]);
+          zc[0] = mfma_f64(p[ib][0].x, xb[ib][0].x, zc[0]);
+          zc[1] = mfma_f64(p[ib][0].y, xb[ib][0].y, zc[1]);
+          zc[2] = mfma_f64(p[ib][1].x, xb[ib][1].x, zc[2]);
+          zc[3] = mfma_f64(p[ib][1].y, xb[ib][1].y, zc[3]);
         }
-        z[jt] = (zc[0] + zc[1]) + (zc[2] + zc[3]);
       }
     }
-    if (offdiag) {
-      // z[jt][reg]: tile column cb*64 + jt*16 + g + 4 reg, block column c.  Sum the 4 waves.
-      __syncthreads();
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) red[wave][c * RS + jt * 16 + g + 4 * reg] = z[jt][reg];
-      __syncthreads();
+    if constexpr (OFF) {
+      // z[reg]: tile column col + g + 4 reg, block column c; complete (all 256 rows) - no cross-wave sum.
       // slabT tile (I, J): [16 block columns][256 tile columns]
-      double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16) * SYM_TB + cb * 64;
-      for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-        const int le = (e >> 6) * RS + (e & 63);
-        outT[(int64_t)(e >> 6) * SYM_TB + (e & 63)] = red[0][le] + red[1][le] + red[2][le] + red[3][le];
-      }
+      const f64x4 z = (zc[0] + zc[1]) + (zc[2] + zc[3]);
+      const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
+      double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16 + c) * SYM_TB + col + g;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
     }
-  }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = bn[u];
+  };
+  const int nq_off = ((J1 - 1 == I ? J1 - 1 : J1) - J0) * 4;
+  int q = 0;
+  for (; q < nq_off; ++q) unit(std::true_type{}, q);
+  for (; q < nunits; ++q) unit(std::false_type{}, q);
 
-  double* outD = slabD + (int64_t)blockIdx.x * 16 * SYM_TB + wave * 64;
+  // end of the run: sum the direct partials of the four waves (they own different tile columns), one
+  // 64-row group at a time, through the scratch the transposition used
+  double* red = &tr[0][0];
+  double* outD = slabD + (int64_t)blockIdx.x * 16 * SYM_TB;
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-    const int half = rt >> 1, par = rt & 1;
+  for (int rg = 0; rg < 4; ++rg) {
+    __syncthreads();
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg)
-      outD[(int64_t)c * SYM_TB + 32 * half + 2 * (g + 4 * reg) + par] = acc[rt][reg];
+    for (int rt = 0; rt < 4; ++rt) {
+      const int half = rt >> 1, par = rt & 1;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        red[wave * 16 * TRS + c * RS + 32 * half + 2 * (g + 4 * reg) + par] = acc[rg][rt][reg];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int le = (e >> 6) * RS + (e & 63);
+      outD[(int64_t)(e >> 6) * SYM_TB + rg * 64 + (e & 63)] =
+          red[le] + red[16 * TRS + le] + red[2 * 16 * TRS + le] + red[3 * 16 * TRS + le];
+    }
   }
 }
 
@@ -177,8 +212,13 @@ __global__ __launch_bounds__(256) void sym_reduce_kernel(const double* __restric
   double sum = 0.0;
   for (int it = row_item_begin[J]; it < row_item_begin[J + 1]; ++it)
     sum += slabD[((int64_t)it * ncol16 + col) * SYM_TB + r];
-  for (int I = J + 1; I < nb; ++I)
-    sum += slabT[((((int64_t)I * (I - 1) / 2 + J) * ncol16) + col) * SYM_TB + r];
+  // four interleaved partial sums (fixed order, so still reproducible): four loads in flight per thread
+  auto zt = [&](int I) { return slabT[((((int64_t)I * (I - 1) / 2 + J) * ncol16) + col) * SYM_TB + r]; };
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int I = J + 1;
+  for (; I + 3 < nb; I += 4) { s0 += zt(I); s1 += zt(I + 1); s2 += zt(I + 2); s3 += zt(I + 3); }
+  for (; I < nb; ++I) s0 += zt(I);
+  sum += (s0 + s1) + (s2 + s3);
   int64_t row = (int64_t)J * SYM_TB + r;
   dst[(int64_t)col * ldd + row] = row < nloc ? sum : 0.0;
 }
