@@ -2,6 +2,7 @@
 // of k_*.hip on one HIP stream; the host (Fortran driver) keeps only m x m matrices.
 #include "../../include/davidson_hip.h"
 #include "kernels.h"
+#include "ingest.h"
 
 #include <dlfcn.h>
 #include <pthread.h>
@@ -143,6 +144,13 @@ struct dav_engine {
   LocalGroup* lg = nullptr;       // loopback transport (tests); owned by rank 0
   OpDesc op[2];
   std::vector<double> diag_host[2];
+  // streaming ingest (dav_dense_begin .. dav_dense_end): two pinned row-major staging buffers + device twins
+  double* ing_host[2] = {nullptr, nullptr};
+  double* ing_dev[2] = {nullptr, nullptr};
+  hipEvent_t ing_done[2] = {nullptr, nullptr};
+  bool ing_pending[2] = {false, false};
+  int64_t ing_cap_rows = 0;
+  int ing_flip = 0, ing_which = -1;
   // statistics
   dav_stats st{};
   hipEvent_t ev[N_EVPAIRS][2];
@@ -151,6 +159,7 @@ struct dav_engine {
   int ev_used = 0;
 };
 typedef dav_engine E;
+static void ingest_release(E* e);
 
 static inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -336,6 +345,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->idx_dev);
   hipFree(e->norm_partial);
   hipFree(e->gjd_ws);
+  ingest_release(e);
   hipFree(e->sym_items);
   hipFree(e->sym_row_begin);
   hipFree(e->sym_slab);
@@ -578,6 +588,135 @@ extern "C" int dav_set_dense_host(dav_handle_t e, int which, const double* a, in
 
 extern "C" int dav_set_dense_dev(dav_handle_t e, int which, const double* a_dev, int64_t lda) {
   return set_dense_from(e, which, a_dev, lda, hipMemcpyDeviceToDevice);
+}
+
+// ---- streaming ingest: rows arrive in the reference's on-disk order (row-major) -----------------------------
+static void ingest_release(E* e) {
+  for (int b = 0; b < 2; ++b) {
+    if (e->ing_done[b]) { hipEventSynchronize(e->ing_done[b]); hipEventDestroy(e->ing_done[b]); e->ing_done[b] = nullptr; }
+    if (e->ing_host[b]) { hipHostFree(e->ing_host[b]); e->ing_host[b] = nullptr; }
+    if (e->ing_dev[b]) { hipFree(e->ing_dev[b]); e->ing_dev[b] = nullptr; }
+    e->ing_pending[b] = false;
+  }
+  e->ing_which = -1;
+}
+
+extern "C" int dav_dense_begin(dav_handle_t e, int which) {
+  if (which < 0 || which > 1) return fail("dav_dense_begin: bad operator id");
+  if (e->ing_which >= 0) return fail("dav_dense_begin: another streaming upload is open (call dav_dense_end)");
+  CHK(bind(e));
+  CHK(alloc_dense(e, which));
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_DENSE;
+  size_t bytes = o.storage == 1 ? sizeof(double) * (size_t)((int64_t)e->sym_nb * (e->sym_nb + 1) / 2) * SYM_TB * SYM_TB
+                                : sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
+  HIPCHK(hipMemsetAsync(o.a, 0, bytes, e->stream));
+  // ~128 MiB per staging buffer, whole rows, at least 32 of them
+  int64_t cap = std::max<int64_t>(32, ((int64_t)128 << 20) / (8 * e->n) / 32 * 32);
+  cap = std::min<int64_t>(cap, roundup(e->n, 32));
+  e->ing_cap_rows = cap;
+  for (int b = 0; b < 2; ++b) {
+    HIPCHK(hipHostMalloc(&e->ing_host[b], sizeof(double) * (size_t)(cap * e->n), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&e->ing_dev[b], sizeof(double) * (size_t)(cap * e->n)));
+    HIPCHK(hipEventCreateWithFlags(&e->ing_done[b], hipEventDisableTiming));
+  }
+  e->ing_flip = 0;
+  e->ing_which = which;
+  return 0;
+}
+
+static int ingest_acquire(E* e, double** buf, int64_t* cap_rows) {
+  if (e->ing_which < 0) return fail("streaming upload is not open (call dav_dense_begin)");
+  int b = e->ing_flip;
+  if (e->ing_pending[b]) { HIPCHK(hipEventSynchronize(e->ing_done[b])); e->ing_pending[b] = false; }
+  *buf = e->ing_host[b];
+  *cap_rows = e->ing_cap_rows;
+  return 0;
+}
+
+static int ingest_commit(E* e, int64_t row0, int64_t nrows) {
+  if (e->ing_which < 0) return fail("streaming upload is not open (call dav_dense_begin)");
+  if (row0 < 0 || nrows < 0 || row0 + nrows > e->n || nrows > e->ing_cap_rows) return fail("dav_dense_put_rows: rows out of range");
+  if (nrows == 0) return 0;
+  CHK(bind(e));
+  OpDesc& o = e->op[e->ing_which];
+  int b = e->ing_flip;
+  HIPCHK(hipMemcpyAsync(e->ing_dev[b], e->ing_host[b], sizeof(double) * (size_t)(nrows * e->n), hipMemcpyHostToDevice, e->stream));
+  launch_rows_scatter(e->stream, e->ing_dev[b], e->n, row0, nrows, e->n, o.a, e->nloc_pad, e->row0, e->nloc, o.storage == 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ing_done[b], e->stream));
+  e->ing_pending[b] = true;
+  e->ing_flip ^= 1;
+  return 0;
+}
+
+static void ingest_wanted(E* e, int64_t* first, int64_t* count) {
+  if (e->op[e->ing_which].storage == 1) { *first = 0; *count = e->n; }
+  else { *first = e->row0; *count = e->nloc; }
+}
+
+extern "C" int dav_dense_put_rows(dav_handle_t e, int which, int64_t row0, int64_t nrows, const double* rows, int64_t ldr) {
+  if (e->ing_which != which) return fail("dav_dense_put_rows: no streaming upload open for this operator");
+  if (!rows || ldr < e->n || row0 < 0 || nrows < 0 || row0 + nrows > e->n) return fail("dav_dense_put_rows: bad arguments");
+  int64_t w0, wn;
+  ingest_wanted(e, &w0, &wn);
+  int64_t lo = std::max(row0, w0), hi = std::min(row0 + nrows, w0 + wn);     // rows of other ranks are ignored
+  for (int64_t r = lo; r < hi;) {
+    double* buf; int64_t cap;
+    CHK(ingest_acquire(e, &buf, &cap));
+    int64_t take = std::min(cap, hi - r);
+    for (int64_t i = 0; i < take; ++i) memcpy(buf + i * e->n, rows + (r - row0 + i) * ldr, sizeof(double) * (size_t)e->n);
+    CHK(ingest_commit(e, r, take));
+    r += take;
+  }
+  return 0;
+}
+
+extern "C" int dav_dense_end(dav_handle_t e, int which) {
+  if (e->ing_which != which) return fail("dav_dense_end: no streaming upload open for this operator");
+  CHK(bind(e));
+  OpDesc& o = e->op[which];
+  if (o.storage == 1) launch_diag_sym(e->stream, o.a, e->n, o.diag);
+  else launch_diag_dense(e->stream, o.a, e->nloc_pad, e->row0, e->nloc, o.diag);
+  int rc = refresh_diag_host(e, which);
+  ingest_release(e);
+  return rc;
+}
+
+namespace {
+struct EngineSink : IngestSink {
+  E* e;
+  explicit EngineSink(E* e_) : e(e_) {}
+  int acquire(double** buf, int64_t* cap_rows) override { return ingest_acquire(e, buf, cap_rows); }
+  int commit(int64_t row0, int64_t nrows) override { return ingest_commit(e, row0, nrows); }
+  void wanted(int64_t* first, int64_t* count) override { ingest_wanted(e, first, count); }
+};
+}  // namespace
+
+extern "C" int dav_set_dense_file(dav_handle_t e, int which, const char* path, int format) {
+  if (!path) return fail("dav_set_dense_file: null path");
+  if (format != DAV_FILE_TEXT && format != DAV_FILE_F64) return fail("dav_set_dense_file: unknown format");
+  CHK(dav_dense_begin(e, which));
+  EngineSink sink(e);
+  std::string err;
+  int rc = format == DAV_FILE_TEXT ? ingest_text_file(path, e->n, sink, &err) : ingest_f64_file(path, e->n, sink, &err);
+  if (rc != 0) {
+    hipStreamSynchronize(e->stream);
+    ingest_release(e);
+    e->op[which].kind = DAV_KIND_NONE;
+    return err.empty() ? rc : fail("dav_set_dense_file: " + err);
+  }
+  return dav_dense_end(e, which);
+}
+
+extern "C" int dav_parse_text_f64(const char* text, size_t len, double* out, size_t max_vals, size_t* nvals) {
+  std::vector<double> v;
+  std::string err;
+  size_t used = ingest_parse_text_parallel(text, len, true, &v, 4, &err);
+  if (used == (size_t)-1) return fail("dav_parse_text_f64: " + err);
+  if (nvals) *nvals = v.size();
+  if (out) memcpy(out, v.data(), sizeof(double) * std::min(v.size(), max_vals));
+  return 0;
 }
 
 extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed, double sparsity, int use_diag_val,

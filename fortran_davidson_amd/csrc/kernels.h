@@ -67,6 +67,12 @@ void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double*
 
 
 
+// ---- ingest (k_ingest.hip): row-major staged rows -> resident slab / tiles ----------------------------
+// stage: nrows complete rows, row-major (ld = ldr), global rows grow0...; dst = full slab (lda, rows
+// [slab_row0, slab_row0 + slab_rows) kept) or, sym != 0, the lower block triangle of SYM_TB tiles.
+void launch_rows_scatter(hipStream_t st, const double* stage, int64_t ldr, int64_t grow0, int64_t nrows, int64_t n,
+                         double* dst, int64_t lda, int64_t slab_row0, int64_t slab_rows, int sym);
+
 // ---- K7 helpers (k_gjd.hip) ------------------------------------------------------------------------
 struct LincombArgs {      // out[:, j] = sum_t coef[t*ldc + j] * in[t][:, j]
   const double* in[4]; const double* coef; int ldc; int nterms;

@@ -111,6 +111,24 @@ class CEngine:
                                                    C.c_int(0 if diag_val is None else 1),
                                                    C.c_double(0.0 if diag_val is None else diag_val)))
 
+    # -- streaming ingest (rows in the reference's on-disk order, row-major)
+    def dense_begin(self, which):
+        self._chk(self.lib.dav_dense_begin(self.h, C.c_int(which)))
+
+    def dense_put_rows(self, which, row0, rows):
+        """rows: (nrows, n) C-ordered block of complete rows, global rows row0..row0+nrows-1."""
+        r = np.ascontiguousarray(rows, dtype=np.float64)
+        self._chk(self.lib.dav_dense_put_rows(self.h, C.c_int(which), C.c_int64(row0), C.c_int64(r.shape[0]), _dp(r),
+                                              C.c_int64(r.shape[1])))
+
+    def dense_end(self, which):
+        self._chk(self.lib.dav_dense_end(self.h, C.c_int(which)))
+
+    def set_dense_file(self, which, path, fmt="text"):
+        """fmt: "text" = the reference's write_matrix/read_matrix format, "f64" = raw row-major float64."""
+        code = {"text": 0, "f64": 1}[fmt]
+        self._chk(self.lib.dav_set_dense_file(self.h, C.c_int(which), str(path).encode(), C.c_int(code)))
+
     def set_operator_hashed(self, which, seed, sparsity, diag_val=None):
         self._chk(self.lib.dav_set_operator_hashed(self.h, C.c_int(which), C.c_uint64(seed), C.c_double(sparsity),
                                                    C.c_int(0 if diag_val is None else 1),
@@ -212,3 +230,15 @@ class CEngine:
         self._chk(self.lib.dav_bench_apply(self.h, C.c_int(which), C.c_int(k), C.c_int(reps), C.byref(ms),
                                            C.byref(nbytes)))
         return ms.value, nbytes.value
+
+
+def parse_text_f64(data: bytes) -> np.ndarray:
+    """The engine's parser of the reference's text dumps (host only): all numbers in `data`."""
+    lib = hip_lib()
+    n = C.c_size_t(0)
+    if lib.dav_parse_text_f64(data, C.c_size_t(len(data)), None, C.c_size_t(0), C.byref(n)) != 0:
+        raise DavidsonHipError(lib.dav_last_error().decode())
+    out = np.empty(n.value)
+    if lib.dav_parse_text_f64(data, C.c_size_t(len(data)), _dp(out), C.c_size_t(out.size), C.byref(n)) != 0:
+        raise DavidsonHipError(lib.dav_last_error().decode())
+    return out

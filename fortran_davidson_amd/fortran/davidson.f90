@@ -21,6 +21,7 @@ module davidson_device
   implicit none
   private
   public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, &
+       engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
        engine_set_identity, engine_comm_unique_id, engine_comm_init, &
        generalized_eigensolver_device, davidson_device_loop, basis_capacity
@@ -128,6 +129,60 @@ contains
     call check_dav(dav_set_dense_host(eng%h, int(which - 1, c_int), matrix, int(size(matrix, 1), c_int64_t)), &
          "dav_set_dense_host")
   end subroutine engine_set_dense
+
+  !> Operator A (which=1) or B (which=2) from a file, streamed to HBM by blocks of rows - no host N x N
+  !> array.  fmt = "text" (default): the format read_matrix reads and write_matrix writes in the reference's
+  !> test_utils (src/tests/test_utils.f90:118-135,150-166: list-directed reals, row-major); fmt = "f64": raw
+  !> float64, row-major, 8 n^2 bytes.
+  subroutine engine_read_matrix(eng, which, path_file, fmt)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    character(len=*), intent(in) :: path_file
+    character(len=*), intent(in), optional :: fmt
+    integer(c_int) :: code
+    code = 0
+    if (present(fmt)) then
+       select case (trim(fmt))
+       case ("text")
+          code = 0
+       case ("f64")
+          code = 1
+       case default
+          print *, "engine_read_matrix: fmt must be 'text' or 'f64'"
+          error stop
+       end select
+    end if
+    call check_dav(dav_set_dense_file(eng%h, int(which - 1, c_int), trim(path_file) // c_null_char, code), &
+         "dav_set_dense_file")
+  end subroutine engine_read_matrix
+
+  !> Streaming upload for hosts that produce the matrix row by row: begin, any number of put_rows (each a
+  !> block of complete rows; rows(j, r) = element (row0 + r - 1, j), i.e. one matrix row per COLUMN of the
+  !> Fortran array, which is the row-major order of the file format), end.
+  subroutine engine_dense_begin(eng, which)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    call check_dav(dav_dense_begin(eng%h, int(which - 1, c_int)), "dav_dense_begin")
+  end subroutine engine_dense_begin
+
+  subroutine engine_dense_put_rows(eng, which, row0, rows)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    integer, intent(in) :: row0                          !< 1-based global index of the first row
+    real(dp), dimension(:, :), contiguous, intent(in) :: rows   !< (n, nrows)
+    if (size(rows, 1) /= eng%n) then
+       print *, "engine_dense_put_rows: rows must be (", eng%n, ", nrows)"
+       error stop
+    end if
+    call check_dav(dav_dense_put_rows(eng%h, int(which - 1, c_int), int(row0 - 1, c_int64_t), &
+         int(size(rows, 2), c_int64_t), rows, int(size(rows, 1), c_int64_t)), "dav_dense_put_rows")
+  end subroutine engine_dense_put_rows
+
+  subroutine engine_dense_end(eng, which)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    call check_dav(dav_dense_end(eng%h, int(which - 1, c_int)), "dav_dense_end")
+  end subroutine engine_dense_end
 
   !> generate_diagonal_dominant(n, sparsity[, diag_val]) built directly in HBM (same entries as the
   !> host function of array_utils with the same seed).

@@ -70,6 +70,33 @@ module davidson_hip_c
        integer(c_int64_t), value :: lda
        integer(c_int) :: ierr
      end function
+     function dav_dense_begin(h, which) bind(C, name="dav_dense_begin") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: which
+       integer(c_int) :: ierr
+     end function
+     function dav_dense_put_rows(h, which, row0, nrows, rows, ldr) bind(C, name="dav_dense_put_rows") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: which
+       integer(c_int64_t), value :: row0, nrows, ldr
+       real(c_double), intent(in) :: rows(*)
+       integer(c_int) :: ierr
+     end function
+     function dav_dense_end(h, which) bind(C, name="dav_dense_end") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: which
+       integer(c_int) :: ierr
+     end function
+     function dav_set_dense_file(h, which, path, fmt) bind(C, name="dav_set_dense_file") result(ierr)
+       import :: c_ptr, c_int, c_char
+       type(c_ptr), value :: h
+       integer(c_int), value :: which, fmt
+       character(kind=c_char), intent(in) :: path(*)
+       integer(c_int) :: ierr
+     end function
      function dav_set_dense_generated(h, which, seed, sparsity, use_diag_val, diag_val) &
           bind(C, name="dav_set_dense_generated") result(ierr)
        import :: c_ptr, c_int, c_int64_t, c_double

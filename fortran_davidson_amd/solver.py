@@ -109,6 +109,11 @@ class DavidsonEngine:
         assert a.shape == (self.n, self.n)
         self.lib.fd_engine_set_dense(self.p, C.c_int(which), _dp(a))
 
+    def read_matrix(self, which, path, fmt="text"):
+        """Operator from a file, streamed to HBM (Fortran: engine_read_matrix): "text" = the reference's
+        write_matrix/read_matrix dump format, "f64" = raw row-major float64."""
+        self.c.set_dense_file(which - 1, path, fmt)
+
     def _set_op(self, which, kind, seed, sparsity, diag_val):
         self.lib.fd_engine_set_operator(self.p, C.c_int(which), C.c_int(kind), C.c_int(seed), C.c_double(sparsity),
                                         C.c_int(0 if diag_val is None else 1),

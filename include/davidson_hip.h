@@ -22,6 +22,7 @@
 #ifndef DAVIDSON_HIP_H
 #define DAVIDSON_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -92,6 +93,27 @@ int dav_set_dense_host(dav_handle_t h, int which, const double* a, int64_t lda);
 /* Same with a(lda, n) already in device memory (e.g. produced by an upstream GPU stage): copied once
  * into the engine's padded slab / tile layout, the caller's buffer is not referenced afterwards. */
 int dav_set_dense_dev(dav_handle_t h, int which, const double* a_dev, int64_t lda);
+/* Streaming upload by blocks of COMPLETE ROWS, row-major - the order of the reference's on-disk format
+ * (read_matrix / write_matrix, src/tests/test_utils.f90:118-135,150-166: list-directed text, one value
+ * per line, row i outer, column j inner) - so that a matrix larger than host memory, or one produced row
+ * by row, reaches HBM without a host N x N copy.  begin allocates and zeroes the resident storage (full
+ * row slab or symmetric tiles, as dav_set_storage says); put_rows takes rows [row0, row0 + nrows) with
+ * element (row0 + r, j) at rows[r * ldr + j], any order, global row numbers (rows of other ranks are
+ * ignored; with symmetric-tiled storage the upper block triangle is dropped); the caller's buffer may be
+ * reused as soon as the call returns; end extracts the diagonal (array_utils.f90:115-134) and makes the
+ * operator usable. */
+int dav_dense_begin(dav_handle_t h, int which);
+int dav_dense_put_rows(dav_handle_t h, int which, int64_t row0, int64_t nrows, const double* rows, int64_t ldr);
+int dav_dense_end(dav_handle_t h, int which);
+/* Whole matrix from a file through the streaming path above.  DAV_FILE_TEXT: the reference's text format
+ * (whitespace/comma separated reals, E/D exponents, n*n values, row-major; what test_utils.f90 read_matrix
+ * reads and write_matrix writes).  DAV_FILE_F64: raw little-endian float64, row-major, exactly 8 n^2
+ * bytes (each rank preads only its rows). */
+enum { DAV_FILE_TEXT = 0, DAV_FILE_F64 = 1 };
+int dav_set_dense_file(dav_handle_t h, int which, const char* path, int format);
+/* The text parser of DAV_FILE_TEXT on a memory buffer (host only, no GPU needed): *nvals = numbers found,
+ * the first min(*nvals, max_vals) are stored to out (out may be NULL to count). */
+int dav_parse_text_f64(const char* text, size_t len, double* out, size_t max_vals, size_t* nvals);
 /* Dense matrix generated directly in HBM with the semantics of generate_diagonal_dominant
  * (src/array_utils.f90:86-113) and the counter-based stream of oracle/davidson_oracle.py. */
 int dav_set_dense_generated(dav_handle_t h, int which, uint64_t seed, double sparsity,

@@ -39,12 +39,19 @@ def build_programs(tmp_path):
     return dense, free
 
 
+def build_ingest_program(tmp_path):
+    bindir = os.path.join(SRC, "_bin")
+    os.makedirs(bindir, exist_ok=True)
+    return compile_link([os.path.join(SRC, "prog_ingest.f90")], os.path.join(bindir, "prog_ingest"), tmp_path)
+
+
 @needs_flang
 def test_user_programs_compile_and_link(tmp_path):
     if not os.path.isdir(MODDIR):
         pytest.skip("module files not built")
     dense, free = build_programs(tmp_path)
     assert os.path.exists(dense) and os.path.exists(free)
+    assert os.path.exists(build_ingest_program(tmp_path))
 
 
 @needs_flang
@@ -94,3 +101,15 @@ def test_free_program_runs_on_gpu(golden, tmp_path):
     assert np.abs(ev - arrays["free_n50__evals"]).max() < 1e-8
     iters = [int(x) for x in re.search(r"ITERS\s+(\d+)\s+(\d+)", out).groups()]
     assert iters[0] == manifest["free"]["free_n50"]["iters"]
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_ingest_program_runs_on_gpu(tmp_path):
+    """Text dump in the reference's write_matrix format, raw float64 and row-block streaming, from Fortran."""
+    exe = build_ingest_program(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0, out
+    checks = re.findall(r"CHECK (\S+) ([TF])", out)
+    assert len(checks) == 4 * 6 and all(v == "T" for _, v in checks), out
