@@ -210,6 +210,23 @@ def main():
         ms, nbytes = eng.c.bench_apply(k, 20)
         apply_k[f"k{k}"] = {"ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
                             "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    # opt-in correction policy (not the reference's, so never part of `value`): same workload,
+    # corrections only for the wanted pairs that have not converged
+    eng.set_correction_policy("unconverged")
+    eng.solve("DPR", 1000, args.tol, want_vectors=False)
+    eng.c.synchronize(); barrier()
+    t2 = time.perf_counter()
+    it_pol = 0
+    for _ in range(args.steps):
+        lam_pol, _, it = eng.solve("DPR", 1000, args.tol, want_vectors=False)
+        it_pol += it
+    eng.c.synchronize(); barrier()
+    dt_pol = max_over_ranks(time.perf_counter() - t2)
+    opt_in = {"policy": "unconverged (engine_set_correction_policy / DAVIDSON_CORRECTION_POLICY)",
+              "ms_per_solve": round(dt_pol / args.steps * 1e3, 4), "iters_per_solve": it_pol // args.steps,
+              "solves_per_s": round(args.steps / dt_pol, 2),
+              "reference_policy_solves_per_s": round(args.steps / elapsed, 2),
+              "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_pol - lam).max())}
     eng.close()
 
     # ---- configs[2]: N=200000 dense fp64, lowest=16, DPR, subspace restart at 80 ------------------------
@@ -242,6 +259,15 @@ def main():
                                   "algorithmic_bytes": b8,
                                   "note": "bytes = 8*S + 16*N*k, S = N(N+1)/2 (symmetric-tiled) or nloc*N (full slab)"},
                      "eigenvalues": [float(x) for x in lam_big[:3]]}
+            big.set_correction_policy("unconverged")
+            big.solve("DPR", 1000, args.tol, want_vectors=False)
+            big.c.synchronize(); barrier()
+            t3 = time.perf_counter()
+            lam_p, _, it_p = big.solve("DPR", 1000, args.tol, want_vectors=False)
+            big.c.synchronize(); barrier()
+            dt_p = max_over_ranks(time.perf_counter() - t3)
+            large["opt_in_policy_unconverged"] = {"ms_per_solve": round(dt_p * 1e3, 2), "iters_per_solve": int(it_p),
+                                                  "max_abs_eigenvalue_diff": float(np.abs(lam_p - lam_big).max())}
             big.close()
         except Exception as exc:       # noqa: BLE001
             large = {"error": repr(exc)[:300]}
@@ -270,7 +296,7 @@ def main():
                            "N": n, "lowest": lowest, "iters_per_solve": total_iters // args.steps,
                            "basis_widths": "2L,4L,8L", "parallelism": f"row-slab x{world}"},
                 "eigenvalues": [float(x) for x in lam[:3]],
-                "roofline": roofline, "phase_ms_per_step": phase, "apply": apply_k, "large": large, "cpu_baseline": cpu}
+                "roofline": roofline, "phase_ms_per_step": phase, "apply": apply_k, "opt_in_policy": opt_in, "large": large, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

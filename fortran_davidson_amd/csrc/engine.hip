@@ -974,16 +974,16 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
 }
 
 // ---- K3 -----------------------------------------------------------------------------------------
-extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, const double* Y, int64_t ldy,
-                                            const double* theta, int method, double* resnorm) {
+extern "C" int dav_ritz_residual_correction_n(dav_handle_t e, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
+                                              const double* theta, int method, double* resnorm) {
   CHK(bind(e));
-  if (m <= 0 || lowest <= 0 || lowest > m || ldy < m) return fail("dav_ritz_residual_correction: bad shape");
-  if (method == DAV_METHOD_DPR && 2 * m > e->cols_alloc) return fail("basis panel too narrow for the correction block");
+  if (m <= 0 || lowest <= 0 || lowest > ncorr || ncorr > m || ldy < m) return fail("dav_ritz_residual_correction: bad shape");
+  if (method == DAV_METHOD_DPR && m + ncorr > e->cols_alloc) return fail("basis panel too narrow for the correction block");
   CHK(check_panel(e, DAV_PANEL_V, 0, m));
-  std::vector<double> y2((size_t)m * m);
-  for (int j = 0; j < m; ++j)
+  std::vector<double> y2((size_t)m * ncorr);
+  for (int j = 0; j < ncorr; ++j)
     for (int i = 0; i < m; ++i) y2[(size_t)j * m + i] = -Y[j * ldy + i] * theta[j];
-  SmallMat sm3[3] = {{Y, ldy, m, m, nullptr, 0}, {y2.data(), m, m, m, nullptr, 0}, {theta, m, m, 1, nullptr, 0}};
+  SmallMat sm3[3] = {{Y, ldy, m, ncorr, nullptr, 0}, {y2.data(), m, m, ncorr, nullptr, 0}, {theta, ncorr, ncorr, 1, nullptr, 0}};
   CHK(small_upload_multi(e, 0, sm3, 3));
   const double* dY = sm3[0].dev; const double* dY2 = sm3[1].dev; const double* dTheta = sm3[2].dev;
   const int64_t ldm_y = sm3[0].ldm, ldm_y2 = sm3[1].ldm;
@@ -991,7 +991,7 @@ extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, c
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
   // X = V * Y(:, 1:nx)
-  int nx = method == DAV_METHOD_DPR ? lowest : (method == DAV_METHOD_GJD ? m : lowest);
+  int nx = method == DAV_METHOD_GJD ? ncorr : lowest;
   PanelGemmArgs a{};
   a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = dY; a.ldm1 = ldm_y;
   a.p2 = 0;
@@ -1002,7 +1002,7 @@ extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, c
   PanelGemmArgs r{};
   r.P1 = panel_ptr(e, DAV_PANEL_W, 0); r.ld1 = e->ldp; r.p1 = m; r.M1 = dY; r.ldm1 = ldm_y;
   r.P2 = panel_ptr(e, e->gev ? DAV_PANEL_BV : DAV_PANEL_V, 0); r.ld2 = e->ldp; r.p2 = m; r.M2 = dY2; r.ldm2 = ldm_y2;
-  r.q = m; r.nloc = e->nloc; r.nrows_pad = e->nloc_pad;
+  r.q = ncorr; r.nloc = e->nloc; r.nrows_pad = e->nloc_pad;
   r.theta = dTheta; r.dA = e->op[DAV_OP_A].diag; r.dB = e->gev ? e->op[DAV_OP_B].diag : nullptr;
   r.nnorm = lowest; r.norm_partial = e->norm_partial;
   if (method == DAV_METHOD_DPR) {
@@ -1016,6 +1016,24 @@ extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, c
   if (e->nranks > 1) CHK(need_comm(e));
   CHK(result_fetch(e, (size_t)lowest));
   for (int j = 0; j < lowest; ++j) resnorm[j] = std::sqrt(e->gram_host[j]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, const double* Y, int64_t ldy,
+                                            const double* theta, int method, double* resnorm) {
+  return dav_ritz_residual_correction_n(e, m, m, lowest, Y, ldy, theta, method, resnorm);
+}
+
+extern "C" int dav_panel_select(dav_handle_t e, int panel, int c0, int nsel, const int* sel) {
+  CHK(bind(e));
+  if (nsel < 0 || (nsel > 0 && !sel)) return fail("dav_panel_select: bad arguments");
+  for (int i = 0; i < nsel; ++i) {
+    if (sel[i] < i || (i > 0 && sel[i] <= sel[i - 1])) return fail("dav_panel_select: indices must be ascending");
+    CHK(check_panel(e, panel, c0 + sel[i], 1));
+    if (sel[i] != i)      // columns only move to the left, in ascending order: no overlap
+      launch_copy_columns(e->stream, panel_ptr(e, panel, c0 + sel[i]), e->ldp, panel_ptr(e, panel, c0 + i), e->ldp, e->nloc_pad, 1);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1239,8 +1257,13 @@ static int gjd_dots(Gjd& g, int npairs, const double* const* a, const double* co
 
 extern "C" int dav_gjd_correction(dav_handle_t e, int m, const double* theta, int max_inner, double inner_tol,
                                   int* inner_iters_out) {
+  return dav_gjd_correction_n(e, m, m, theta, max_inner, inner_tol, inner_iters_out);
+}
+
+extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const double* theta, int max_inner, double inner_tol,
+                                    int* inner_iters_out) {
   CHK(bind(e));
-  if (m <= 0 || 2 * m > e->cols_alloc) return fail("dav_gjd_correction: bad block width");
+  if (m <= 0 || mbasis < m || mbasis + m > e->cols_alloc || m > e->cols_alloc / 2) return fail("dav_gjd_correction: bad block width");
   if (e->op[DAV_OP_A].kind == DAV_KIND_HOST || e->op[DAV_OP_A].kind == DAV_KIND_NONE)
     return fail("dav_gjd_correction: needs a device operator A");
   const bool gev = e->gev != 0;
@@ -1253,7 +1276,7 @@ extern "C" int dav_gjd_correction(dav_handle_t e, int m, const double* theta, in
   }
   auto ws = [&](int i) { return e->gjd_ws + (size_t)i * e->ldp * wcols; };
   double* X = panel_ptr(e, DAV_PANEL_X, 0);
-  double* T = panel_ptr(e, DAV_PANEL_V, m);
+  double* T = panel_ptr(e, DAV_PANEL_V, mbasis);
   double* r1 = panel_ptr(e, DAV_PANEL_R, 0);          // becomes b = -r in place
   double *r2 = ws(0), *y = ws(1), *v = ws(2), *w = ws(3), *w1 = ws(4), *w2 = ws(5), *ua = ws(6), *ub = ws(7), *mx = ws(8);
 

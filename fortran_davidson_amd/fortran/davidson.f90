@@ -22,6 +22,7 @@ module davidson_device
   private
   public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, &
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
+       engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
        engine_set_identity, engine_comm_unique_id, engine_comm_init, &
        generalized_eigensolver_device, davidson_device_loop, basis_capacity
@@ -32,6 +33,7 @@ module davidson_device
      integer :: n = 0
      integer :: max_cols = 0
      logical :: gev = .false.
+     integer :: policy = 0          !< POLICY_ALL (the reference) or POLICY_UNCONVERGED (opt-in)
   end type davidson_engine
 
   !> Wall time of the last solve by phase (seconds): 1 setup (init basis + first projection),
@@ -39,6 +41,9 @@ module davidson_device
   !> 5 operator apply (expand), 6 projection, 7 restart, 8 GJD inner solves.  Printed when the
   !> environment variable DAVIDSON_VERBOSE is set; never printed otherwise (drop-in silence).
   real(dp), save, public :: last_phase_seconds(8) = 0.0_dp
+
+  !> Correction policies of the outer loop (see davidson_device_loop)
+  integer, parameter, public :: POLICY_ALL = 0, POLICY_UNCONVERGED = 1
 
   abstract interface
      function block_operator(input_vect) result(output_vect)
@@ -66,7 +71,8 @@ contains
     integer, intent(in) :: n, lowest
     integer, intent(in), optional :: max_dim_sub, device, rank, nranks
     logical, intent(in), optional :: gev
-    integer :: max_dim, dev, rk, nr
+    integer :: max_dim, dev, rk, nr, envlen, envstat
+    character(len=32) :: envbuf
     max_dim = 10 * lowest
     if (present(max_dim_sub)) max_dim = max_dim_sub
     dev = 0; rk = 0; nr = 1
@@ -79,7 +85,33 @@ contains
     eng%max_cols = basis_capacity(lowest, max_dim)
     call check_dav(dav_create(eng%h, int(dev, c_int), int(n, c_int64_t), int(eng%max_cols, c_int), &
          merge(1_c_int, 0_c_int, eng%gev), int(rk, c_int), int(nr, c_int)), "dav_create")
+    ! engine knob that does not touch the reference's argument lists (reaches the dense and matrix-free
+    ! front ends too): DAVIDSON_CORRECTION_POLICY=unconverged
+    call get_environment_variable("DAVIDSON_CORRECTION_POLICY", envbuf, envlen, envstat)
+    eng%policy = POLICY_ALL
+    if (envstat == 0 .and. envlen > 0) call engine_set_correction_policy(eng, envbuf(1:envlen))
   end subroutine engine_create
+
+  !> Which Ritz pairs get a correction vector each iteration.  "all" (default) is the reference's policy:
+  !> one correction per basis vector, the basis doubles (src/davidson.f90:195-213), sticky convergence on the
+  !> dense path.  "unconverged" (opt-in; not in the reference, changes the iteration count): only those of
+  !> the `lowest` wanted pairs whose residual is still above the tolerance are corrected, convergence is
+  !> tested on all wanted pairs at once, and the basis grows by at most `lowest` columns per iteration -
+  !> narrower panels, one 16-column pass of the symmetric sweep per iteration, and GJD inner solves only for
+  !> the pairs that need them.
+  subroutine engine_set_correction_policy(eng, policy)
+    type(davidson_engine), intent(inout) :: eng
+    character(len=*), intent(in) :: policy
+    select case (trim(policy))
+    case ("all")
+       eng%policy = POLICY_ALL
+    case ("unconverged")
+       eng%policy = POLICY_UNCONVERGED
+    case default
+       print *, "engine_set_correction_policy: policy must be 'all' or 'unconverged', got '", trim(policy), "'"
+       error stop
+    end select
+  end subroutine engine_set_correction_policy
 
   subroutine engine_destroy(eng)
     type(davidson_engine), intent(inout) :: eng
@@ -262,7 +294,7 @@ contains
        error stop
     end if
     call davidson_device_loop(eng%h, eng%n, lowest, method, max_iterations, tolerance, iters, max_dim, &
-         eng%gev, .true., eigenvalues)
+         eng%gev, .true., eigenvalues, policy=eng%policy)
     if (present(eigenvectors)) then
        call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), eigenvectors, &
             int(size(eigenvectors, 1), c_int64_t)), "dav_panel_get")
@@ -274,7 +306,7 @@ contains
   !> matrix-free path's all-at-once test (:416).  fun_a/fun_b present = operators applied by the
   !> host through callbacks (API-faithful matrix-free path).
   subroutine davidson_device_loop(h, n, lowest, method, max_iterations, tolerance, iters, max_dim, gev, &
-       sticky, eigenvalues, fun_a, fun_b)
+       sticky, eigenvalues, fun_a, fun_b, policy)
     type(c_ptr), intent(in) :: h
     integer, intent(in) :: n, lowest, max_iterations, max_dim
     character(len=*), intent(in) :: method
@@ -283,8 +315,15 @@ contains
     logical, intent(in) :: gev, sticky
     real(dp), dimension(lowest), intent(out) :: eigenvalues
     procedure(block_operator), optional :: fun_a, fun_b
+    !> POLICY_ALL (default) = the reference: one correction per basis vector, the basis doubles.
+    !> POLICY_UNCONVERGED (opt-in, changes iters): corrections only for those of the `lowest` wanted pairs
+    !> whose residual is still above the tolerance; all-at-once convergence test.
+    integer, intent(in), optional :: policy
 
-    integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase
+    integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr
+    integer(c_int), allocatable :: sel(:)
+    real(dp), allocatable :: theta_sel(:)
+    logical :: expand_now
     integer(c_int64_t) :: ld
     integer(c_int64_t), allocatable :: idx(:)
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
@@ -305,6 +344,8 @@ contains
     end select
     host_ops = present(fun_a)
     if (host_ops .and. meth == DAV_METHOD_GJD) meth = DAV_METHOD_DPR    ! free path is DPR only (:428)
+    pol = POLICY_ALL
+    if (present(policy)) pol = policy
 
     initial_dimension = 2 * lowest
     cap = basis_capacity(lowest, max_dim)
@@ -338,12 +379,20 @@ contains
 
        ! 4. Ritz vectors, residues, their norms and the DPR correction - one fused device phase
        phase = meth
-       if (m > max_dim) phase = DAV_METHOD_NONE      ! this iteration ends in a restart: no correction block
-       call check_dav(dav_ritz_residual_correction(h, int(m, c_int), int(lowest, c_int), y, int(m, c_int64_t), &
-            theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
+       if (pol == POLICY_ALL) then
+          ncorr = m
+          expand_now = m <= max_dim
+       else
+          ncorr = lowest
+          ! grow while the widest possible block still fits; a basis that has just been (re)started always grows
+          expand_now = (m + lowest <= max_dim) .or. (m <= initial_dimension)
+       end if
+       if (.not. expand_now) phase = DAV_METHOD_NONE      ! this iteration ends in a restart: no correction block
+       call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), y, &
+            int(m, c_int64_t), theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
        call lap(3)
        eigenvalues = theta(1:lowest)
-       if (sticky) then
+       if (sticky .and. pol == POLICY_ALL) then
           do j = 1, lowest
              if (errors(j) < tolerance) has_converged(j) = .true.
           end do
@@ -356,13 +405,37 @@ contains
           exit outer_loop
        end if
 
-       if (m <= max_dim) then
-          ! 5. correction block T (m columns) -> orthonormalise against V and itself -> new basis columns
-          kt = m
-          if (meth == DAV_METHOD_GJD) then
-             call check_dav(dav_gjd_correction(h, int(m, c_int), theta, 300_c_int, 1.0e-10_dp, inner), &
-                  "dav_gjd_correction")
-             call lap(8)
+       if (expand_now) then
+          ! 5. correction block T -> orthonormalise against V and itself -> new basis columns
+          if (pol == POLICY_ALL) then
+             kt = m                                      ! one correction per basis vector (the reference)
+             if (meth == DAV_METHOD_GJD) then
+                call check_dav(dav_gjd_correction(h, int(m, c_int), theta, 300_c_int, 1.0e-10_dp, inner), &
+                     "dav_gjd_correction")
+                call lap(8)
+             end if
+          else
+             ! only the wanted pairs that have not converged: keep their columns, drop the others
+             kt = count(errors >= tolerance)
+             if (allocated(sel)) deallocate(sel, theta_sel)
+             allocate(sel(kt), theta_sel(kt))
+             kt = 0
+             do j = 1, lowest
+                if (errors(j) >= tolerance) then
+                   kt = kt + 1
+                   sel(kt) = int(j - 1, c_int)
+                   theta_sel(kt) = theta(j)
+                end if
+             end do
+             if (meth == DAV_METHOD_GJD) then
+                call check_dav(dav_panel_select(h, DAV_PANEL_X, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
+                call check_dav(dav_panel_select(h, DAV_PANEL_R, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
+                call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), theta_sel, 300_c_int, &
+                     1.0e-10_dp, inner), "dav_gjd_correction")
+                call lap(8)
+             else
+                call check_dav(dav_panel_select(h, DAV_PANEL_V, int(m, c_int), int(kt, c_int), sel), "dav_panel_select")
+             end if
           end if
           call block_orthonormalise(h, n, m, kt)
           call lap(4)
@@ -692,7 +765,7 @@ contains
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_A, diag_a), "dav_set_operator_host")
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_B, diag_b), "dav_set_operator_host")
     call davidson_device_loop(eng%h, n, lowest, method, max_iterations, tolerance, iters, max_dim, .true., &
-         .false., eigenvalues, fun_matrix_gemv, fun_second_matrix_gemv)
+         .false., eigenvalues, fun_matrix_gemv, fun_second_matrix_gemv, eng%policy)
     call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), ritz_vectors, &
          int(size(ritz_vectors, 1), c_int64_t)), "dav_panel_get")
     call engine_destroy(eng)

@@ -143,6 +143,18 @@ contains
     end if
   end subroutine fd_engine_set_storage
 
+  subroutine fd_engine_set_policy(p, code) bind(C, name="fd_engine_set_policy")
+    type(c_ptr), value :: p
+    integer(c_int), value :: code
+    type(davidson_engine), pointer :: eng
+    call c_f_pointer(p, eng)
+    if (code == 1) then
+       call engine_set_correction_policy(eng, "unconverged")
+    else
+       call engine_set_correction_policy(eng, "all")
+    end if
+  end subroutine fd_engine_set_policy
+
   subroutine fd_engine_set_dense(p, which, a) bind(C, name="fd_engine_set_dense")
     type(c_ptr), value :: p
     integer(c_int), value :: which

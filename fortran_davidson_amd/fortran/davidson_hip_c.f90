@@ -171,6 +171,33 @@ module davidson_hip_c
        integer(c_int64_t), value :: ldh, lds
        integer(c_int) :: ierr
      end function
+     function dav_ritz_residual_correction_n(h, m, ncorr, lowest, y, ldy, theta, method, resnorm) &
+          bind(C, name="dav_ritz_residual_correction_n") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, ncorr, lowest, method
+       real(c_double), intent(in) :: y(*), theta(*)
+       integer(c_int64_t), value :: ldy
+       real(c_double), intent(out) :: resnorm(*)
+       integer(c_int) :: ierr
+     end function
+     function dav_panel_select(h, panel, c0, nsel, sel) bind(C, name="dav_panel_select") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: panel, c0, nsel
+       integer(c_int), intent(in) :: sel(*)
+       integer(c_int) :: ierr
+     end function
+     function dav_gjd_correction_n(h, m, ncols, theta, max_inner, inner_tol, inner_iters) &
+          bind(C, name="dav_gjd_correction_n") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, ncols, max_inner
+       real(c_double), intent(in) :: theta(*)
+       real(c_double), value :: inner_tol
+       integer(c_int), intent(out) :: inner_iters
+       integer(c_int) :: ierr
+     end function
      function dav_ritz_residual_correction(h, m, lowest, y, ldy, theta, method, resnorm) &
           bind(C, name="dav_ritz_residual_correction") result(ierr)
        import :: c_ptr, c_int, c_int64_t, c_double

@@ -109,6 +109,11 @@ class DavidsonEngine:
         assert a.shape == (self.n, self.n)
         self.lib.fd_engine_set_dense(self.p, C.c_int(which), _dp(a))
 
+    def set_correction_policy(self, policy):
+        """"all" = the reference's policy (default); "unconverged" = opt-in: correct only the wanted pairs
+        that have not converged (Fortran: engine_set_correction_policy)."""
+        self.lib.fd_engine_set_policy(self.p, C.c_int({"all": 0, "unconverged": 1}[policy]))
+
     def read_matrix(self, which, path, fmt="text"):
         """Operator from a file, streamed to HBM (Fortran: engine_read_matrix): "text" = the reference's
         write_matrix/read_matrix dump format, "f64" = raw row-major float64."""

@@ -157,11 +157,23 @@ int dav_project(dav_handle_t h, int c0, int k, double* H, int64_t ldh, double* S
  * left in their panels for dav_gjd_correction. */
 int dav_ritz_residual_correction(dav_handle_t h, int m, int lowest, const double* Y, int64_t ldy,
                                  const double* theta, int method, double* resnorm);
+/* Opt-in variant (not in the reference): the same phase for the first ncorr Ritz pairs only
+ * (Y is m x ncorr, theta has ncorr entries, lowest <= ncorr <= m): X = V*Y, R, norms of the first `lowest`
+ * columns, DPR block T (ncorr columns) into V[:, m:m+ncorr].  dav_ritz_residual_correction is the case
+ * ncorr = m.  dav_panel_select then keeps the chosen columns of a block (e.g. the corrections of the pairs
+ * that have not converged): panel[:, c0+i] = panel[:, c0+sel[i]], sel ascending. */
+int dav_ritz_residual_correction_n(dav_handle_t h, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
+                                   const double* theta, int method, double* resnorm);
+int dav_panel_select(dav_handle_t h, int panel, int c0, int nsel, const int* sel);
 /* K7 - replaces compute_GJD_generalized_dense (src/davidson.f90:700-734): solves
  * (I - x x^T)(A - theta_k B)(I - x x^T) t_k = -r_k for all m Ritz pairs at once with a block
  * preconditioned MINRES whose operator is the K1 block matvec; T goes to V[:, m:2m]. */
 int dav_gjd_correction(dav_handle_t h, int m, const double* theta, int max_inner, double inner_tol,
                        int* inner_iters_out);
+/* Same for ncols <= m pairs whose X and R sit in the first ncols columns of their panels; T goes to
+ * V[:, m:m+ncols] (opt-in correction policy, see dav_ritz_residual_correction_n). */
+int dav_gjd_correction_n(dav_handle_t h, int m, int ncols, const double* theta, int max_inner, double inner_tol,
+                         int* inner_iters_out);
 /* K4 - replaces concatenate + lapack_qr (src/davidson.f90:210-213): block Gram-Schmidt of the
  * k = kt correction columns T = V[:, m:m+kt] against V[:, 0:m] and among themselves.
  * dav_ortho_gram returns C = V^T T (m x kt) and G = T^T T (kt x kt); the host factors

@@ -252,6 +252,61 @@ def generalized_eigensolver_dense(matrix, lowest, method, max_iterations, tolera
     return eigenvalues, eigenvectors, iters
 
 
+def generalized_eigensolver_dense_unconverged(matrix, lowest, method, max_iterations, tolerance,
+                                              max_dim_sub=None, second_matrix=None, trace=None):
+    """NOT in the reference: CPU statement of the engine's OPT-IN correction policy "unconverged"
+    (fortran_davidson_amd/fortran/davidson.f90, POLICY_UNCONVERGED), kept here as its checker.
+    Same building blocks as generalized_eigensolver_dense above (davidson.f90:51-246) with three changes:
+    residues and corrections only for the `lowest` wanted pairs, and among them only for those whose residual
+    is still >= tolerance; convergence tested on all wanted pairs at once; the basis grows while
+    m + lowest <= max_dim (a basis of 2*lowest columns always grows), else collapses to 2*lowest (:218)."""
+    A = np.asarray(matrix, dtype=np.float64)
+    B = None if second_matrix is None else np.asarray(second_matrix, dtype=np.float64)
+    n = A.shape[0]
+    initial_dimension = 2 * lowest
+    max_dim = max_dim_sub if max_dim_sub is not None else 10 * lowest
+    gev = B is not None
+    if method not in ("DPR", "GJD"):
+        raise ValueError("method must be DPR or GJD")
+    V = generate_preconditioner(diagonal(A), initial_dimension)
+    H = V.T @ (A @ V)
+    S = V.T @ (B @ V) if gev else None
+    eigenvalues = np.zeros(lowest)
+    eigenvectors = np.zeros((n, lowest), order="F")
+    iters = max_iterations + 1
+    for i in range(1, max_iterations + 1):
+        theta, Y = lapack_generalized_eigensolver(H, S)
+        m = V.shape[1]
+        X = np.asfortranarray(V @ Y[:, :lowest])
+        BX = B @ X if gev else X
+        R = np.asfortranarray(A @ X - BX * theta[None, :lowest])
+        errors = np.array([norm(R[:, j]) for j in range(lowest)])
+        eigenvalues = theta[:lowest].copy()
+        eigenvectors = X
+        if trace is not None:
+            trace.widths.append(m)
+            trace.errors.append(errors)
+        if (errors < tolerance).all():
+            iters = i
+            if trace is not None:
+                trace.converged = True
+            break
+        if m + lowest <= max_dim or m <= initial_dimension:
+            sel = np.nonzero(errors >= tolerance)[0]
+            if method == "DPR":
+                T = compute_DPR_generalized_dense(A, theta[sel], np.asfortranarray(R[:, sel]), B)
+            else:
+                T = compute_GJD_generalized_dense(A, theta[sel], np.asfortranarray(X[:, sel]),
+                                                  np.asfortranarray(R[:, sel]), B)
+            V = lapack_qr(concatenate(V, T))
+        else:
+            V = V @ Y[:, :initial_dimension]
+        H = V.T @ (A @ V)
+        if gev:
+            S = V.T @ (B @ V)
+    return eigenvalues, eigenvectors, iters
+
+
 # --------------------------------------------------------------------------------------------
 # matrix-free solver, davidson.f90:277-460
 # --------------------------------------------------------------------------------------------

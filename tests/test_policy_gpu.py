@@ -1,0 +1,148 @@
+"""Opt-in correction policy "unconverged" (not in the reference, so it is never the default):
+corrections only for the wanted Ritz pairs that have not converged.  Same eigenpairs as the reference path
+(golden eigenvalues, residuals below the tolerance); iteration counts equal to the CPU statement of the
+policy in oracle/davidson_oracle.py."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import fortran_davidson_amd as fd
+from fortran_davidson_amd.solver import generalized_eigensolver_free
+from oracle import davidson_oracle as O
+from conftest import case_matrices
+
+pytestmark = pytest.mark.gpu
+EV_TOL = 1e-8
+
+CASES = ["matrix_txt_dpr", "matrix_txt_gjd", "c1_n50_std_dpr", "c1_n50_std_gjd", "c1_n50_gev_dpr", "c1_n50_gev_gjd",
+         "n400_std_dpr", "n400_std_gjd", "n400_gev_gjd", "n1000_restart_dpr", "n1000_gev_restart_dpr", "n2000_std_dpr",
+         "n3000_hard_dpr", "n4000_gev_dpr"]
+
+
+def residuals(A, B, lam, X):
+    BX = X if B is None else B @ X
+    return np.linalg.norm(A @ X - BX * lam[None, :], axis=0)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_unconverged_policy_same_eigenpairs_and_oracle_iteration_count(golden, name):
+    manifest, arrays = golden
+    case = manifest["dense"][name]
+    A, B = case_matrices(case, arrays)
+    L, tol = case["lowest"], case["tol"]
+    with fd.DavidsonEngine(case["n"], L, case["max_dim"], gev=B is not None) as eng:
+        eng.set_correction_policy("unconverged")
+        eng.set_dense(1, A)
+        if B is not None:
+            eng.set_dense(2, B)
+        lam, vec, iters = eng.solve(case["method"], case["max_it"], tol)
+        eng.set_correction_policy("all")                       # and back: the reference's path, golden iterations
+        lam_all, _, iters_all = eng.solve(case["method"], case["max_it"], tol)
+    assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
+    assert (residuals(A, B, lam, vec) < tol).all()
+    tr = O.Trace()
+    lam_o, _, it_o = O.generalized_eigensolver_dense_unconverged(A, L, case["method"], case["max_it"], tol,
+                                                                 case["max_dim"], B, trace=tr)
+    assert iters == it_o, (iters, it_o, tr.widths)
+    assert np.abs(lam - lam_o).max() < EV_TOL
+    assert iters_all == case["iters"] and np.abs(lam_all - arrays[f"{name}__evals"]).max() < EV_TOL
+
+
+def test_policy_through_the_environment_reaches_the_dense_and_free_front_ends(monkeypatch):
+    n, L = 600, 4
+    A = O.generate_diagonal_dominant(n, 2e-2, seed=8)
+    B = O.generate_diagonal_dominant(n, 2e-2, 1.0, seed=9)
+    lam_all, _, it_all = fd.generalized_eigensolver(A, L, "DPR", 200, 1e-8, 24)
+    monkeypatch.setenv("DAVIDSON_CORRECTION_POLICY", "unconverged")
+    lam, vec, it = fd.generalized_eigensolver(A, L, "DPR", 200, 1e-8, 24)
+    lam_o, _, it_o = O.generalized_eigensolver_dense_unconverged(A, L, "DPR", 200, 1e-8, 24)
+    assert it == it_o and np.abs(lam - lam_o).max() < EV_TOL and np.abs(lam - lam_all).max() < EV_TOL
+    assert (residuals(A, None, lam, vec) < 1e-8).all()
+    lam_f, vec_f, it_f = generalized_eigensolver_free(lambda x: A @ x, n, L, "DPR", 200, 1e-8, 24, lambda x: B @ x)
+    import scipy.linalg
+    ref = scipy.linalg.eigh(A, B, eigvals_only=True, subset_by_index=[0, L - 1])
+    assert np.abs(lam_f - ref).max() < EV_TOL
+    assert (residuals(A, B, lam_f, vec_f) < 1e-8).all()
+
+
+def test_policy_with_symmetric_storage_and_restart():
+    n, L = 3000, 8
+    tr = O.Trace()
+    A = O.generate_diagonal_dominant(n, 2e-2, seed=1)
+    lam_o, _, it_o = O.generalized_eigensolver_dense_unconverged(A, L, "DPR", 200, 1e-8, 32, trace=tr)
+    assert min(tr.widths[1:]) == 2 * L                         # the case does restart
+    with fd.DavidsonEngine(n, L, 32, storage="symmetric") as eng:
+        eng.set_correction_policy("unconverged")
+        eng.generate_diagonal_dominant(1, 2e-2, seed=1)
+        lam, vec, it = eng.solve("DPR", 200, 1e-8)
+    assert it == it_o and np.abs(lam - lam_o).max() < EV_TOL
+    assert (residuals(A, None, lam, vec) < 1e-8).all()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_policy_on_row_slab_ranks(golden, nranks):
+    manifest, arrays = golden
+    for name in ("n1000_gev_restart_dpr", "n400_gev_gjd"):
+        case = manifest["dense"][name]
+        A, B = case_matrices(case, arrays)
+        _, _, it_o = O.generalized_eigensolver_dense_unconverged(A, case["lowest"], case["method"], case["max_it"],
+                                                                 case["tol"], case["max_dim"], B)
+        engs = [fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=True, rank=r, nranks=nranks)
+                for r in range(nranks)]
+        handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+        assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+        out = [None] * nranks
+
+        def work(r):
+            engs[r].set_correction_policy("unconverged")
+            engs[r].generate_diagonal_dominant(1, case["sparsity"], seed=case["seed_a"])
+            engs[r].generate_diagonal_dominant(2, case["sparsity"], 1.0, seed=case["seed_b"])
+            out[r] = engs[r].solve(case["method"], case["max_it"], case["tol"])
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        [t.start() for t in threads]
+        [t.join(timeout=300) for t in threads]
+        assert all(o is not None for o in out), "a rank did not finish"
+        for lam, vec, iters in out:
+            assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
+            assert iters == it_o
+            assert (residuals(A, B, lam, vec) < case["tol"]).all()
+        for e in engs:
+            e.close()
+
+
+def test_panel_select_and_partial_ritz_phase_against_numpy():
+    """The two C-ABI pieces the policy adds, on their own."""
+    from fortran_davidson_amd.engine_c import OP_A, PANEL_V, PANEL_W, PANEL_X
+    n, m, L = 700, 12, 5
+    rng = np.random.default_rng(2)
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=4)
+    V, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    with fd.CEngine(n=n, max_cols=64) as e:
+        e.set_dense_host(OP_A, A)
+        e.panel_put(PANEL_V, 0, V)
+        e.apply(OP_A, PANEL_V, 0, m, PANEL_W, 0)
+        e.set_width(m)
+        H = V.T @ A @ V
+        theta, Y = np.linalg.eigh(H)
+        lib = fd.hip_lib()
+        res = np.zeros(L)
+        Yl = np.asfortranarray(Y[:, :L])
+        rc = lib.dav_ritz_residual_correction_n(e.h, C.c_int(m), C.c_int(L), C.c_int(L), Yl.ctypes.data_as(C.POINTER(C.c_double)),
+                                                C.c_int64(m), theta[:L].ctypes.data_as(C.POINTER(C.c_double)), C.c_int(0),
+                                                res.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0, lib.dav_last_error()
+        X = V @ Y[:, :L]
+        R = A @ X - X * theta[None, :L]
+        assert np.allclose(res, np.linalg.norm(R, axis=0), rtol=1e-10)
+        assert np.allclose(e.panel_get(PANEL_X, 0, L), X, atol=1e-12)
+        T = R / (theta[None, :L] - np.diag(A)[:, None])
+        assert np.allclose(e.panel_get(PANEL_V, m, L), T, rtol=1e-9, atol=1e-12)
+        sel = np.array([1, 3, 4], dtype=np.int32)
+        assert lib.dav_panel_select(e.h, C.c_int(PANEL_V), C.c_int(m), C.c_int(3), sel.ctypes.data_as(C.POINTER(C.c_int))) == 0
+        assert np.allclose(e.panel_get(PANEL_V, m, 3), T[:, sel], rtol=1e-9, atol=1e-12)
+        bad = np.array([2, 1], dtype=np.int32)
+        assert lib.dav_panel_select(e.h, C.c_int(PANEL_V), C.c_int(m), C.c_int(2), bad.ctypes.data_as(C.POINTER(C.c_int))) != 0
+        assert b"ascending" in lib.dav_last_error()
