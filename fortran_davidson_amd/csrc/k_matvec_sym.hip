@@ -3,6 +3,9 @@
 // entries, which is what makes N = 200000 (160 GB) fit one MI355X - and every off-diagonal tile is
 // used twice per sweep:   W_I += A_IJ X_J   (direct)   and   W_J += A_IJ^T X_I   (transposed).
 //
+// Two kernels, same slabs and same reduction: matvec_sym8_kernel (default: 8 waves, two per SIMD, further
+// down) and matvec_sym_kernel (4 waves, one per SIMD, described first; DAV_SYM_V8=0 selects it for A/B runs).
+//
 // Workgroup = 4 waves, one run of tiles (I, J0..J1) of block row I.  Inside every 64-column batch of a
 // tile wave w owns the 16 tile columns 16w..16w+15 over ALL 256 rows ("unit" = 256 x 16, processed as four
 // 64-row steps).  That choice makes the transposed partial Z (16 tile columns x 16 block columns, summed
@@ -34,6 +37,7 @@
 // fetch = tile bytes.  Traffic per sweep: the stored half matrix once, plus 1/16 of it written as per-tile
 // Z slabs and read back by the reduction kernel (8 % of the sweep time) - the price of a deterministic sum.
 #include "kernels.h"
+#include <cstdlib>
 #include <type_traits>
 
 // tile (I, J), J <= I, at tiles + (I (I+1)/2 + J) * TB*TB, column-major with leading dimension TB
@@ -55,7 +59,8 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int I = items[3 * blockIdx.x], J0 = items[3 * blockIdx.x + 1], J1 = items[3 * blockIdx.x + 2];
+  // work item: (block row, first tile, end tile, slab slot); items are dispatched longest first
+  const int I = items[4 * blockIdx.x], J0 = items[4 * blockIdx.x + 1], J1 = items[4 * blockIdx.x + 2];
 
   // B operand of the transposed product: X_I, stored transposed ([block column][row]) so that the four
   // consecutive rows a lane needs are one 32-byte run
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
   // end of the run: sum the direct partials of the four waves (they own different tile columns), one
   // 64-row group at a time, through the scratch the transposition used
   double* red = &tr[0][0];
-  double* outD = slabD + (int64_t)blockIdx.x * 16 * SYM_TB;
+  double* outD = slabD + (int64_t)items[4 * blockIdx.x + 3] * 16 * SYM_TB;
 #pragma unroll
   for (int rg = 0; rg < 4; ++rg) {
     __syncthreads();
@@ -195,12 +200,174 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
   }
 }
 
+// ---- v8: two waves per SIMD -----------------------------------------------------------------------------
+// Measured on gfx950 (scratch microbenchmarks): while a wave has a v_mfma_f64_16x16x4 in
+// flight it issues nothing else - every VALU / DS / VMEM instruction of that wave adds its own issue time
+// (4-5 cycles, 18+ for a 16-byte global load) on top of the 64 cycles per MFMA; a SECOND wave on the same
+// SIMD, however, issues in the shadow of those MFMAs at full MFMA rate for the first.  The kernel above
+// runs one wave per SIMD (128 accumulator + 128 ring registers), so its ~100 non-MFMA instructions per
+// step are serialised with the 32 MFMAs.  Here a workgroup has 8 waves: wave (w, h) owns tile columns
+// 16w..16w+15 of every 64-column batch over the row half h (128 rows, four 32-row half-steps), which fits
+// 256 registers.  The transposed partial of a unit is now split over the two waves of a pair: wave h=1
+// hands its 16 x 16 partial to wave h=0 through LDS (one workgroup barrier per unit, double buffered).
+constexpr int SYM8_DEPTH = 3;     // half-steps of load lookahead (ring of 4 slots)
+
+__global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
+                                                             const double* __restrict__ xt, double* __restrict__ slabD,
+                                                             double* __restrict__ slabT) {
+  constexpr int TRS = 34;         // padded column stride of the 32-row transposition scratch (272 B)
+  constexpr int TRW = 16 * TRS;   // doubles per wave
+  constexpr int XT = 258;         // padded column stride of the transposed X_I copy
+  constexpr int RS = 33;          // padded stride of the end-of-run exchange (32 rows per block column)
+  __shared__ __attribute__((aligned(16))) double tr[8 * TRW];
+  __shared__ __attribute__((aligned(16))) double xsT[16 * XT];
+  __shared__ __attribute__((aligned(16))) double zred[2][4][2][128];   // [unit parity][column group][half of f64x4][lane x 2]
+  static_assert(TRW >= 16 * RS, "the end-of-run exchange reuses the transposition scratch");
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int w = wave & 3, h = wave >> 2;
+  const int c = lane & 15, g = lane >> 4;
+  // work item: (block row, first tile, end tile, slab slot); items are dispatched longest first
+  const int I = items[4 * blockIdx.x], J0 = items[4 * blockIdx.x + 1], J1 = items[4 * blockIdx.x + 2];
+
+  for (int e = threadIdx.x; e < SYM_TB * 16; e += 512)
+    xsT[(e & 15) * XT + (e >> 4)] = xt[((int64_t)I * SYM_TB + (e >> 4)) * 16 + (e & 15)];
+  __syncthreads();
+
+  // direct partials: 128 rows (this wave's half) x 16 block columns; [half-step][row parity]
+  f64x4 acc[4][2];
+#pragma unroll
+  for (int hs = 0; hs < 4; ++hs) { acc[hs][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[hs][1] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+
+  const int nunits = (J1 - J0) * 4;
+  const int nsteps = nunits * 4;                    // half-steps
+  const int64_t dlane = 128 * h + 2 * c + (int64_t)g * SYM_TB;
+  double* tw = tr + wave * TRW;
+
+  f64x2 ra[4][4];                                   // ring: slot = half-step inside the unit
+  auto load_hs = [&](int s, f64x2 (&a)[4]) {
+    s = s < nsteps ? s : nsteps - 1;
+    const int q = s >> 2, hs = s & 3;
+    const int J = J0 + (q >> 2), col = (q & 3) * 64 + w * 16;
+    const double* ad = sym_tile(tiles, I, J) + (int64_t)col * SYM_TB + 32 * hs + dlane;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
+  };
+  auto load_b = [&](int q, double (&b)[4]) {
+    q = q < nunits ? q : nunits - 1;
+    const int J = J0 + (q >> 2), col = (q & 3) * 64 + w * 16;
+    const double* xj = xt + ((int64_t)J * SYM_TB + col + g) * 16 + c;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = xj[(4 * u) * 16];
+  };
+  double b[4], bn[4];
+  load_b(0, b);
+#pragma unroll
+  for (int d = 0; d < SYM8_DEPTH; ++d) load_hs(d, ra[d]);
+
+  auto unit = [&](auto off_tag, int q) {
+    constexpr bool OFF = decltype(off_tag)::value;
+    load_b(q + 1, bn);
+    int xoff = c * XT + 128 * h + 4 * g;            // opaque: keeps the X_I reads inside the loop
+    asm volatile("" : "+v"(xoff));
+    const double* xw = xsT + xoff;
+    f64x4 zc[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int hs = 0; hs < 4; ++hs) {
+      f64x2 (&a)[4] = ra[hs];
+      load_hs(q * 4 + hs + SYM8_DEPTH, ra[(hs + SYM8_DEPTH) & 3]);
+      if constexpr (OFF) {
+        f64x2 p[2][2], xb[2][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c) = a[u];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          p[ib][0] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g);
+          p[ib][1] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g + 2);
+          xb[ib][0] = *reinterpret_cast<const f64x2*>(xw + 32 * hs + 16 * ib);
+          xb[ib][1] = *reinterpret_cast<const f64x2*>(xw + 32 * hs + 16 * ib + 2);
+        }
+        // direct and transposed MFMAs alternate: every accumulator chain is touched once per four MFMAs
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          acc[hs][0] = mfma_f64(a[2 * ib].x, b[2 * ib], acc[hs][0]);
+          zc[0] = mfma_f64(p[ib][0].x, xb[ib][0].x, zc[0]);
+          acc[hs][1] = mfma_f64(a[2 * ib].y, b[2 * ib], acc[hs][1]);
+          zc[1] = mfma_f64(p[ib][0].y, xb[ib][0].y, zc[1]);
+          acc[hs][0] = mfma_f64(a[2 * ib + 1].x, b[2 * ib + 1], acc[hs][0]);
+          zc[2] = mfma_f64(p[ib][1].x, xb[ib][1].x, zc[2]);
+          acc[hs][1] = mfma_f64(a[2 * ib + 1].y, b[2 * ib + 1], acc[hs][1]);
+          zc[3] = mfma_f64(p[ib][1].y, xb[ib][1].y, zc[3]);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[hs][0] = mfma_f64(a[u].x, b[u], acc[hs][0]);
+          acc[hs][1] = mfma_f64(a[u].y, b[u], acc[hs][1]);
+        }
+      }
+    }
+    if constexpr (OFF) {
+      // z[reg]: tile column col + g + 4 reg, block column c, summed over this wave's 128 rows; the pair's
+      // other half arrives through LDS.  One barrier per unit; the buffer alternates with the unit parity.
+      f64x4 z = (zc[0] + zc[1]) + (zc[2] + zc[3]);
+      double* zr = &zred[q & 1][w][0][0];
+      if (h == 1) {
+        *reinterpret_cast<f64x2*>(zr + 2 * lane) = f64x2{z[0], z[1]};
+        *reinterpret_cast<f64x2*>(zr + 128 + 2 * lane) = f64x2{z[2], z[3]};
+      }
+      __syncthreads();
+      if (h == 0) {
+        const f64x2 z01 = *reinterpret_cast<const f64x2*>(zr + 2 * lane);
+        const f64x2 z23 = *reinterpret_cast<const f64x2*>(zr + 128 + 2 * lane);
+        z[0] += z01.x; z[1] += z01.y; z[2] += z23.x; z[3] += z23.y;
+        const int J = J0 + (q >> 2), col = (q & 3) * 64 + w * 16;
+        double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16 + c) * SYM_TB + col + g;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = bn[u];
+  };
+  const int nq_off = ((J1 - 1 == I ? J1 - 1 : J1) - J0) * 4;
+  int q = 0;
+  for (; q < nq_off; ++q) unit(std::true_type{}, q);
+  for (; q < nunits; ++q) unit(std::false_type{}, q);
+
+  // end of the run: sum the direct partials over the four column groups, one 32-row half-step at a time
+  double* outD = slabD + (int64_t)items[4 * blockIdx.x + 3] * 16 * SYM_TB;
+#pragma unroll
+  for (int hs = 0; hs < 4; ++hs) {
+    __syncthreads();
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) tw[c * RS + 2 * (g + 4 * reg) + par] = acc[hs][par][reg];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int e = threadIdx.x + 512 * t;
+      const int hh = e >> 9, bc = (e >> 5) & 15, r = e & 31;
+      const double* rp = tr + (hh * 4) * TRW + bc * RS + r;
+      outD[(int64_t)bc * SYM_TB + 128 * hh + 32 * hs + r] = (rp[0] + rp[TRW]) + (rp[2 * TRW] + rp[3 * TRW]);
+    }
+  }
+}
+
 void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev, int nitems, const double* xt,
                        int64_t xt_group_stride, int ngroups, double* slabD, double* slabT) {
   // one 16-column group per pass
   (void)ngroups;
   (void)xt_group_stride;
-  hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, items_dev, xt, slabD, slabT);
+  // DAV_SYM_V8=0 selects the one-wave-per-SIMD kernel (kept for A/B measurements)
+  static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
+  if (v8)
+    hipLaunchKernelGGL(matvec_sym8_kernel, dim3(nitems), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT);
+  else
+    hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, items_dev, xt, slabD, slabT);
 }
 
 // W[J*256 + r, col] = sum over runs of block row J of slabD + sum over I > J of slabT(I, J), fixed order.
