@@ -1267,11 +1267,11 @@ static int gjd_dots(Gjd& g, int npairs, const double* const* a, const double* co
 
 extern "C" int dav_gjd_correction(dav_handle_t e, int m, const double* theta, int max_inner, double inner_tol,
                                   int* inner_iters_out) {
-  return dav_gjd_correction_n(e, m, m, theta, max_inner, inner_tol, inner_iters_out);
+  return dav_gjd_correction_n(e, m, m, theta, max_inner, inner_tol, nullptr, inner_iters_out);
 }
 
 extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const double* theta, int max_inner, double inner_tol,
-                                    int* inner_iters_out) {
+                                    const double* tol_per_col, int* inner_iters_out) {
   CHK(bind(e));
   if (m <= 0 || mbasis < m || mbasis + m > e->cols_alloc || m > e->cols_alloc / 2) return fail("dav_gjd_correction: bad block width");
   if (e->op[DAV_OP_A].kind == DAV_KIND_HOST || e->op[DAV_OP_A].kind == DAV_KIND_NONE)
@@ -1336,12 +1336,23 @@ extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const dou
       c1[j] = c0[j] * cy[j];
     }
     CHK(gjd_lincomb(g, v, y, &c0, mx, &c1));
-    // U = A v, UB = B v
-    CHK(apply_ptr(e, DAV_OP_A, v, m, ua, true));
+    // U = A v, UB = B v - only over the 16-column groups that still hold an active pair (a sweep costs one
+    // pass per group in symmetric storage; columns outside the range are multiplied by zero below)
+    int c_lo = m, c_hi = 0;
+    for (int j = 0; j < m; ++j)
+      if (active[j] != 0.0) { c_lo = std::min(c_lo, j); c_hi = std::max(c_hi, j + 1); }
+    c_lo = c_lo / 16 * 16;
+    c_hi = std::min(m, (c_hi + 15) / 16 * 16);
+    CHK(apply_ptr(e, DAV_OP_A, v + (size_t)c_lo * e->ldp, c_hi - c_lo, ua + (size_t)c_lo * e->ldp, true));
     const double* ubp = v;
     if (gev) {
-      CHK(apply_ptr(e, DAV_OP_B, v, m, ub, true));
+      CHK(apply_ptr(e, DAV_OP_B, v + (size_t)c_lo * e->ldp, c_hi - c_lo, ub + (size_t)c_lo * e->ldp, true));
       ubp = ub;
+    }
+    if (getenv("DAV_GJD_TRACE")) {
+      int na = 0;
+      for (int j = 0; j < m; ++j) na += active[j] != 0.0;
+      fprintf(stderr, "gjd inner %d: active %d of %d, columns [%d, %d)\n", itn, na, m, c_lo, c_hi);
     }
     // y = (U - theta UB) - (x^T(U - theta UB)) x - (beta/oldb) r1
     {
@@ -1404,7 +1415,7 @@ extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const dou
     for (int j = 0; j < m; ++j) c1[j] = phi[j] * active[j];
     CHK(gjd_lincomb(g, T, T, &one, w, &c1));
     for (int j = 0; j < m; ++j)
-      if (active[j] != 0.0 && (!(phibar[j] > inner_tol * beta1[j]) || !(beta[j] > 0.0) ||
+      if (active[j] != 0.0 && (!(phibar[j] > (tol_per_col ? tol_per_col[j] : inner_tol) * beta1[j]) || !(beta[j] > 0.0) ||
                                (stall[j] >= 8 && phibar[j] < 1e-6 * beta1[j])))
         active[j] = 0.0;      // converged, broke down, or stagnated at the attainable accuracy
   }

@@ -322,7 +322,7 @@ contains
 
     integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr
     integer(c_int), allocatable :: sel(:)
-    real(dp), allocatable :: theta_sel(:)
+    real(dp), allocatable :: theta_sel(:), tols(:)
     logical :: expand_now
     integer(c_int64_t) :: ld
     integer(c_int64_t), allocatable :: idx(:)
@@ -410,8 +410,14 @@ contains
           if (pol == POLICY_ALL) then
              kt = m                                      ! one correction per basis vector (the reference)
              if (meth == DAV_METHOD_GJD) then
-                call check_dav(dav_gjd_correction(h, int(m, c_int), theta, 300_c_int, 1.0e-10_dp, inner), &
-                     "dav_gjd_correction")
+                ! the wanted pairs are solved to 1e-10 (what makes the outer iteration count equal to the
+                ! reference's exact solves); the other m - lowest corrections only enrich the basis
+                if (allocated(tols)) deallocate(tols)
+                allocate(tols(m))
+                tols = gjd_tol_unwanted()
+                tols(1:lowest) = 1.0e-10_dp
+                call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(m, c_int), theta, 300_c_int, 1.0e-10_dp, &
+                     tols, inner), "dav_gjd_correction")
                 call lap(8)
              end if
           else
@@ -430,8 +436,11 @@ contains
              if (meth == DAV_METHOD_GJD) then
                 call check_dav(dav_panel_select(h, DAV_PANEL_X, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
                 call check_dav(dav_panel_select(h, DAV_PANEL_R, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
+                if (allocated(tols)) deallocate(tols)
+                allocate(tols(kt))
+                tols = 1.0e-10_dp
                 call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), theta_sel, 300_c_int, &
-                     1.0e-10_dp, inner), "dav_gjd_correction")
+                     1.0e-10_dp, tols, inner), "dav_gjd_correction")
                 call lap(8)
              else
                 call check_dav(dav_panel_select(h, DAV_PANEL_V, int(m, c_int), int(kt, c_int), sel), "dav_panel_select")
@@ -484,6 +493,20 @@ contains
     end subroutine lap
 
   end subroutine davidson_device_loop
+
+  !> Inner tolerance of the GJD solves for the Ritz pairs beyond `lowest`: 1e-4 relative (DAV_GJD_TOL_UNWANTED
+  !> overrides).  Their corrections only enrich the search space; with 1e-6, 1e-4 and 1e-2 every golden GJD
+  !> case keeps the reference's outer iteration count while the block sweeps of A drop by a third to a half
+  !> (N=40000 generalized: 62 -> 45 / 39 / 33 sweeps).
+  function gjd_tol_unwanted() result(t)
+    real(dp) :: t
+    integer :: stat, length
+    character(len=32) :: buf
+    t = 1.0e-4_dp
+    call get_environment_variable("DAV_GJD_TOL_UNWANTED", buf, length, stat)
+    if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) t
+    if (stat /= 0) t = 1.0e-4_dp
+  end function gjd_tol_unwanted
 
   function tick() result(t)
     real(dp) :: t

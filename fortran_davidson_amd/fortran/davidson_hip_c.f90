@@ -188,12 +188,12 @@ module davidson_hip_c
        integer(c_int), intent(in) :: sel(*)
        integer(c_int) :: ierr
      end function
-     function dav_gjd_correction_n(h, m, ncols, theta, max_inner, inner_tol, inner_iters) &
+     function dav_gjd_correction_n(h, m, ncols, theta, max_inner, inner_tol, tol_per_col, inner_iters) &
           bind(C, name="dav_gjd_correction_n") result(ierr)
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
        integer(c_int), value :: m, ncols, max_inner
-       real(c_double), intent(in) :: theta(*)
+       real(c_double), intent(in) :: theta(*), tol_per_col(*)
        real(c_double), value :: inner_tol
        integer(c_int), intent(out) :: inner_iters
        integer(c_int) :: ierr

@@ -171,9 +171,10 @@ int dav_panel_select(dav_handle_t h, int panel, int c0, int nsel, const int* sel
 int dav_gjd_correction(dav_handle_t h, int m, const double* theta, int max_inner, double inner_tol,
                        int* inner_iters_out);
 /* Same for ncols <= m pairs whose X and R sit in the first ncols columns of their panels; T goes to
- * V[:, m:m+ncols] (opt-in correction policy, see dav_ritz_residual_correction_n). */
+ * V[:, m:m+ncols] (opt-in correction policy, see dav_ritz_residual_correction_n).  tol_per_col (ncols
+ * entries, or NULL = inner_tol everywhere) sets the relative residual at which each pair's inner solve stops. */
 int dav_gjd_correction_n(dav_handle_t h, int m, int ncols, const double* theta, int max_inner, double inner_tol,
-                         int* inner_iters_out);
+                         const double* tol_per_col, int* inner_iters_out);
 /* K4 - replaces concatenate + lapack_qr (src/davidson.f90:210-213): block Gram-Schmidt of the
  * k = kt correction columns T = V[:, m:m+kt] against V[:, 0:m] and among themselves.
  * dav_ortho_gram returns C = V^T T (m x kt) and G = T^T T (kt x kt); the host factors
