@@ -827,8 +827,7 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       int slot = -1;
       double bytes = 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) + 16.0 * (double)e->n * kk;
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
-      launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, e->xt_group_stride, ngroups, e->sym_slab,
-                        e->sym_slab + e->sym_slabD_doubles);
+      launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, e->sym_slab + e->sym_slabD_doubles);
       if (timed) CHK(timed_end(e, slot));
       launch_sym_reduce(e->stream, e->sym_slab, e->sym_slab + e->sym_slabD_doubles, e->sym_row_begin, e->sym_nb, ngroups,
                         e->nloc, kk, dst + (int64_t)c * e->ldp, e->ldp);

@@ -49,7 +49,7 @@ constexpr int SYM_DEPTH = 3;      // steps of load lookahead (ring of 4 slots)
 
 __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
                                                             const double* __restrict__ xt, double* __restrict__ slabD,
-                                                            double* __restrict__ slabT) {
+                                                            double* __restrict__ slabT, int kcols) {
   constexpr int RS = 65;          // padded stride of the end-of-run exchange of the direct partials
   constexpr int TRS = 66;         // padded column stride of the transposition scratch (528 B)
   constexpr int XT = 258;         // padded column stride of the transposed X_I copy (b128 reads conflict free)
@@ -166,8 +166,10 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
       const f64x4 z = (zc[0] + zc[1]) + (zc[2] + zc[3]);
       const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
       double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16 + c) * SYM_TB + col + g;
+      if (c < kcols) {            // block columns beyond the k in use carry zeros nobody reads
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
+        for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) b[u] = bn[u];
@@ -194,8 +196,9 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * 16; e += 256) {
       const int le = (e >> 6) * RS + (e & 63);
-      outD[(int64_t)(e >> 6) * SYM_TB + rg * 64 + (e & 63)] =
-          red[le] + red[16 * TRS + le] + red[2 * 16 * TRS + le] + red[3 * 16 * TRS + le];
+      if ((e >> 6) < kcols)
+        outD[(int64_t)(e >> 6) * SYM_TB + rg * 64 + (e & 63)] =
+            red[le] + red[16 * TRS + le] + red[2 * 16 * TRS + le] + red[3 * 16 * TRS + le];
     }
   }
 }
@@ -214,7 +217,7 @@ constexpr int SYM8_DEPTH = 3;     // half-steps of load lookahead (ring of 4 slo
 
 __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
-                                                             double* __restrict__ slabT) {
+                                                             double* __restrict__ slabT, int kcols) {
   constexpr int TRS = 34;         // padded column stride of the 32-row transposition scratch (272 B)
   constexpr int TRW = 16 * TRS;   // doubles per wave
   constexpr int XT = 258;         // padded column stride of the transposed X_I copy
@@ -325,8 +328,10 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
         z[0] += z01.x; z[1] += z01.y; z[2] += z23.x; z[3] += z23.y;
         const int J = J0 + (q >> 2), col = (q & 3) * 64 + w * 16;
         double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16 + c) * SYM_TB + col + g;
+        if (c < kcols) {          // block columns beyond the k in use carry zeros nobody reads
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
+          for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
+        }
       }
     }
 #pragma unroll
@@ -352,22 +357,20 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
       const int e = threadIdx.x + 512 * t;
       const int hh = e >> 9, bc = (e >> 5) & 15, r = e & 31;
       const double* rp = tr + (hh * 4) * TRW + bc * RS + r;
-      outD[(int64_t)bc * SYM_TB + 128 * hh + 32 * hs + r] = (rp[0] + rp[TRW]) + (rp[2 * TRW] + rp[3 * TRW]);
+      if (bc < kcols) outD[(int64_t)bc * SYM_TB + 128 * hh + 32 * hs + r] = (rp[0] + rp[TRW]) + (rp[2 * TRW] + rp[3 * TRW]);
     }
   }
 }
 
-void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev, int nitems, const double* xt,
-                       int64_t xt_group_stride, int ngroups, double* slabD, double* slabT) {
-  // one 16-column group per pass
-  (void)ngroups;
-  (void)xt_group_stride;
+void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev, int nitems, const double* xt, int kcols,
+                       double* slabD, double* slabT) {
+  // one 16-column group per pass; kcols <= 16 of its block columns are in use
   // DAV_SYM_V8=0 selects the one-wave-per-SIMD kernel (kept for A/B measurements)
   static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
   if (v8)
-    hipLaunchKernelGGL(matvec_sym8_kernel, dim3(nitems), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT);
+    hipLaunchKernelGGL(matvec_sym8_kernel, dim3(nitems), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT, kcols);
   else
-    hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, items_dev, xt, slabD, slabT);
+    hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, items_dev, xt, slabD, slabT, kcols);
 }
 
 // W[J*256 + r, col] = sum over runs of block row J of slabD + sum over I > J of slabT(I, J), fixed order.
