@@ -25,9 +25,11 @@ static int fail(const std::string& msg) {
 #define HIPCHK(call)                                                                                  \
   do {                                                                                                \
     hipError_t e_ = (call);                                                                           \
-    if (e_ != hipSuccess)                                                                             \
+    if (e_ != hipSuccess) {                                                                           \
+      (void)hipGetLastError(); /* reported here: do not leave it for a later hipGetLastError() */     \
       return fail(std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" +      \
                   std::to_string(__LINE__) + ")");                                                    \
+    }                                                                                                 \
   } while (0)
 #define CHK(call)            \
   do {                       \
@@ -263,13 +265,28 @@ static int check_panel(E* e, int panel, int c0, int k) {
 extern "C" const char* dav_last_error(void) { return g_err.c_str(); }
 extern "C" int dav_version(void) { return 100; }
 
+static int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, int nranks);
+
 extern "C" int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, int gev, int rank, int nranks) {
   if (!h || n <= 0 || max_cols <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return fail("dav_create: bad arguments");
+  *h = nullptr;
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) return fail("dav_create: no HIP device visible - the HIP path has no CPU fallback");
   if (device < 0 || device >= ndev) return fail("dav_create: device index out of range");
   E* e = new E();
+  int rc = create_impl(e, device, n, max_cols, gev, rank, nranks);
+  if (rc != 0) {                     // e.g. out of device memory: release what was allocated, keep the message
+    std::string msg = g_err;
+    dav_destroy(e);
+    g_err = msg;
+    return rc;
+  }
+  *h = e;
+  return 0;
+}
+
+static int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, int nranks) {
   e->device = device;
   e->n = n;
   e->rank = rank;
@@ -287,7 +304,6 @@ extern "C" int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, 
   e->st.nloc = e->nloc;
   e->st.rank = rank;
   e->st.nranks = nranks;
-  *h = e;
   CHK(bind(e));
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   size_t pbytes = sizeof(double) * (size_t)e->ldp * e->cols_alloc;
@@ -529,7 +545,10 @@ static int sym_setup(E* e) {
   size_t slabT = (size_t)((int64_t)nb * (nb - 1) / 2) * 32 * SYM_TB;
   e->sym_slab_doubles = e->sym_slabD_doubles + slabT;
   hipError_t r = hipMalloc(&e->sym_slab, sizeof(double) * e->sym_slab_doubles);
-  if (r != hipSuccess) return fail("hipMalloc of the symmetric sweep slabs failed: " + std::string(hipGetErrorString(r)));
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    return fail("hipMalloc of the symmetric sweep slabs failed: " + std::string(hipGetErrorString(r)));
+  }
   return 0;
 }
 
@@ -546,8 +565,10 @@ static int alloc_dense(E* e, int which) {
       bytes = sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
     }
     hipError_t r = hipMalloc(&o.a, bytes);
-    if (r != hipSuccess)
+    if (r != hipSuccess) {
+      (void)hipGetLastError();
       return fail("hipMalloc of the dense matrix (" + std::to_string(bytes >> 20) + " MiB) failed: " + hipGetErrorString(r));
+    }
   }
   if (o.storage == 1) CHK(sym_setup(e));
   return 0;

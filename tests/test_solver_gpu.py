@@ -339,3 +339,16 @@ def test_gjd_on_harder_matrices_matches_oracle_iteration_counts(n, L, sp, md, ge
     assert it == it_o
     assert np.abs(lam - lam_o).max() < EV_TOL
     assert (residuals(A, B, lam, vec) < 1e-8).all()
+
+
+def test_engine_that_does_not_fit_fails_with_a_message_and_releases_memory():
+    """Panels of 10^7 x 2064 doubles (5 x 165 GB) cannot be allocated: dav_create must report it, free what
+    it got and leave the device usable."""
+    import torch
+    free0, _ = torch.cuda.mem_get_info()
+    with pytest.raises(fd.DavidsonHipError, match="hipMalloc"):
+        fd.CEngine(n=10_000_000, max_cols=2048)
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 > free0 - (1 << 30)
+    lam, _, it = fd.generalized_eigensolver(O.generate_diagonal_dominant(64, 1e-2, seed=1), 2, "DPR", 50, 1e-8)
+    assert it <= 50 and np.isfinite(lam).all()
