@@ -9,6 +9,7 @@
 // The column range is split over blockIdx.y (>>256 workgroups); partial tiles go to a slab that a
 // second, tiny kernel sums in a fixed order (bitwise reproducible, no fp64 atomics).
 #include "kernels.h"
+#include <type_traits>
 #include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
@@ -115,7 +116,6 @@ __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t r
   const int64_t j0 = (int64_t)s * jc;
   int64_t j1 = j0 + jc;
   if (j1 > ncols_pad) j1 = ncols_pad;
-  const double* xp = xt + (j0 + g) * 16 + c;
 
   f64x4 acc[4][NT];
 #pragma unroll
@@ -124,26 +124,66 @@ __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t r
     for (int t = 0; t < NT; ++t) acc[rt][t] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   int64_t li[4] = {r0 + 2 * c, r0 + 2 * c + 1, r0 + 32 + 2 * c, r0 + 32 + 2 * c + 1};
-  for (int64_t j = j0; j < j1; j += 4) {
-    const int64_t gj = j + g;
-    double a[4];
+  // MODE 0: every test per entry (bounds, diagonal, which index is the smaller).  MODE 1 / 2 (hashed
+  // operator only): the whole column range lies strictly below / above the rows of this workgroup and
+  // inside the matrix, so lo/hi are known and the key of uniform01 is one 64-bit add away from a
+  // per-row constant - the generator is VALU bound, every instruction removed counts.
+  const uint64_t seedmix = op.seed * 0x9E3779B97F4A7C15ull;
+  uint64_t kb_below[4], kb_above[4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      double v = 0.0;
-      if (li[rt] < nloc && gj < n) {
-        int64_t gi = row0 + li[rt];
-        if (KIND == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
-        else v = dav_harness_entry(op.e_table, op.trig, gi, gj);
+  for (int rt = 0; rt < 4; ++rt) {
+    const uint64_t gi = (uint64_t)(row0 + li[rt]);
+    kb_below[rt] = gi + seedmix;                 // key = (gj << 32) + gi + seedmix
+    kb_above[rt] = (gi << 32) + seedmix;         // key = (gi << 32) + gj + seedmix
+  }
+  // (m * 2^-53) * sparsity with one rounding, as dav_uniform01 * sparsity gives: m (53 bits) is exactly
+  // hi * 2^32 + lo, and 2^-53 * sparsity is an exact scaling of sparsity
+  const double scale = op.sparsity * (1.0 / 9007199254740992.0);
+  auto u53 = [](uint64_t m) { return __builtin_fma((double)(uint32_t)(m >> 32), 4294967296.0, (double)(uint32_t)m); };
+  auto sweep = [&](auto mode_tag, int64_t ja, int64_t jb) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const double* xq = xt + (ja + g) * 16 + c;
+    for (int64_t j = ja; j < jb; j += 4) {
+      const int64_t gj = j + g;
+      double a[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        double v = 0.0;
+        if (MODE == 1) {
+          v = u53(dav_splitmix64(((uint64_t)gj << 32) + kb_below[rt]) >> 11) * scale;
+        } else if (MODE == 2) {
+          v = u53(dav_splitmix64(kb_above[rt] + (uint64_t)gj) >> 11) * scale;
+        } else if (li[rt] < nloc && gj < n) {
+          int64_t gi = row0 + li[rt];
+          if (KIND == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
+          else v = dav_harness_entry(op.e_table, op.trig, gi, gj);
+        }
+        a[rt] = v;
       }
-      a[rt] = v;
-    }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      double b = xp[t * group_stride];
+      for (int t = 0; t < NT; ++t) {
+        double b = xq[t * group_stride];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt][t] = mfma_f64(a[rt], b, acc[rt][t]);
+        for (int rt = 0; rt < 4; ++rt) acc[rt][t] = mfma_f64(a[rt], b, acc[rt][t]);
+      }
+      xq += 4 * 16;
     }
-    xp += 4 * 16;
+  };
+  // global rows of this workgroup: [gr0, gr0 + MV_ROWS); fast segments need all of them inside the slab
+  const int64_t gr0 = row0 + (int64_t)blockIdx.x * MV_ROWS;
+  const bool rows_inside = (int64_t)(blockIdx.x + 1) * MV_ROWS <= nloc;
+  if (KIND == DAV_KIND_HASHED && rows_inside) {
+    const int64_t jn = j1 < n ? j1 : (n / 4 * 4);                       // columns [jn, j1) may cross the matrix edge
+    int64_t jlo = gr0 / 4 * 4;                                          // first column step that can touch the diagonal band
+    int64_t jhi = (gr0 + MV_ROWS + 3) / 4 * 4;                          // first column step strictly above it
+    jlo = jlo < j0 ? j0 : (jlo > jn ? jn : jlo);
+    jhi = jhi < jlo ? jlo : (jhi > jn ? jn : jhi);
+    sweep(std::integral_constant<int, 1>{}, j0, jlo);                   // gj < every gi
+    sweep(std::integral_constant<int, 0>{}, jlo, jhi);                  // diagonal band
+    sweep(std::integral_constant<int, 2>{}, jhi, jn);                   // gj > every gi
+    sweep(std::integral_constant<int, 0>{}, jn, j1);                    // ragged edge
+  } else {
+    sweep(std::integral_constant<int, 0>{}, j0, j1);
   }
 
   double* out = slab + (int64_t)s * (NT * 16) * nrows_pad;
