@@ -236,6 +236,17 @@ contains
     end if
   end subroutine fd_lapack_eigensolver
 
+  subroutine fd_lapack_rayleigh_ritz(n, mtx, has_stx, stx, nvec, evals, evecs) bind(C, name="fd_lapack_rayleigh_ritz")
+    integer(c_int), value :: n, has_stx, nvec
+    real(c_double), intent(in) :: mtx(n, n), stx(n, *)
+    real(c_double), intent(out) :: evals(n), evecs(n, n)
+    if (has_stx /= 0) then
+       call lapack_rayleigh_ritz(mtx, evals, evecs, int(nvec), stx(:, 1:n))
+    else
+       call lapack_rayleigh_ritz(mtx, evals, evecs, int(nvec))
+    end if
+  end subroutine fd_lapack_rayleigh_ritz
+
   subroutine fd_lapack_qr(m, n, basis) bind(C, name="fd_lapack_qr")
     integer(c_int), value :: m, n
     real(c_double), intent(inout) :: basis(m, n)

@@ -165,6 +165,18 @@ def lapack_generalized_eigensolver(mtx, stx=None):
     return w, v
 
 
+def lapack_rayleigh_ritz(mtx, nvec, stx=None):
+    """The Rayleigh-Ritz solver of the outer loop: lowest `nvec` pairs (first nvec entries / columns valid)."""
+    mtx = _f(mtx)
+    n = mtx.shape[0]
+    s = _f(stx) if stx is not None else np.zeros((1, 1), order="F")
+    w = np.zeros(n)
+    v = np.zeros((n, n), order="F")
+    fortran_lib().fd_lapack_rayleigh_ritz(C.c_int(n), _dp(mtx), C.c_int(0 if stx is None else 1), _dp(s), C.c_int(nvec),
+                                          _dp(w), _dp(v))
+    return w[:nvec], v[:, :nvec]
+
+
 def lapack_qr(basis):
     q = _f(basis).copy(order="F")
     fortran_lib().fd_lapack_qr(C.c_int(q.shape[0]), C.c_int(q.shape[1]), _dp(q))

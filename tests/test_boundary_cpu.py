@@ -80,3 +80,23 @@ def test_sort_and_preconditioner():
     pre = fd.generate_preconditioner(d, 6)
     assert np.array_equal(pre, O.generate_preconditioner(d, 6))
     assert fd.norm(np.array([3.0, 4.0])) == 5.0
+
+
+@pytest.mark.parametrize("n,nvec", [(40, 40), (40, 6), (96, 96), (150, 150), (150, 20), (300, 64)])
+@pytest.mark.parametrize("gev", [False, True])
+def test_rayleigh_ritz_solver_all_routes_against_scipy(n, nvec, gev):
+    """lapack_rayleigh_ritz: DSYEV/DSYGV below order 96 (the reference's route), divide and conquer above,
+    MRRR on a leading subset (Cholesky-reduced when generalized) - same eigenpairs, DSYGV normalisation."""
+    import scipy.linalg
+    from fortran_davidson_amd.solver import lapack_rayleigh_ritz
+    rng = np.random.default_rng(n + nvec)
+    H = rng.standard_normal((n, n)); H = (H + H.T) / 2 + np.diag(np.arange(n))
+    S = None
+    if gev:
+        S = rng.standard_normal((n, n)) * 0.02; S = np.eye(n) + (S + S.T) / 2
+    w, Y = lapack_rayleigh_ritz(H, nvec, S)
+    ref = scipy.linalg.eigh(H, S, eigvals_only=True)[:nvec]
+    assert np.abs(w - ref).max() < 1e-10
+    SY = Y if S is None else S @ Y
+    assert np.abs(H @ Y - SY * w[None, :]).max() < 1e-9
+    assert np.abs(Y.T @ SY - np.eye(nvec)).max() < 1e-10
