@@ -229,6 +229,29 @@ def main():
               "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_pol - lam).max())}
     eng.close()
 
+    # same workload with the matrix kept as its lower block triangle (engine option, single GPU): every
+    # off-diagonal tile is read once and used twice, so a sweep moves half the bytes
+    sym = None
+    if world == 1:
+        try:
+            es = make_engine(n, lowest, None, "symmetric")
+            es.generate_diagonal_dominant(1, args.sparsity, seed=1)
+            es.solve("DPR", 1000, args.tol, want_vectors=False)
+            es.c.synchronize()
+            t4 = time.perf_counter()
+            it_s = 0
+            for _ in range(args.steps):
+                lam_s, _, it = es.solve("DPR", 1000, args.tol, want_vectors=False)
+                it_s += it
+            es.c.synchronize()
+            dt_s = time.perf_counter() - t4
+            sym = {"storage": "symmetric-tiled (dav_set_storage / engine_set_storage)", "ms_per_solve": round(dt_s / args.steps * 1e3, 4),
+                   "iterations_per_s": round(it_s / dt_s, 2), "iters_per_solve": it_s // args.steps,
+                   "max_abs_eigenvalue_diff_vs_full_storage": float(np.abs(lam_s - lam).max())}
+            es.close()
+        except Exception as exc:       # noqa: BLE001
+            sym = {"error": repr(exc)[:300]}
+
     # ---- configs[2]: N=200000 dense fp64, lowest=16, DPR, subspace restart at 80 ------------------------
     # one GPU: symmetric-tiled storage (160 GB, K1s sweep); >= 2 GPUs: full row slabs + RCCL all-gather
     large = None
@@ -296,7 +319,7 @@ def main():
                            "N": n, "lowest": lowest, "iters_per_solve": total_iters // args.steps,
                            "basis_widths": "2L,4L,8L", "parallelism": f"row-slab x{world}"},
                 "eigenvalues": [float(x) for x in lam[:3]],
-                "roofline": roofline, "phase_ms_per_step": phase, "apply": apply_k, "opt_in_policy": opt_in, "large": large, "cpu_baseline": cpu}
+                "roofline": roofline, "phase_ms_per_step": phase, "apply": apply_k, "opt_in_policy": opt_in, "symmetric_storage": sym, "large": large, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
