@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--n", "--order", dest="n", type=int, default=20000,
+                    help="matrix order (use --order under torch.distributed.run, whose parser rejects the prefix --n)")
     ap.add_argument("--lowest", type=int, default=8)
     ap.add_argument("--sparsity", type=float, default=1e-3)
     ap.add_argument("--tol", type=float, default=1e-8)
@@ -150,16 +151,28 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # DAVIDSON_TRANSPORT=shm: all ranks share GPU 0 and exchange through shared memory - a test transport
+    # that runs this whole multi-process flow on a single-GPU box (tests/test_bench_multiprocess_gpu.py).
+    # The multi-GPU data path is RCCL, one GPU per rank.
+    transport = os.environ.get("DAVIDSON_TRANSPORT", "rccl")
+    device = local_rank if transport == "rccl" else 0
+    torch.cuda.set_device(device)
 
     import fortran_davidson_amd as fd
+    engines_made = [0]
 
     def make_engine(n, lowest, max_dim=None, storage="full"):
-        eng = fd.DavidsonEngine(n, lowest, max_dim, gev=False, device=local_rank, rank=rank, nranks=world, storage=storage)
+        eng = fd.DavidsonEngine(n, lowest, max_dim, gev=False, device=device, rank=rank, nranks=world, storage=storage)
         if world > 1:
-            ident = [fd.CEngine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ident, src=0)
-            eng.comm_init(ident[0])
+            engines_made[0] += 1
+            if transport == "shm":
+                ident = [f"/dav_bench_{os.getpid()}_{engines_made[0]}" if rank == 0 else None]
+                dist.broadcast_object_list(ident, src=0)
+                eng.c.comm_init_shm(ident[0])
+            else:
+                ident = [fd.CEngine.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ident, src=0)
+                eng.comm_init(ident[0])
         return eng
 
     def barrier():

@@ -5,7 +5,11 @@
 #include "ingest.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -89,6 +93,23 @@ struct LocalGroup {
   const double* send[16] = {nullptr};
 };
 
+// ---- shared-memory transport: several ranks of one problem as PROCESSES that share one GPU ---------------
+// Same collective semantics again, through a POSIX shared-memory segment (staging via the host).  It lets
+// the complete multi-process launch flow (torch.distributed.run, id broadcast, one engine per process,
+// barriers) run on a single-GPU box; the multi-GPU data path is RCCL.
+struct ShmHeader {
+  pthread_barrier_t bar;
+  int nranks;
+  size_t slot_doubles;
+};
+struct ShmGroup {
+  ShmHeader* hdr = nullptr;
+  double* slots = nullptr;      // nranks x slot_doubles
+  size_t bytes = 0;
+  std::string name;
+  bool owner = false;
+};
+
 // ------------------------------------------------------------------------------------------------
 struct OpDesc {
   int kind = DAV_KIND_NONE;
@@ -144,6 +165,7 @@ struct dav_engine {
   size_t small_doubles = 0;
   ncclComm_t comm = nullptr;
   LocalGroup* lg = nullptr;       // loopback transport (tests); owned by rank 0
+  ShmGroup* shm = nullptr;        // shared-memory transport (tests of the multi-process launch flow)
   OpDesc op[2];
   std::vector<double> diag_host[2];
   // streaming ingest (dav_dense_begin .. dav_dense_end): two pinned row-major staging buffers + device twins
@@ -162,6 +184,7 @@ struct dav_engine {
 };
 typedef dav_engine E;
 static void ingest_release(E* e);
+static void shm_release(E* e);
 
 static inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -362,6 +385,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->norm_partial);
   hipFree(e->gjd_ws);
   ingest_release(e);
+  shm_release(e);
   hipFree(e->sym_items);
   hipFree(e->sym_row_begin);
   hipFree(e->sym_slab);
@@ -438,7 +462,7 @@ extern "C" int dav_local_rows(dav_handle_t e, int64_t* row0, int64_t* nloc) {
 }
 
 // ---- operators ---------------------------------------------------------------------------------
-static bool has_comm(E* e) { return e->comm != nullptr || e->lg != nullptr; }
+static bool has_comm(E* e) { return e->comm != nullptr || e->lg != nullptr || e->shm != nullptr; }
 static int need_comm(E* e) {
   if (e->nranks > 1 && !has_comm(e)) return fail("multi-rank engine used before dav_comm_init");
   return 0;
@@ -456,6 +480,20 @@ static int coll_allgather(E* e, const double* send, double* recv, size_t count) 
         HIPCHK(hipMemcpyAsync(recv + (size_t)p * count, g->send[p], sizeof(double) * count, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     pthread_barrier_wait(&g->bar);
+    return 0;
+  }
+  if (e->shm) {
+    ShmGroup* g = e->shm;
+    if (count > g->hdr->slot_doubles) return fail("shared-memory transport: message larger than a slot");
+    HIPCHK(hipMemcpyAsync(g->slots + (size_t)e->rank * g->hdr->slot_doubles, send, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
+    for (int p = 0; p < e->nranks; ++p)
+      if (p != e->rank || recv + (size_t)p * count != send)
+        HIPCHK(hipMemcpyAsync(recv + (size_t)p * count, g->slots + (size_t)p * g->hdr->slot_doubles, sizeof(double) * count,
+                              hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
     return 0;
   }
   NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
@@ -478,7 +516,81 @@ static int coll_allreduce(E* e, double* buf, size_t count) {
     HIPCHK(hipMemcpy(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
     return 0;
   }
+  if (e->shm) {
+    ShmGroup* g = e->shm;
+    if (count > g->hdr->slot_doubles) return fail("shared-memory transport: message larger than a slot");
+    HIPCHK(hipMemcpyAsync(g->slots + (size_t)e->rank * g->hdr->slot_doubles, buf, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
+    std::vector<double> sum(count, 0.0);
+    for (int p = 0; p < e->nranks; ++p) {          // rank order: the same bits on every rank
+      const double* src = g->slots + (size_t)p * g->hdr->slot_doubles;
+      for (size_t i = 0; i < count; ++i) sum[i] += src[i];
+    }
+    pthread_barrier_wait(&g->hdr->bar);
+    HIPCHK(hipMemcpy(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
   NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
+  return 0;
+}
+
+static void shm_release(E* e) {
+  ShmGroup* g = e->shm;
+  if (!g) return;
+  if (g->hdr) munmap(g->hdr, g->bytes);
+  if (g->owner) shm_unlink(g->name.c_str());
+  delete g;
+  e->shm = nullptr;
+}
+
+extern "C" int dav_comm_init_shm(dav_handle_t e, const char* name) {
+  if (!name || name[0] != '/') return fail("dav_comm_init_shm: name must start with '/'");
+  if (has_comm(e)) return fail("dav_comm_init_shm: the engine already has a transport");
+  if (e->nranks == 1) return 0;
+  // one slot holds the largest message: an all-gathered slab block (nslab x 16) or a small result matrix
+  size_t slot = std::max<size_t>((size_t)e->nslab * 16, std::max(e->gram_doubles, (size_t)e->ncols_pad));
+  size_t bytes = sizeof(ShmHeader) + 64 + sizeof(double) * slot * (size_t)e->nranks;
+  ShmGroup* g = new ShmGroup();
+  g->name = name;
+  g->bytes = bytes;
+  int fd = -1;
+  if (e->rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { delete g; return fail(std::string("dav_comm_init_shm: cannot create ") + name); }
+    g->owner = true;
+  } else {
+    for (int tries = 0; tries < 3000 && fd < 0; ++tries) {       // rank 0 creates it: wait up to 30 s
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd < 0) usleep(10000);
+    }
+    if (fd < 0) { delete g; return fail(std::string("dav_comm_init_shm: cannot open ") + name); }
+    struct stat sb;
+    for (int tries = 0; tries < 3000; ++tries) {                   // ... and sizes it
+      if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+      usleep(10000);
+    }
+  }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { delete g; return fail("dav_comm_init_shm: mmap failed"); }
+  g->hdr = (ShmHeader*)p;
+  g->slots = (double*)((char*)p + ((sizeof(ShmHeader) + 63) / 64) * 64);
+  if (e->rank == 0) {
+    pthread_barrierattr_t attr;
+    pthread_barrierattr_init(&attr);
+    pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(&g->hdr->bar, &attr, (unsigned)e->nranks);
+    pthread_barrierattr_destroy(&attr);
+    g->hdr->slot_doubles = slot;
+    __atomic_store_n(&g->hdr->nranks, e->nranks, __ATOMIC_RELEASE);   // published last
+  } else {
+    for (int tries = 0; tries < 3000 && __atomic_load_n(&g->hdr->nranks, __ATOMIC_ACQUIRE) != e->nranks; ++tries) usleep(10000);
+    if (__atomic_load_n(&g->hdr->nranks, __ATOMIC_ACQUIRE) != e->nranks) { munmap(p, bytes); delete g; return fail("dav_comm_init_shm: rank 0 did not initialise the segment"); }
+  }
+  e->shm = g;
+  pthread_barrier_wait(&g->hdr->bar);
   return 0;
 }
 

@@ -85,6 +85,10 @@ class CEngine:
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self.lib.dav_comm_init(self.h, buf))
 
+    def comm_init_shm(self, name: str):
+        """Test transport for ranks that are processes sharing one GPU (POSIX shared memory `name`)."""
+        self._chk(self.lib.dav_comm_init_shm(self.h, name.encode()))
+
     @staticmethod
     def comm_unique_id() -> bytes:
         lib = hip_lib()

@@ -74,6 +74,10 @@ int dav_comm_init(dav_handle_t h, const void* id128);
 /* Test transport: the n engines (created with rank r of n, same process, same GPU) exchange through
  * device copies and thread barriers instead of RCCL; each rank must then be driven by its own thread. */
 int dav_local_group_join(dav_handle_t* handles, int n);
+/* Second test transport: ranks are PROCESSES sharing one GPU; collectives go through the POSIX shared-memory
+ * segment `name` ("/something", created by rank 0).  Exercises the complete multi-process launch flow
+ * (one engine per process, as under torch.distributed.run) on a single-GPU box. */
+int dav_comm_init_shm(dav_handle_t h, const char* name);
 int dav_synchronize(dav_handle_t h);
 int dav_get_stats(dav_handle_t h, dav_stats* out);
 int dav_reset_stats(dav_handle_t h);
