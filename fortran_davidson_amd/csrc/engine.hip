@@ -344,7 +344,7 @@ static int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int r
   size_t s2 = gram_scratch_doubles(e->cols_alloc, e->cols_alloc, e->nloc_pad);
   e->scratch_doubles = std::max(s1, s2);
   HIPCHK(hipMalloc(&e->scratch, sizeof(double) * e->scratch_doubles));
-  e->gram_doubles = (size_t)e->cols_alloc * e->cols_alloc;
+  e->gram_doubles = 2 * (size_t)e->cols_alloc * e->cols_alloc;      // H and S blocks of one projection side by side
   HIPCHK(hipMalloc(&e->gram_dev, sizeof(double) * e->gram_doubles));
   HIPCHK(hipHostMalloc(&e->gram_host, sizeof(double) * e->gram_doubles, hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&e->gram_host_dev, e->gram_host, 0));
@@ -1065,15 +1065,29 @@ extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh
   int mt = c0 + k;
   CHK(check_panel(e, DAV_PANEL_V, 0, mt));
   if (k <= 0 || ldh < mt) return fail("dav_project: bad shape");
-  for (int pass = 0; pass < 2; ++pass) {
+  const bool both = e->gev && S != nullptr;
+  if (both && lds < mt) return fail("dav_project: bad shape");
+  const size_t blk = (size_t)mt * k;
+  if ((both ? 2 : 1) * blk > e->gram_doubles) return fail("gram result exceeds engine capacity");
+  if (gram_scratch_doubles(mt, k, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
+  // V^T W_new and (generalized) V^T (B V)_new: two Gram launches, ONE reduction/fetch of both blocks
+  int slot;
+  CHK(timed_begin(e, 1, 0, &slot));
+  launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_W, c0), e->ldp, k, e->nloc_pad, e->scratch,
+              result_target(e));
+  if (both)
+    launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_BV, c0), e->ldp, k, e->nloc_pad,
+                e->scratch, result_target(e) + blk);
+  CHK(timed_end(e, slot));
+  if (e->nranks > 1) CHK(need_comm(e));
+  CHK(result_fetch(e, (both ? 2 : 1) * blk));
+  for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
     double* out = pass == 0 ? H : S;
     int64_t ld = pass == 0 ? ldh : lds;
-    if (pass == 1 && (!e->gev || !S)) break;
-    int panel = pass == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
-    CHK(gram_impl(e, panel_ptr(e, DAV_PANEL_V, 0), mt, panel_ptr(e, panel, c0), k));
+    const double* res = e->gram_host + pass * blk;
     for (int j = 0; j < k; ++j)
       for (int i = 0; i < mt; ++i) {
-        double v = e->gram_host[(size_t)j * mt + i];
+        double v = res[(size_t)j * mt + i];
         out[(c0 + j) * ld + i] = v;
         if (i < c0) out[i * ld + (c0 + j)] = v;       // mirror: the projected matrices are symmetric
       }
