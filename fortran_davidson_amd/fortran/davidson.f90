@@ -370,10 +370,20 @@ contains
        ! 3. Rayleigh-Ritz on the host (the only LAPACK call on the path)
        if (allocated(theta)) deallocate(theta, y)
        allocate(theta(m), y(m, m))
-       ! the reference's policy needs every Ritz pair (one correction per basis vector); the opt-in policy
-       ! only the wanted ones plus what a collapse restart keeps
-       nvec = m
-       if (pol == POLICY_UNCONVERGED) nvec = min(m, initial_dimension)
+       ! Does this iteration grow the basis or end in a collapse restart?  (known before the Ritz problem is
+       ! solved: it only depends on the width.)  The reference's policy corrects every Ritz pair, so a growing
+       ! iteration needs all m eigenpairs of the projected problem; a restarting one only the 2*lowest it
+       ! keeps, and the opt-in policy never more than that.
+       if (pol == POLICY_ALL) then
+          expand_now = m <= max_dim
+          ncorr = merge(m, lowest, expand_now)
+       else
+          ! grow while the widest possible block still fits; a basis that has just been (re)started always grows
+          expand_now = (m + lowest <= max_dim) .or. (m <= initial_dimension)
+          ncorr = lowest
+       end if
+       nvec = min(m, initial_dimension)
+       if (pol == POLICY_ALL .and. expand_now) nvec = m
        if (gev) then
           call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, nvec, sm(1:m, 1:m))
        else
@@ -383,14 +393,6 @@ contains
 
        ! 4. Ritz vectors, residues, their norms and the DPR correction - one fused device phase
        phase = meth
-       if (pol == POLICY_ALL) then
-          ncorr = m
-          expand_now = m <= max_dim
-       else
-          ncorr = lowest
-          ! grow while the widest possible block still fits; a basis that has just been (re)started always grows
-          expand_now = (m + lowest <= max_dim) .or. (m <= initial_dimension)
-       end if
        if (.not. expand_now) phase = DAV_METHOD_NONE      ! this iteration ends in a restart: no correction block
        call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), y, &
             int(m, c_int64_t), theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
