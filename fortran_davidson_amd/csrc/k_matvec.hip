@@ -284,11 +284,24 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restri
   f64x2 sum = {0.0, 0.0};
   const double* p = slab + (int64_t)col * nrows_pad + i;
   const int64_t stride = (int64_t)ncol16 * nrows_pad;
-  for (int s = 0; s < nsplit; ++s) {
-    f64x2 v = *reinterpret_cast<const f64x2*>(p + s * stride);
-    sum.x += v.x;
-    sum.y += v.y;
+  // four interleaved partial sums in a fixed order: four 16-byte loads in flight per thread
+  f64x2 part[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f64x2 v = *reinterpret_cast<const f64x2*>(p + (s + u) * stride);
+      part[u].x += v.x;
+      part[u].y += v.y;
+    }
   }
+  for (int u = 0; s < nsplit; ++s, ++u) {
+    f64x2 v = *reinterpret_cast<const f64x2*>(p + s * stride);
+    part[u].x += v.x;
+    part[u].y += v.y;
+  }
+  sum.x = (part[0].x + part[1].x) + (part[2].x + part[3].x);
+  sum.y = (part[0].y + part[1].y) + (part[2].y + part[3].y);
   if (i >= nloc) sum.x = 0.0;
   if (i + 1 >= nloc) sum.y = 0.0;
   *reinterpret_cast<f64x2*>(dst + (int64_t)col * ldd + i) = sum;

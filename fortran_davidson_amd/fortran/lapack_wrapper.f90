@@ -143,11 +143,11 @@ contains
   end subroutine lapack_generalized_eigensolver
 
   !> Rayleigh-Ritz step of the outer loop: the lowest `nvec` eigenpairs of the projected problem (all of
-  !> them when nvec = n).  Small problems take exactly the reference's route (DSYEV / DSYGV,
-  !> lapack_generalized_eigensolver above), so every small case reproduces its numbers.  From n = 96 on the
-  !> host eigensolver becomes the largest non-device cost of an iteration (sequential MKL, n = 800: 170 ms
-  !> DSYEV against a 30 ms sweep of a 160 GB matrix), so: all pairs -> divide and conquer (DSYEVD / DSYGVD,
-  !> 1.7x faster at n >= 256); a leading subset (nvec <= n/2, the opt-in correction policy) -> MRRR on that
+  !> them when nvec = n).  Small problems (n < 48) take exactly the reference's route (DSYEV / DSYGV,
+  !> lapack_generalized_eigensolver above).  Above that the host eigensolver is the largest non-device cost of
+  !> an iteration (sequential MKL on the MI355X host: n = 64: 202 us DSYEV / 152 us DSYEVD, n = 256: 6.2 / 3.8 ms;
+  !> n = 800: 170 ms DSYEV against a 30 ms sweep of a 160 GB matrix), so: all pairs -> divide and conquer
+  !> (DSYEVD / DSYGVD); a leading subset (nvec <= n/2, the opt-in correction policy) -> MRRR on that
   !> subset only (DSYEVR; generalized: Cholesky reduction DPOTRF + DSYGST, back-transformation DTRSM).
   !> Eigenvalues ascending; eigenvectors normalised as DSYEV / DSYGV itype=1 do (y^T stx y = I).
   subroutine lapack_rayleigh_ritz(mtx, eigenvalues, eigenvectors, nvec, stx)
@@ -156,7 +156,7 @@ contains
     integer, intent(in) :: nvec
     real(dp), dimension(size(mtx, 1)), intent(inout) :: eigenvalues
     real(dp), dimension(size(mtx, 1), size(mtx, 2)), intent(inout) :: eigenvectors
-    integer, parameter :: switch_order = 96
+    integer, parameter :: switch_order = 48
     real(dp), allocatable :: a(:, :), b(:, :), z(:, :), w(:), work(:)
     integer, allocatable :: iwork(:), isuppz(:)
     real(dp) :: query(1)

@@ -82,10 +82,10 @@ def test_sort_and_preconditioner():
     assert fd.norm(np.array([3.0, 4.0])) == 5.0
 
 
-@pytest.mark.parametrize("n,nvec", [(40, 40), (40, 6), (96, 96), (150, 150), (150, 20), (300, 64)])
+@pytest.mark.parametrize("n,nvec", [(40, 40), (40, 6), (48, 48), (64, 8), (150, 150), (150, 20), (300, 64)])
 @pytest.mark.parametrize("gev", [False, True])
 def test_rayleigh_ritz_solver_all_routes_against_scipy(n, nvec, gev):
-    """lapack_rayleigh_ritz: DSYEV/DSYGV below order 96 (the reference's route), divide and conquer above,
+    """lapack_rayleigh_ritz: DSYEV/DSYGV below order 48 (the reference's route), divide and conquer above,
     MRRR on a leading subset (Cholesky-reduced when generalized) - same eigenpairs, DSYGV normalisation."""
     import scipy.linalg
     from fortran_davidson_amd.solver import lapack_rayleigh_ritz
