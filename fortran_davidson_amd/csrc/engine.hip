@@ -168,6 +168,7 @@ struct dav_engine {
   ShmGroup* shm = nullptr;        // shared-memory transport (tests of the multi-process launch flow)
   OpDesc op[2];
   std::vector<double> diag_host[2];
+  std::vector<int64_t> basis_order;   // indices of the smallest diagonal entries of A (cache of dav_init_basis)
   // streaming ingest (dav_dense_begin .. dav_dense_end): two pinned row-major staging buffers + device twins
   double* ing_host[2] = {nullptr, nullptr};
   double* ing_dev[2] = {nullptr, nullptr};
@@ -608,6 +609,7 @@ extern "C" int dav_local_group_join(dav_handle_t* handles, int n) {
 
 static int refresh_diag_host(E* e, int which) {
   // global diagonal on the host (stable top-k selection, dav_get_diagonal)
+  if (which == DAV_OP_A) e->basis_order.clear();
   std::vector<double>& d = e->diag_host[which];
   d.assign((size_t)e->n, 0.0);
   if (!has_comm(e)) {
@@ -931,6 +933,7 @@ extern "C" int dav_set_operator_host(dav_handle_t e, int which, const double* di
     HIPCHK(hipMemcpyAsync(o.diag, diag + e->row0, sizeof(double) * e->nloc, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->diag_host[which].assign(diag, diag + e->n);
+  if (which == DAV_OP_A) e->basis_order.clear();
   return 0;
 }
 
@@ -1101,12 +1104,18 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
   if (ncols <= 0 || ncols > e->max_cols || ncols > e->n) return fail("dav_init_basis: bad column count");
   const std::vector<double>& d = e->diag_host[DAV_OP_A];
   if (d.empty()) return fail("dav_init_basis: operator A not set");
-  std::vector<int64_t> order((size_t)e->n);
-  std::iota(order.begin(), order.end(), 0);
-  // stable selection of the ncols smallest diagonal entries (ties -> lower index first)
-  std::partial_sort(order.begin(), order.begin() + ncols, order.end(),
-                    [&](int64_t a, int64_t b) { return d[a] < d[b] || (d[a] == d[b] && a < b); });
-  order.resize(ncols);
+  // stable selection of the ncols smallest diagonal entries (ties -> lower index first); a property of the
+  // resident operator, so it is kept until the diagonal changes (repeated solves on one engine)
+  if ((int)e->basis_order.size() < ncols) {
+    std::vector<int64_t> all((size_t)e->n);
+    std::iota(all.begin(), all.end(), 0);
+    int keep = (int)std::min<int64_t>(e->n, std::max(ncols, e->max_cols));
+    std::partial_sort(all.begin(), all.begin() + keep, all.end(),
+                      [&](int64_t a, int64_t b) { return d[a] < d[b] || (d[a] == d[b] && a < b); });
+    all.resize(keep);
+    e->basis_order.swap(all);
+  }
+  std::vector<int64_t> order(e->basis_order.begin(), e->basis_order.begin() + ncols);
   HIPCHK(hipMemcpyAsync(e->idx_dev, order.data(), sizeof(int64_t) * ncols, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   launch_unit_columns(e->stream, e->idx_dev, ncols, e->row0, e->nloc, e->nloc_pad, panel_ptr(e, DAV_PANEL_V, 0), e->ldp);
