@@ -73,6 +73,10 @@ class CEngine:
     def reset_stats(self):
         self._chk(self.lib.dav_reset_stats(self.h))
 
+    def set_timing(self, level):
+        """0 = no events, 1 = block matvec only (default), 2 = every phase (gram_ms, panel_ms, comm_ms)."""
+        self._chk(self.lib.dav_set_timing(self.h, C.c_int(level)))
+
     def synchronize(self):
         self._chk(self.lib.dav_synchronize(self.h))
 

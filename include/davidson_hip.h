@@ -81,6 +81,10 @@ int dav_comm_init_shm(dav_handle_t h, const char* name);
 int dav_synchronize(dav_handle_t h);
 int dav_get_stats(dav_handle_t h, dav_stats* out);
 int dav_reset_stats(dav_handle_t h);
+/* What dav_get_stats measures with HIP events on the engine's stream: 0 = nothing, 1 (default) = the block
+ * matvec only (apply_ms / apply_bytes: the roofline kernel), 2 = also the Gram, panel and collective phases
+ * (gram_ms, panel_ms, comm_ms; each event pair costs ~5 us of host time per launch group). */
+int dav_set_timing(dav_handle_t h, int level);
 /* rows of this rank: [row0, row0+nloc) */
 int dav_local_rows(dav_handle_t h, int64_t* row0, int64_t* nloc);
 

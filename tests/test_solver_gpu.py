@@ -206,6 +206,7 @@ def test_sharded_code_path_through_rccl_single_rank(golden, monkeypatch):
         case = manifest["dense"][name]
         with fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=case["gev"]) as eng:
             eng.comm_init(fd.CEngine.comm_unique_id())
+            eng.c.set_timing(2)                                   # time the collectives too
             eng.generate_diagonal_dominant(1, case["sparsity"], seed=case["seed_a"])
             if case["gev"]:
                 eng.generate_diagonal_dominant(2, case["sparsity"], 1.0, seed=case["seed_b"])
