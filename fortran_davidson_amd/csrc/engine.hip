@@ -18,6 +18,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -823,7 +824,20 @@ extern "C" int dav_dense_put_rows(dav_handle_t e, int which, int64_t row0, int64
     double* buf; int64_t cap;
     CHK(ingest_acquire(e, &buf, &cap));
     int64_t take = std::min(cap, hi - r);
-    for (int64_t i = 0; i < take; ++i) memcpy(buf + i * e->n, rows + (r - row0 + i) * ldr, sizeof(double) * (size_t)e->n);
+    // staging copy, by several threads when the block is large (one memcpy stream into pinned memory runs at
+    // ~4 GB/s, far below the host-to-device copy that follows)
+    const size_t blk_bytes = sizeof(double) * (size_t)take * (size_t)e->n;
+    const int T = (int)std::min<size_t>(8, blk_bytes / ((size_t)8 << 20) + 1);
+    auto copy_rows = [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; ++i) memcpy(buf + i * e->n, rows + (r - row0 + i) * ldr, sizeof(double) * (size_t)e->n);
+    };
+    if (T <= 1) {
+      copy_rows(0, take);
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < T; ++t) pool.emplace_back(copy_rows, take * t / T, take * (t + 1) / T);
+      for (auto& th : pool) th.join();
+    }
     CHK(ingest_commit(e, r, take));
     r += take;
   }
