@@ -382,6 +382,36 @@ contains
           expand_now = (m + lowest <= max_dim) .or. (m <= initial_dimension)
           ncorr = lowest
        end if
+       ! Convergence usually arrives at the widest basis, exactly where the full Ritz problem is dearest
+       ! (order 64: 150-200 us on the host) although a converged iteration only needs the `lowest` wanted pairs.
+       ! When the previous residues say convergence is near, solve for those pairs first (MRRR on a subset) and
+       ! test them; only if the test fails is the full problem solved.  Same Ritz pairs, same iteration count.
+       if (pol == POLICY_ALL .and. expand_now .and. i > 1 .and. m >= 48 .and. 2 * lowest <= m) then
+          if (maxval(errors) < sqrt(tolerance)) then
+             if (gev) then
+                call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, lowest, sm(1:m, 1:m))
+             else
+                call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, lowest)
+             end if
+             call lap(2)
+             call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(lowest, c_int), int(lowest, c_int), y, &
+                  int(m, c_int64_t), theta, DAV_METHOD_NONE, errors), "dav_ritz_residual_correction")
+             call lap(3)
+             if (sticky) then
+                do j = 1, lowest
+                   if (errors(j) < tolerance) has_converged(j) = .true.
+                end do
+                done = all(has_converged)
+             else
+                done = all(errors < tolerance)
+             end if
+             if (done) then
+                eigenvalues = theta(1:lowest)
+                iters = i
+                exit outer_loop
+             end if
+          end if
+       end if
        nvec = min(m, initial_dimension)
        if (pol == POLICY_ALL .and. expand_now) nvec = m
        if (gev) then
