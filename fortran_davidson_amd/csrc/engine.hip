@@ -1166,8 +1166,23 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
 }
 
 // ---- K3 -----------------------------------------------------------------------------------------
+static int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, const double* theta, int method,
+                     double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg);
+
 extern "C" int dav_ritz_residual_correction_n(dav_handle_t e, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
                                               const double* theta, int method, double* resnorm) {
+  return ritz_impl(e, m, ncorr, lowest, Y, ldy, theta, method, resnorm, nullptr, 0, nullptr, 0);
+}
+
+extern "C" int dav_ritz_residual_correction_g(dav_handle_t e, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
+                                              const double* theta, double* resnorm, double* C, int64_t ldc, double* G,
+                                              int64_t ldg) {
+  if (!C || !G || ldc < m || ldg < ncorr) return fail("dav_ritz_residual_correction_g: bad shape");
+  return ritz_impl(e, m, ncorr, lowest, Y, ldy, theta, DAV_METHOD_DPR, resnorm, C, ldc, G, ldg);
+}
+
+static int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, const double* theta, int method,
+                     double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg) {
   CHK(bind(e));
   if (m <= 0 || lowest <= 0 || lowest > ncorr || ncorr > m || ldy < m) return fail("dav_ritz_residual_correction: bad shape");
   if (method == DAV_METHOD_DPR && m + ncorr > e->cols_alloc) return fail("basis panel too narrow for the correction block");
@@ -1204,10 +1219,29 @@ extern "C" int dav_ritz_residual_correction_n(dav_handle_t e, int m, int ncorr, 
   }
   launch_panel_gemm(e->stream, r);
   launch_norm_finish(e->stream, e->norm_partial, (int)(e->nloc_pad / PG_ROWS), lowest, result_target(e));
+  // optionally the Gram block the first orthonormalisation pass needs, [V T]^T T with T = V[:, m:m+ncorr] just
+  // written: it rides on the same reduction and the same fetch as the norms (one synchronisation less)
+  size_t count = (size_t)lowest;
+  const size_t goff = ((size_t)lowest + 7) / 8 * 8;
+  const int p = m + ncorr;
+  if (C) {
+    if (goff + (size_t)p * ncorr > e->gram_doubles) return fail("gram result exceeds engine capacity");
+    if (gram_scratch_doubles(p, ncorr, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
+    launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, p, panel_ptr(e, DAV_PANEL_V, m), e->ldp, ncorr, e->nloc_pad,
+                e->scratch, result_target(e) + goff);
+    count = goff + (size_t)p * ncorr;
+  }
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
-  CHK(result_fetch(e, (size_t)lowest));
+  CHK(result_fetch(e, count));
   for (int j = 0; j < lowest; ++j) resnorm[j] = std::sqrt(e->gram_host[j]);
+  if (C) {
+    const double* gh = e->gram_host + goff;
+    for (int j = 0; j < ncorr; ++j) {
+      for (int i = 0; i < m; ++i) C[j * ldc + i] = gh[(size_t)j * p + i];
+      for (int i = 0; i < ncorr; ++i) G[j * ldg + i] = gh[(size_t)j * p + m + i];
+    }
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

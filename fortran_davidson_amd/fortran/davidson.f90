@@ -322,7 +322,8 @@ contains
 
     integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr, nvec
     integer(c_int), allocatable :: sel(:)
-    real(dp), allocatable :: theta_sel(:), tols(:)
+    real(dp), allocatable :: theta_sel(:), tols(:), c_pre(:, :), g_pre(:, :)
+    logical :: have_pre
     logical :: expand_now
     integer(c_int64_t) :: ld
     integer(c_int64_t), allocatable :: idx(:)
@@ -424,8 +425,19 @@ contains
        ! 4. Ritz vectors, residues, their norms and the DPR correction - one fused device phase
        phase = meth
        if (.not. expand_now) phase = DAV_METHOD_NONE      ! this iteration ends in a restart: no correction block
-       call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), y, &
-            int(m, c_int64_t), theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
+       have_pre = .false.
+       if (phase == DAV_METHOD_DPR) then
+          ! the Gram blocks of the first orthonormalisation pass come back with the residual norms
+          if (allocated(c_pre)) deallocate(c_pre, g_pre)
+          allocate(c_pre(m, ncorr), g_pre(ncorr, ncorr))
+          call check_dav(dav_ritz_residual_correction_g(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), y, &
+               int(m, c_int64_t), theta, errors, c_pre, int(m, c_int64_t), g_pre, int(ncorr, c_int64_t)), &
+               "dav_ritz_residual_correction")
+          have_pre = .true.
+       else
+          call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), y, &
+               int(m, c_int64_t), theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
+       end if
        call lap(3)
        eigenvalues = theta(1:lowest)
        if (sticky .and. pol == POLICY_ALL) then
@@ -480,9 +492,17 @@ contains
                 call lap(8)
              else
                 call check_dav(dav_panel_select(h, DAV_PANEL_V, int(m, c_int), int(kt, c_int), sel), "dav_panel_select")
+                if (have_pre) then                       ! keep the same columns of the prefetched Gram blocks
+                   c_pre(:, 1:kt) = c_pre(:, sel(1:kt) + 1)
+                   g_pre(1:kt, 1:kt) = g_pre(sel(1:kt) + 1, sel(1:kt) + 1)
+                end if
              end if
           end if
-          call block_orthonormalise(h, n, m, kt)
+          if (have_pre) then
+             call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt))
+          else
+             call block_orthonormalise(h, n, m, kt)
+          end if
           call lap(4)
           ! 6. one block sweep of A over the new columns, then the new rows/columns of H (and S)
           call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
@@ -583,9 +603,11 @@ contains
   !> rounding; a direction that is numerically dependent (e.g. the correction of an already converged
   !> pair) is replaced by a deterministic pseudo-random vector, as Householder QR would complete the
   !> basis with an arbitrary direction.
-  subroutine block_orthonormalise(h, n, m, kt)
+  subroutine block_orthonormalise(h, n, m, kt, c_first, g_first)
     type(c_ptr), intent(in) :: h
     integer, intent(in) :: n, m, kt
+    !> Gram blocks V^T T and T^T T of the block as it stands (first pass), when the caller already has them
+    real(dp), intent(in), optional :: c_first(:, :), g_first(:, :)
     integer, parameter :: max_pass = 6
     real(dp), parameter :: floor_rel = 1.0e-14_dp
     real(dp), allocatable :: c(:, :), g(:, :), gp(:, :), d(:), w(:), u(:, :), mm(:, :), vec(:)
@@ -597,8 +619,13 @@ contains
     allocate(c(max(m, 1), kt), g(kt, kt), gp(kt, kt), d(kt), w(kt), u(kt, kt), mm(kt, kt))
     clean = .false.
     do pass = 1, max_pass
-       call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
-            int(kt, c_int64_t)), "dav_ortho_gram")
+       if (pass == 1 .and. present(c_first)) then
+          if (m > 0) c(1:m, :) = c_first
+          g = g_first
+       else
+          call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
+               int(kt, c_int64_t)), "dav_ortho_gram")
+       end if
        gp = g
        if (m > 0) then
           if (m * kt >= 4096) then

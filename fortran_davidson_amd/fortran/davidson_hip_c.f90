@@ -181,6 +181,16 @@ module davidson_hip_c
        real(c_double), intent(out) :: resnorm(*)
        integer(c_int) :: ierr
      end function
+     function dav_ritz_residual_correction_g(h, m, ncorr, lowest, y, ldy, theta, resnorm, c, ldc, g, ldg) &
+          bind(C, name="dav_ritz_residual_correction_g") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, ncorr, lowest
+       real(c_double), intent(in) :: y(*), theta(*)
+       integer(c_int64_t), value :: ldy, ldc, ldg
+       real(c_double), intent(out) :: resnorm(*), c(*), g(*)
+       integer(c_int) :: ierr
+     end function
      function dav_panel_select(h, panel, c0, nsel, sel) bind(C, name="dav_panel_select") result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: h

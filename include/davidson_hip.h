@@ -173,6 +173,12 @@ int dav_ritz_residual_correction(dav_handle_t h, int m, int lowest, const double
 int dav_ritz_residual_correction_n(dav_handle_t h, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
                                    const double* theta, int method, double* resnorm);
 int dav_panel_select(dav_handle_t h, int panel, int c0, int nsel, const int* sel);
+/* DPR variant of dav_ritz_residual_correction_n that also returns the Gram blocks of the first
+ * orthonormalisation pass, C = V[:, 0:m]^T T (m x ncorr) and G = T^T T (ncorr x ncorr) with T the correction
+ * block just written - what dav_ortho_gram(h, m, ncorr, ...) would return - in the same reduction and the
+ * same fetch as the residual norms: one host-device round trip less per iteration. */
+int dav_ritz_residual_correction_g(dav_handle_t h, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
+                                   const double* theta, double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg);
 /* K7 - replaces compute_GJD_generalized_dense (src/davidson.f90:700-734): solves
  * (I - x x^T)(A - theta_k B)(I - x x^T) t_k = -r_k for all m Ritz pairs at once with a block
  * preconditioned MINRES whose operator is the K1 block matvec; T goes to V[:, m:2m]. */
