@@ -300,6 +300,8 @@ def main():
                      "iterations_per_s": round(it_big / dt, 3), "iters_per_solve": it_big // reps,
                      "ms_per_solve": round(dt / reps * 1e3, 2),
                      "apply_GBps_per_rank": round(sb.apply_bytes / (sb.apply_ms * 1e-3) / 1e9, 1),
+                     "apply_GBps_note": "stored bytes counted once per launch; a launch covers up to 32 columns "
+                                        "(symmetric storage: two paired 16-column groups, MFMA/issue bound)",
                      "apply_k8": {"ms": round(ms8, 3), "GBps_per_rank": round(b8 / (ms8 * 1e-3) / 1e9, 1),
                                   "frac_of_8TBps": round(b8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                   "algorithmic_bytes": b8,

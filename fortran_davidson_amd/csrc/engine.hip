@@ -982,18 +982,26 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
   }
   CHK(need_comm(e));
   if (o.kind == DAV_KIND_DENSE && o.storage == 1) {
-    // symmetric-tiled sweep: 16 columns per pass; every off-diagonal tile read once, used twice
-    for (int c = 0; c < k; c += 16) {
-      int kk = std::min(16, k - c);
-      int ngroups = (kk + 15) / 16;
+    // symmetric-tiled sweep: every off-diagonal tile read once, used twice.  16 columns per workgroup; 32
+    // columns per launch as paired workgroups that share their tile reads through the memory-side cache
+    static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
+    const int step = (pair_env && matvec_sym_can_pair()) ? 32 : 16;
+    const int64_t dstride = (int64_t)e->sym_nitems * 16 * SYM_TB;
+    const int64_t tstride = (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
+    for (int c = 0; c < k; c += step) {
+      int kk = std::min(step, k - c);
+      int npair = (kk + 15) / 16;
       launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
       int slot = -1;
       double bytes = 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) + 16.0 * (double)e->n * kk;
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
-      launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, e->sym_slab + e->sym_slabD_doubles);
+      double* slabT = e->sym_slab + e->sym_slabD_doubles;
+      launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair, e->xt_group_stride,
+                        dstride, tstride);
       if (timed) CHK(timed_end(e, slot));
-      launch_sym_reduce(e->stream, e->sym_slab, e->sym_slab + e->sym_slabD_doubles, e->sym_row_begin, e->sym_nb, ngroups,
-                        e->nloc, kk, dst + (int64_t)c * e->ldp, e->ldp);
+      for (int g = 0; g < npair; ++g)
+        launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, e->sym_nb, 1, e->nloc,
+                          std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
       if (which == DAV_OP_A) {
         e->st.applies += 1;
         e->st.apply_cols += kk;

@@ -217,7 +217,31 @@ constexpr int SYM8_DEPTH = 3;     // half-steps of load lookahead (ring of 4 slo
 
 __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
-                                                             double* __restrict__ slabT, int kcols) {
+                                                             double* __restrict__ slabT, int kcols, int npair,
+                                                             int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
+  // npair = 2: two 16-column groups in ONE launch - workgroups 2i and 2i+1 run the same work item on group 0
+  // and group 1, are dispatched back to back and stream the same tiles at the same pace, so the second read
+  // of a tile is served by the memory-side cache instead of HBM
+  // consecutive workgroups go to consecutive XCDs (8 of them, each with its own L2): the two members of a
+  // pair are 8 apart in the grid, so they land on the same XCD and can share its L2 as well
+  int item, grp;
+  if (npair == 2) {
+    const int nfull = (int)(gridDim.x / 16) * 16;            // whole blocks of 8 pairs
+    if ((int)blockIdx.x < nfull) {
+      item = (blockIdx.x / 16) * 8 + (blockIdx.x % 8);
+      grp = (blockIdx.x / 8) % 2;
+    } else {                                                   // ragged tail: plain interleaving
+      item = nfull / 2 + (blockIdx.x - nfull) / 2;
+      grp = (blockIdx.x - nfull) % 2;
+    }
+  } else {
+    item = blockIdx.x;
+    grp = 0;
+  }
+  xt += grp * xt_gstride;
+  slabD += grp * slabD_gstride;
+  slabT += grp * slabT_gstride;
+  kcols = kcols - 16 * grp < 16 ? kcols - 16 * grp : 16;
   constexpr int TRS = 34;         // padded column stride of the 32-row transposition scratch (272 B)
   constexpr int TRW = 16 * TRS;   // doubles per wave
   constexpr int XT = 258;         // padded column stride of the transposed X_I copy
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
   const int w = wave & 3, h = wave >> 2;
   const int c = lane & 15, g = lane >> 4;
   // work item: (block row, first tile, end tile, slab slot); items are dispatched longest first
-  const int I = items[4 * blockIdx.x], J0 = items[4 * blockIdx.x + 1], J1 = items[4 * blockIdx.x + 2];
+  const int I = items[4 * item], J0 = items[4 * item + 1], J1 = items[4 * item + 2];
 
   for (int e = threadIdx.x; e < SYM_TB * 16; e += 512)
     xsT[(e & 15) * XT + (e >> 4)] = xt[((int64_t)I * SYM_TB + (e >> 4)) * 16 + (e & 15)];
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
   for (; q < nunits; ++q) unit(std::false_type{}, q);
 
   // end of the run: sum the direct partials over the four column groups, one 32-row half-step at a time
-  double* outD = slabD + (int64_t)items[4 * blockIdx.x + 3] * 16 * SYM_TB;
+  double* outD = slabD + (int64_t)items[4 * item + 3] * 16 * SYM_TB;
 #pragma unroll
   for (int hs = 0; hs < 4; ++hs) {
     __syncthreads();
@@ -363,14 +387,19 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
 }
 
 void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev, int nitems, const double* xt, int kcols,
-                       double* slabD, double* slabT) {
-  // one 16-column group per pass; kcols <= 16 of its block columns are in use
-  // DAV_SYM_V8=0 selects the one-wave-per-SIMD kernel (kept for A/B measurements)
+                       double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
+  // kcols <= 16 * npair block columns are in use; npair = 2 runs two 16-column groups as paired workgroups
+  // DAV_SYM_V8=0 selects the one-wave-per-SIMD kernel (kept for A/B measurements; one group per launch)
   static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
   if (v8)
-    hipLaunchKernelGGL(matvec_sym8_kernel, dim3(nitems), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT, kcols);
+    hipLaunchKernelGGL(matvec_sym8_kernel, dim3(nitems * npair), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT, kcols, npair,
+                       xt_gstride, slabD_gstride, slabT_gstride);
   else
     hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, items_dev, xt, slabD, slabT, kcols);
+}
+bool matvec_sym_can_pair() {
+  static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
+  return v8 != 0;
 }
 
 // W[J*256 + r, col] = sum over runs of block row J of slabD + sum over I > J of slabT(I, J), fixed order.
