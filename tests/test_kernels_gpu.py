@@ -271,3 +271,36 @@ def test_dense_matrix_from_device_memory(storage):
         e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
         assert relerr(e.panel_get(PANEL_W, 0, k), A @ X) < RTOL * n
         assert np.array_equal(e.get_diagonal(OP_A), np.diag(A))
+
+
+@pytest.mark.parametrize("env", [{"DAV_SYM_V8": "0"}, {"DAV_SYM_PAIR": "0"}, {"DAV_SYM_RUN": "1"}, {"DAV_SYM_RUN": "7"}])
+def test_symmetric_sweep_alternative_kernels_and_schedules(env):
+    """The A/B knobs of the symmetric sweep (one-wave-per-SIMD kernel, unpaired 16-column launches, other run
+    lengths) are read once per process, so each runs in a child process; same product, bit-reproducible."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np
+import fortran_davidson_amd as fd
+from fortran_davidson_amd.engine_c import OP_A, PANEL_V, PANEL_W, PANEL_S
+for n, k in [(300, 8), (1300, 40), (2500, 64)]:
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((n, n)); A = A + A.T
+    X = rng.standard_normal((n, k))
+    with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
+        e.set_storage(1)
+        e.set_dense_host(OP_A, A)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        W = e.panel_get(PANEL_W, 0, k)
+        ref = A @ X
+        assert np.abs(W - ref).max() <= 1e-12 * n * np.abs(ref).max(), (n, k)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
+        assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
+print("OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(os.environ, PYTHONPATH=root, **env))
+    assert res.returncode == 0 and "OK" in res.stdout, (res.stdout + res.stderr)[-2000:]
