@@ -923,6 +923,10 @@ extern "C" int dav_set_operator_hashed(dav_handle_t e, int which, uint64_t seed,
   CHK(bind(e));
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_HASHED; o.seed = seed; o.sparsity = sparsity; o.use_diag = use_diag_val; o.diag_val = diag_val;
+  // storage mode "symmetric" (single rank) also applies to the generated operator: every entry of the lower
+  // block triangle is produced once and used for both products
+  o.storage = (e->storage == 1 && e->nranks == 1) ? 1 : 0;
+  if (o.storage == 1) CHK(sym_setup(e));
   launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
   CHK(refresh_diag_host(e, which));
   return 0;
@@ -981,8 +985,8 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     return 0;
   }
   CHK(need_comm(e));
-  if (o.kind == DAV_KIND_DENSE && o.storage == 1) {
-    // symmetric-tiled sweep: every off-diagonal tile read once, used twice.  16 columns per workgroup; 32
+  if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED) && o.storage == 1) {
+    // symmetric-tiled sweep: every off-diagonal tile read (or generated) once, used twice.  16 columns per workgroup; 32
     // columns per launch as paired workgroups that share their tile reads through the memory-side cache
     static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
     const int step = (pair_env && matvec_sym_can_pair()) ? 32 : 16;
@@ -993,11 +997,15 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       int npair = (kk + 15) / 16;
       launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
       int slot = -1;
-      double bytes = 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) + 16.0 * (double)e->n * kk;
+      double bytes = (o.kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) : 0.0) + 16.0 * (double)e->n * kk;
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
       double* slabT = e->sym_slab + e->sym_slabD_doubles;
-      launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair, e->xt_group_stride,
-                        dstride, tstride);
+      if (o.kind == DAV_KIND_HASHED)
+        launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
+                                    e->xt_group_stride, dstride, tstride);
+      else
+        launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair, e->xt_group_stride,
+                          dstride, tstride);
       if (timed) CHK(timed_end(e, slot));
       for (int g = 0; g < npair; ++g)
         launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, e->sym_nb, 1, e->nloc,

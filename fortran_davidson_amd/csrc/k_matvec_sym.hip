@@ -215,10 +215,15 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
 // hands its 16 x 16 partial to wave h=0 through LDS (one workgroup barrier per unit, double buffered).
 constexpr int SYM8_DEPTH = 3;     // half-steps of load lookahead (ring of 4 slots)
 
+// GEN = true: the matrix-free variant - the entries of the hashed diagonal-dominant operator (same values as
+// the dense generator) are produced in registers instead of being loaded, ONCE per symmetric pair: half the
+// hash evaluations of the row-slab kernel (matvec_free_kernel), which is what that VALU-bound path is made of.
+template <bool GEN>
 __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
                                                              double* __restrict__ slabT, int kcols, int npair,
-                                                             int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
+                                                             int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride,
+                                                             OpParams op, int64_t n) {
   // npair = 2: two 16-column groups in ONE launch - workgroups 2i and 2i+1 run the same work item on group 0
   // and group 1, are dispatched back to back and stream the same tiles at the same pace, so the second read
   // of a tile is served by the memory-side cache instead of HBM
@@ -272,13 +277,40 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
   double* tw = tr + wave * TRW;
 
   f64x2 ra[4][4];                                   // ring: slot = half-step inside the unit
+  const uint64_t seedmix = op.seed * 0x9E3779B97F4A7C15ull;
+  const double gscale = op.sparsity * (1.0 / 9007199254740992.0);
+  const bool rows_inside = ((int64_t)I + 1) * SYM_TB <= n;       // no ragged rows in this block row
   auto load_hs = [&](int s, f64x2 (&a)[4]) {
     s = s < nsteps ? s : nsteps - 1;
     const int q = s >> 2, hs = s & 3;
     const int J = J0 + (q >> 2), col = (q & 3) * 64 + w * 16;
-    const double* ad = sym_tile(tiles, I, J) + (int64_t)col * SYM_TB + 32 * hs + dlane;
+    if constexpr (GEN) {
+      // lane (c, g): rows gi, gi + 1 of column gj + 4u
+      const int64_t gi = (int64_t)I * SYM_TB + 128 * h + 32 * hs + 2 * c;
+      const int64_t gj = (int64_t)J * SYM_TB + col + g;
+      if (J < I && rows_inside) {
+        // strictly below the diagonal and inside the matrix: lo = column, hi = row, no tests per entry
+        const uint64_t k0 = (uint64_t)gi + seedmix;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
+        for (int u = 0; u < 4; ++u) {
+          const uint64_t kc = ((uint64_t)(gj + 4 * u) << 32) + k0;
+          const uint64_t m0 = dav_splitmix64(kc) >> 11, m1 = dav_splitmix64(kc + 1) >> 11;
+          a[u].x = __builtin_fma((double)(uint32_t)(m0 >> 32), 4294967296.0, (double)(uint32_t)m0) * gscale;
+          a[u].y = __builtin_fma((double)(uint32_t)(m1 >> 32), 4294967296.0, (double)(uint32_t)m1) * gscale;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t cj = gj + 4 * u;
+          a[u].x = (gi < n && cj < n) ? dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, cj) : 0.0;
+          a[u].y = (gi + 1 < n && cj < n) ? dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi + 1, cj) : 0.0;
+        }
+      }
+    } else {
+      const double* ad = sym_tile(tiles, I, J) + (int64_t)col * SYM_TB + 32 * hs + dlane;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
+    }
   };
   auto load_b = [&](int q, double (&b)[4]) {
     q = q < nunits ? q : nunits - 1;
@@ -392,10 +424,16 @@ void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev
   // DAV_SYM_V8=0 selects the one-wave-per-SIMD kernel (kept for A/B measurements; one group per launch)
   static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
   if (v8)
-    hipLaunchKernelGGL(matvec_sym8_kernel, dim3(nitems * npair), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT, kcols, npair,
-                       xt_gstride, slabD_gstride, slabT_gstride);
+    hipLaunchKernelGGL(matvec_sym8_kernel<false>, dim3(nitems * npair), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT, kcols,
+                       npair, xt_gstride, slabD_gstride, slabT_gstride, OpParams{}, (int64_t)0);
   else
     hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, items_dev, xt, slabD, slabT, kcols);
+}
+void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const int* items_dev, int nitems, const double* xt, int kcols,
+                                 double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride,
+                                 int64_t slabT_gstride) {
+  hipLaunchKernelGGL(matvec_sym8_kernel<true>, dim3(nitems * npair), dim3(512), 0, st, (const double*)nullptr, items_dev, xt, slabD,
+                     slabT, kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, op, n);
 }
 bool matvec_sym_can_pair() {
   static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();

@@ -91,6 +91,10 @@ void launch_coldots(hipStream_t st, const DotsArgs& a);
 constexpr int SYM_TB = 256;     // tile edge; tiles (I, J<=I) contiguous, column-major, ld = SYM_TB
 void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev, int nitems, const double* xt, int kcols,
                        double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
+// the same sweep with the entries of the hashed operator generated in registers (no stored matrix)
+void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const int* items_dev, int nitems, const double* xt, int kcols,
+                                 double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride,
+                                 int64_t slabT_gstride);
 bool matvec_sym_can_pair();
 void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, int nb,
                        int ngroups, int64_t nloc, int k, double* dst, int64_t ldd);

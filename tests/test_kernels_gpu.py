@@ -304,3 +304,30 @@ print("OK")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root,
                          env=dict(os.environ, PYTHONPATH=root, **env))
     assert res.returncode == 0 and "OK" in res.stdout, (res.stdout + res.stderr)[-2000:]
+
+
+@pytest.mark.parametrize("n,k", [(50, 3), (256, 16), (700, 8), (1027, 17), (2500, 40)])
+def test_hashed_operator_symmetric_generation_equals_the_dense_generator(n, k):
+    """Matrix-free hashed operator in storage mode "symmetric": every entry of the lower block triangle is
+    generated once and used for both products - same result as the stored matrix with the same entries."""
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=13)
+    Au = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=13)          # unit-diagonal variant (the B operator)
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, k))
+    with fd.CEngine(n=n, max_cols=max(k, 16), gev=True) as e:
+        e.set_storage(1)
+        e.set_operator_hashed(OP_A, 13, 1e-2)
+        e.set_operator_hashed(OP_B, 13, 1e-2, 1.0)
+        assert np.array_equal(e.get_diagonal(OP_A), np.diag(A))
+        e.panel_put(PANEL_V, 0, X)
+        for op, M in ((OP_A, A), (OP_B, Au)):
+            e.apply(op, PANEL_V, 0, k, PANEL_W, 0)
+            W = e.panel_get(PANEL_W, 0, k)
+            ref = M @ X
+            assert np.abs(W - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # and the row-slab generation of the same operator agrees to rounding
+    with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
+        e.set_operator_hashed(OP_A, 13, 1e-2)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        assert np.abs(e.panel_get(PANEL_W, 0, k) - A @ X).max() <= 1e-12 * np.abs(A @ X).max()
