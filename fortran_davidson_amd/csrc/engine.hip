@@ -937,6 +937,8 @@ extern "C" int dav_set_operator_harness(dav_handle_t e, int which, const double*
   CHK(bind(e));
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_HARNESS; o.trig = which == DAV_OP_A ? 0 : 1;
+  o.storage = (e->storage == 1 && e->nranks == 1) ? 1 : 0;      // symmetric mode: each entry generated once
+  if (o.storage == 1) CHK(sym_setup(e));
   if (!o.e_table) HIPCHK(hipMalloc(&o.e_table, sizeof(double) * e->n));
   HIPCHK(hipMemcpyAsync(o.e_table, e_table, sizeof(double) * e->n, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -985,7 +987,7 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     return 0;
   }
   CHK(need_comm(e));
-  if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED) && o.storage == 1) {
+  if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS) && o.storage == 1) {
     // symmetric-tiled sweep: every off-diagonal tile read (or generated) once, used twice.  16 columns per workgroup; 32
     // columns per launch as paired workgroups that share their tile reads through the memory-side cache
     static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
@@ -1000,7 +1002,7 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       double bytes = (o.kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) : 0.0) + 16.0 * (double)e->n * kk;
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
       double* slabT = e->sym_slab + e->sym_slabD_doubles;
-      if (o.kind == DAV_KIND_HASHED)
+      if (o.kind != DAV_KIND_DENSE)
         launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
                                     e->xt_group_stride, dstride, tstride);
       else

@@ -288,7 +288,15 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
       // lane (c, g): rows gi, gi + 1 of column gj + 4u
       const int64_t gi = (int64_t)I * SYM_TB + 128 * h + 32 * hs + 2 * c;
       const int64_t gj = (int64_t)J * SYM_TB + col + g;
-      if (J < I && rows_inside) {
+      if (op.kind == DAV_KIND_HARNESS) {
+        // the reference's test operator (transcendental entries, symmetric by construction)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t cj = gj + 4 * u;
+          a[u].x = (gi < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi, cj) : 0.0;
+          a[u].y = (gi + 1 < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi + 1, cj) : 0.0;
+        }
+      } else if (J < I && rows_inside) {
         // strictly below the diagonal and inside the matrix: lo = column, hi = row, no tests per entry
         const uint64_t k0 = (uint64_t)gi + seedmix;
 #pragma unroll

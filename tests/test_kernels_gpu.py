@@ -52,12 +52,15 @@ def test_block_matvec_dense(n, k):
         assert st.applies >= 1 and st.apply_bytes > 0
 
 
+@pytest.mark.parametrize("storage", [0, 1])
 @pytest.mark.parametrize("kind", ["hashed", "harness"])
-def test_block_matvec_matrix_free(kind):
+def test_block_matvec_matrix_free(kind, storage):
+    """storage 1 = symmetric mode: every entry of the lower block triangle is generated once, used twice."""
     n, k = 300, 9
     rng = np.random.default_rng(5)
     X = rng.standard_normal((n, k))
     with fd.CEngine(n=n, max_cols=16, gev=True) as e:
+        e.set_storage(storage)
         if kind == "hashed":
             e.set_operator_hashed(OP_A, 11, 1e-3)
             e.set_operator_hashed(OP_B, 12, 1e-3, 1.0)
