@@ -37,8 +37,8 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", "--order", dest="n", type=int, default=20000,
                     help="matrix order (use --order under torch.distributed.run, whose parser rejects the prefix --n)")
     ap.add_argument("--lowest", type=int, default=8)
