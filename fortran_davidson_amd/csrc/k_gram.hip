@@ -13,14 +13,28 @@
 template <int PT, int QT>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P, int64_t ldp, int p,
                                                    const double* __restrict__ Q, int64_t ldq, int q,
-                                                   int64_t nrows_pad, int qtiles, double* __restrict__ slab,
-                                                   int ppad, int qpad, int rows_per_wg) {
+                                                   int64_t nrows_pad, int ptiles, int qtiles, int nchunks,
+                                                   double* __restrict__ slab, int ppad, int qpad, int rows_per_wg) {
   __shared__ double red[4][PT * QT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int tp = blockIdx.x / qtiles, tq = blockIdx.x % qtiles;
+  // 1-D grid of ntiles x nchunks workgroups.  Consecutive workgroups go to consecutive XCDs (8, each with its
+  // own L2), so inside a block of 8 row chunks the workgroup index runs over the chunks first: all output
+  // tiles of one row chunk - which re-read the same panel rows - land on ONE XCD and share its L2.
+  const int ntiles = ptiles * qtiles;
+  const int nfull = nchunks / 8 * 8;
+  int tile, chunk;
+  if ((int)blockIdx.x < nfull * ntiles) {
+    chunk = (blockIdx.x / (8 * ntiles)) * 8 + (blockIdx.x % 8);
+    tile = (blockIdx.x / 8) % ntiles;
+  } else {
+    const int r = blockIdx.x - nfull * ntiles;
+    chunk = nfull + r / ntiles;
+    tile = r % ntiles;
+  }
+  const int tp = tile / qtiles, tq = tile % qtiles;
   const int pc0 = tp * 16 * PT, qc0 = tq * 16 * QT;
-  int64_t n0 = (int64_t)blockIdx.y * rows_per_wg + wave * (rows_per_wg / 4);
+  int64_t n0 = (int64_t)chunk * rows_per_wg + wave * (rows_per_wg / 4);
   int64_t n1 = n0 + rows_per_wg / 4;
   if (n1 > nrows_pad) n1 = nrows_pad;
 
@@ -40,11 +54,16 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
     qp[t] = Q + (int64_t)col * ldq + 4 * g;
   }
 
-  f64x4 acc[PT][QT];
+  // NC accumulator chains per output tile so that consecutive MFMAs never depend on each other: a dependent
+  // f64 MFMA issued fewer than ~4 slots behind its producer stalls the matrix pipe
+  constexpr int NC = PT * QT >= 4 ? 1 : (PT * QT == 2 ? 2 : 4);
+  f64x4 acc[PT][QT][NC];
 #pragma unroll
   for (int a = 0; a < PT; ++a)
 #pragma unroll
-    for (int b = 0; b < QT; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < QT; ++b)
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch) acc[a][b][ch] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   for (int64_t n = n0; n < n1; n += 16) {
     f64x2 pf[PT][2], qf[QT][2];
@@ -59,14 +78,15 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
       qf[t][1] = *reinterpret_cast<const f64x2*>(qp[t] + n + 2);
     }
 #pragma unroll
-    for (int a = 0; a < PT; ++a)
+    for (int st = 0; st < 4; ++st)
 #pragma unroll
-      for (int b = 0; b < QT; ++b) {
-        acc[a][b] = mfma_f64(pf[a][0].x, qf[b][0].x, acc[a][b]);
-        acc[a][b] = mfma_f64(pf[a][0].y, qf[b][0].y, acc[a][b]);
-        acc[a][b] = mfma_f64(pf[a][1].x, qf[b][1].x, acc[a][b]);
-        acc[a][b] = mfma_f64(pf[a][1].y, qf[b][1].y, acc[a][b]);
-      }
+      for (int a = 0; a < PT; ++a)
+#pragma unroll
+        for (int b = 0; b < QT; ++b) {
+          const double pa = (st & 1) ? pf[a][st >> 1].y : pf[a][st >> 1].x;
+          const double qb = (st & 1) ? qf[b][st >> 1].y : qf[b][st >> 1].x;
+          acc[a][b][st % NC] = mfma_f64(pa, qb, acc[a][b][st % NC]);
+        }
   }
 
   // cross-wave sum through LDS, then one partial tile per workgroup
@@ -75,9 +95,14 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
 #pragma unroll
     for (int b = 0; b < QT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][((a * QT + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+      for (int r = 0; r < 4; ++r) {
+        double v = acc[a][b][0][r];
+#pragma unroll
+        for (int ch = 1; ch < NC; ++ch) v += acc[a][b][ch][r];
+        red[wave][((a * QT + b) * 4 + r) * 64 + lane] = v;
+      }
   __syncthreads();
-  double* out = slab + (int64_t)blockIdx.y * ppad * qpad;
+  double* out = slab + (int64_t)chunk * ppad * qpad;
   for (int e = threadIdx.x; e < PT * QT * 256; e += 256) {
     double v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
     int l = e & 63, r = (e >> 6) & 3, ab = e >> 8;
@@ -114,30 +139,31 @@ size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
   return (size_t)nchunks * pad16(p) * pad16(q);
 }
 
+template <int PT, int QT>
+static int launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
+                             int64_t nrows_pad, double* scratch, int ppad, int qpad) {
+  const int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
+  // rows per workgroup: as tall as possible (fewer partial tiles) while the grid still fills the chip
+  int rows_per_wg = GRAM_ROWS;
+  while (rows_per_wg > GRAM_MIN_ROWS && (int64_t)ptiles * qtiles * ((nrows_pad + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg /= 2;
+  const int nchunks = (int)((nrows_pad + rows_per_wg - 1) / rows_per_wg);
+  hipLaunchKernelGGL((gram_kernel<PT, QT>), dim3(ptiles * qtiles * nchunks), dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, ptiles,
+                     qtiles, nchunks, scratch, ppad, qpad, rows_per_wg);
+  return nchunks;
+}
+
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
                  int64_t nrows_pad, double* scratch, double* out_dev) {
   int ppad = pad16(p), qpad = pad16(q);
-  // rows per workgroup: as tall as possible (fewer partial tiles) while the grid still fills the chip
-  int64_t tilegroups = (int64_t)((p + 31) / 32) * ((q + 31) / 32);
-  int rows_per_wg = GRAM_ROWS;
-  while (rows_per_wg > GRAM_MIN_ROWS && tilegroups * ((nrows_pad + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg /= 2;
-  int nchunks = (int)((nrows_pad + rows_per_wg - 1) / rows_per_wg);
-  if (p > 16 && q > 16) {
-    constexpr int PT = 2, QT = 2;
-    int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
-    dim3 grid(ptiles * qtiles, nchunks);
-    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad, rows_per_wg);
-  } else if (p > 16) {
-    constexpr int PT = 2, QT = 1;
-    int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
-    dim3 grid(ptiles * qtiles, nchunks);
-    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad, rows_per_wg);
-  } else {
-    constexpr int PT = 1, QT = 1;
-    int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
-    dim3 grid(ptiles * qtiles, nchunks);
-    hipLaunchKernelGGL((gram_kernel<PT, QT>), grid, dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, qtiles, scratch, ppad, qpad, rows_per_wg);
-  }
+  int nchunks;
+  // register tile of a wave: 32 x 32 down to 16 x 16 (a 64 x 64 tile was measured: 430 -> 387 us at
+  // p=256, q=128 on N=200000 but 130 -> 142 us at p=128, q=64 - one wave per SIMD; not kept)
+  if (p > 16 && q > 16)
+    nchunks = launch_gram_tiles<2, 2>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad);
+  else if (p > 16)
+    nchunks = launch_gram_tiles<2, 1>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad);
+  else
+    nchunks = launch_gram_tiles<1, 1>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad);
   int total = p * q;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, nchunks, p, q, ppad, qpad, out_dev);
 }
