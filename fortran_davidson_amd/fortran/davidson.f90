@@ -456,26 +456,31 @@ contains
        if (expand_now) then
           ! 5. correction block T -> orthonormalise against V and itself -> new basis columns
           if (pol == POLICY_ALL) then
-             kt = m                                      ! one correction per basis vector (the reference)
+             ! one correction per basis vector (the reference) - but never more columns than the space has
+             ! left: with m + kt > n the reference stops in DORGQR (src/lapack_wrapper.f90:176-236); here the
+             ! leading n - m corrections complete the basis and the next Ritz problem is exact
+             kt = min(m, n - m)
+             if (kt <= 0) exit outer_loop                ! V already spans everything (unreachable: exact Ritz pairs converge)
              if (meth == DAV_METHOD_GJD) then
                 ! the wanted pairs are solved to 1e-10 (what makes the outer iteration count equal to the
                 ! reference's exact solves); the other m - lowest corrections only enrich the basis
                 if (allocated(tols)) deallocate(tols)
-                allocate(tols(m))
+                allocate(tols(kt))
                 tols = gjd_tol_unwanted()
-                tols(1:lowest) = 1.0e-10_dp
-                call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(m, c_int), theta, 300_c_int, 1.0e-10_dp, &
+                tols(1:min(lowest, kt)) = 1.0e-10_dp
+                call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), theta, 300_c_int, 1.0e-10_dp, &
                      tols, inner), "dav_gjd_correction")
                 call lap(8)
              end if
           else
              ! only the wanted pairs that have not converged: keep their columns, drop the others
-             kt = count(errors >= tolerance)
+             kt = min(count(errors >= tolerance), n - m)
+             if (kt <= 0) exit outer_loop
              if (allocated(sel)) deallocate(sel, theta_sel)
              allocate(sel(kt), theta_sel(kt))
              kt = 0
              do j = 1, lowest
-                if (errors(j) >= tolerance) then
+                if (errors(j) >= tolerance .and. kt < size(sel)) then
                    kt = kt + 1
                    sel(kt) = int(j - 1, c_int)
                    theta_sel(kt) = theta(j)

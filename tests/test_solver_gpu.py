@@ -353,3 +353,20 @@ def test_engine_that_does_not_fit_fails_with_a_message_and_releases_memory():
     assert free1 > free0 - (1 << 30)
     lam, _, it = fd.generalized_eigensolver(O.generate_diagonal_dominant(64, 1e-2, seed=1), 2, "DPR", 50, 1e-8)
     assert it <= 50 and np.isfinite(lam).all()
+
+
+@pytest.mark.parametrize("n,L,method", [(10, 3, "DPR"), (10, 3, "GJD"), (7, 2, "GJD"), (9, 4, "DPR"), (20, 10, "DPR"), (6, 3, "DPR"),
+                                        (13, 5, "GJD")])
+@pytest.mark.parametrize("policy", ["all", "unconverged"])
+def test_basis_never_outgrows_the_space(n, L, method, policy, monkeypatch):
+    """Tiny orders where doubling the basis would need more columns than the space has: the reference stops
+    with an illegal-argument error in DORGQR (src/lapack_wrapper.f90:176-236); the engine completes the basis
+    with the leading corrections, after which the Ritz problem is exact.  Checked against LAPACK."""
+    if policy != "all":
+        monkeypatch.setenv("DAVIDSON_CORRECTION_POLICY", policy)
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=2)
+    lam, vec, it = fd.generalized_eigensolver(A, L, method, 50, 1e-8)
+    ref = np.linalg.eigvalsh(A)[:L]
+    assert it <= 50
+    assert np.abs(lam - ref).max() < EV_TOL
+    assert (residuals(A, None, lam, vec) < 1e-8).all()
