@@ -370,3 +370,42 @@ def test_basis_never_outgrows_the_space(n, L, method, policy, monkeypatch):
     assert it <= 50
     assert np.abs(lam - ref).max() < EV_TOL
     assert (residuals(A, None, lam, vec) < 1e-8).all()
+
+
+def _weird_cases():
+    n = 300
+    rng = np.random.default_rng(0)
+    cases = {"diagonal": (np.diag(np.arange(1.0, n + 1)), 4, "DPR", 60, 1e-8),
+             "zero": (np.zeros((n, n)), 3, "DPR", 5, 1e-8),
+             "identity": (np.eye(n), 3, "DPR", 5, 1e-8)}
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=5)
+    d = np.arange(1.0, n + 1); d[:6] = 1.0
+    A[np.arange(n), np.arange(n)] = d
+    cases["degenerate_dpr"] = (A, 4, "DPR", 60, 1e-8)
+    cases["degenerate_gjd"] = (A, 4, "GJD", 60, 1e-8)
+    cases["negative_definite"] = (-O.generate_diagonal_dominant(n, 1e-2, seed=6), 3, "DPR", 60, 1e-8)
+    base = O.generate_diagonal_dominant(n, 1e-3, seed=7)
+    cases["max_it_1"] = (base, 3, "DPR", 1, 1e-8)
+    cases["tol_1e-13"] = (base, 3, "DPR", 60, 1e-13)
+    cases["tol_1e-2"] = (base, 3, "DPR", 60, 1e-2)
+    cases["scaled_1e8_unreachable_tolerance"] = (1e8 * base, 3, "DPR", 20, 1e-8)
+    cases["scaled_1e-8"] = (1e-8 * base, 3, "DPR", 60, 1e-8)
+    G = rng.standard_normal((n, n))
+    cases["gaussian_dpr_not_converging"] = ((G + G.T) / 2, 3, "DPR", 12, 1e-8)
+    return cases
+
+
+@pytest.mark.parametrize("name", sorted(_weird_cases()))
+def test_unusual_inputs_behave_like_the_reference_statement(name):
+    """Degenerate, indefinite, badly scaled and non-converging inputs: same iteration count and the same Ritz
+    values as the oracle (which states the reference), including what is returned when nothing converges."""
+    A, L, method, max_it, tol = _weird_cases()[name]
+    lam_o, _, it_o = O.generalized_eigensolver_dense(A, L, method, max_it, tol)
+    lam, vec, it = fd.generalized_eigensolver(A, L, method, max_it, tol)
+    assert it == it_o
+    scale = max(1.0, np.abs(lam_o).max())
+    # not converged: two floating-point orderings of a wandering iteration drift apart, only roughly equal
+    assert np.abs(lam - lam_o).max() < (1e-6 if it <= max_it else 1e-2) * scale
+    if it <= max_it:                                        # converged: the bar of BASELINE.json
+        assert np.abs(lam - lam_o).max() < EV_TOL * scale
+        assert (residuals(A, None, lam, vec) < max(tol, 1e-13 * scale)).all()
