@@ -409,3 +409,36 @@ def test_unusual_inputs_behave_like_the_reference_statement(name):
     if it <= max_it:                                        # converged: the bar of BASELINE.json
         assert np.abs(lam - lam_o).max() < EV_TOL * scale
         assert (residuals(A, None, lam, vec) < max(tol, 1e-13 * scale)).all()
+
+
+@pytest.mark.parametrize("n,L,nranks,method,gev", [(20, 2, 3, "DPR", False), (20, 2, 4, "GJD", False), (50, 3, 4, "DPR", True),
+                                                   (33, 1, 2, "DPR", False), (17, 2, 2, "GJD", True)])
+def test_row_slabs_smaller_than_a_tile_and_empty_slabs(n, L, nranks, method, gev):
+    """More ranks than 16-row slabs: trailing ranks own one row or none at all and still take part in every
+    collective; same eigenpairs and iteration count as the single-rank solve."""
+    import ctypes as C
+    import threading
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=3)
+    B = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=4) if gev else None
+    lam1, vec1, it1 = fd.generalized_eigensolver(A, L, method, 60, 1e-8, None, B)
+    engs = [fd.DavidsonEngine(n, L, None, gev=gev, rank=r, nranks=nranks) for r in range(nranks)]
+    handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+    assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    assert sum(e.c.local_rows()[1] for e in engs) == n and engs[-1].c.local_rows()[1] < 16
+    out = [None] * nranks
+
+    def work(r):
+        engs[r].set_dense(1, A)
+        if gev:
+            engs[r].set_dense(2, B)
+        out[r] = engs[r].solve(method, 60, 1e-8)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in threads]
+    [t.join(timeout=120) for t in threads]
+    assert all(o is not None for o in out), "a rank did not finish"
+    for lam, vec, it in out:
+        assert it == it1 and np.abs(lam - lam1).max() < 1e-12
+        assert np.abs(np.abs(vec) - np.abs(vec1)).max() < 1e-10
+    for e in engs:
+        e.close()
