@@ -24,7 +24,7 @@ module davidson_device
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
-       engine_set_identity, engine_comm_unique_id, engine_comm_init, &
+       engine_set_identity, engine_comm_unique_id, engine_comm_init, engine_comm_init_shm, &
        generalized_eigensolver_device, davidson_device_loop, basis_capacity
 
   !> Handle of a device-resident problem: operators A (and B) plus all work panels in HBM.
@@ -123,6 +123,14 @@ contains
     character(kind=c_char), intent(out) :: id(128)
     call check_dav(dav_comm_unique_id(id), "dav_comm_unique_id")
   end subroutine engine_comm_unique_id
+
+  !> Test transport for ranks that are PROCESSES sharing one GPU: collectives through the POSIX shared-memory
+  !> segment `name` ("/something"; rank 0 creates it).  The multi-GPU data path is engine_comm_init (RCCL).
+  subroutine engine_comm_init_shm(eng, name)
+    type(davidson_engine), intent(inout) :: eng
+    character(len=*), intent(in) :: name
+    call check_dav(dav_comm_init_shm(eng%h, trim(name) // c_null_char), "dav_comm_init_shm")
+  end subroutine engine_comm_init_shm
 
   subroutine engine_comm_init(eng, id)
     type(davidson_engine), intent(inout) :: eng

@@ -39,6 +39,12 @@ module davidson_hip_c
        character(kind=c_char), intent(out) :: id(128)
        integer(c_int) :: ierr
      end function
+     function dav_comm_init_shm(h, name) bind(C, name="dav_comm_init_shm") result(ierr)
+       import :: c_ptr, c_int, c_char
+       type(c_ptr), value :: h
+       character(kind=c_char), intent(in) :: name(*)
+       integer(c_int) :: ierr
+     end function
      function dav_comm_init(h, id) bind(C, name="dav_comm_init") result(ierr)
        import :: c_ptr, c_char, c_int
        type(c_ptr), value :: h

@@ -39,6 +39,12 @@ def build_programs(tmp_path):
     return dense, free
 
 
+def build_ranks_program(tmp_path):
+    bindir = os.path.join(SRC, "_bin")
+    os.makedirs(bindir, exist_ok=True)
+    return compile_link([os.path.join(SRC, "prog_ranks.f90")], os.path.join(bindir, "prog_ranks"), tmp_path)
+
+
 def build_ingest_program(tmp_path):
     bindir = os.path.join(SRC, "_bin")
     os.makedirs(bindir, exist_ok=True)
@@ -52,6 +58,7 @@ def test_user_programs_compile_and_link(tmp_path):
     dense, free = build_programs(tmp_path)
     assert os.path.exists(dense) and os.path.exists(free)
     assert os.path.exists(build_ingest_program(tmp_path))
+    assert os.path.exists(build_ranks_program(tmp_path))
 
 
 @needs_flang
@@ -113,3 +120,32 @@ def test_ingest_program_runs_on_gpu(tmp_path):
     assert res.returncode == 0, out
     checks = re.findall(r"CHECK (\S+) ([TF])", out)
     assert len(checks) == 4 * 6 and all(v == "T" for _, v in checks), out
+
+
+@needs_flang
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_multi_rank_fortran_program(tmp_path, nranks):
+    """One Fortran process per rank (engine_create(rank, nranks) + engine_comm_init_shm + the generic), the ranks
+    sharing this box's GPU: every rank returns the full eigenvectors, rank 0 also checks them against its own
+    single-rank solve."""
+    exe = build_ranks_program(tmp_path)
+    tag = f"dav_prog_ranks_{os.getpid()}_{nranks}"
+    procs = [subprocess.Popen([exe, str(r), str(nranks), tag], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              cwd=tmp_path) for r in range(nranks)]
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    evals = []
+    for r, (pr, out) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0, out[-2000:]
+        checks = re.findall(r"CHECK (\S+) ([TF])", out)
+        assert len(checks) == (6 if r == 0 else 4) and all(v == "T" for _, v in checks), out
+        evals.append([float(x) for x in re.search(r"EVALS(.*)", out).group(1).split()])
+    assert all(e == evals[0] for e in evals)            # same bits on every rank
