@@ -32,7 +32,9 @@
 // registers as the LDS scheme and twice the TA work); interleaving the dependent transposed MFMAs with the
 // direct ones (9 % slower); two 16-column groups per pass (slower than two passes); producing the Gram
 // operand one step ahead with sched_group_barrier (same speed); summing the waves once per 128 columns
-// (1 %); runs of 4..14 tiles per workgroup (within 2 %; a workgroup costs ~7 us to start and drain).
+// (1 %); runs of 4..14 tiles per workgroup (within 2 %; a workgroup costs ~7 us to start and drain); on the
+// 8-wave kernel: fp64 atomics into W instead of the slabs and the reduction kernel (not reproducible; N=60000,
+// k=16: 3.07 -> 2.80 ms, but N=200000, k=8: 29.9 -> 29.5 ms and the paired 32-column launches 4 % slower).
 // Counters (profiles/r01_pmc_mfma_clock_n40000.json, v5, N=40000): matrix pipe 43 % busy at 2.34 GHz, HBM
 // fetch = tile bytes.  Traffic per sweep: the stored half matrix once, plus 1/16 of it written as per-tile
 // Z slabs and read back by the reduction kernel (8 % of the sweep time) - the price of a deterministic sum.
