@@ -34,6 +34,14 @@ def hip_lib() -> C.CDLL:
         if not os.path.exists(HIP_LIB):
             raise NativeLibraryMissing(f"{HIP_LIB} not built: run `make -C fortran_davidson_amd` "
                                        "(there is no CPU fallback)")
+        # One HIP runtime per process.  PyTorch ships its own libamdhip64.so.7 and asks the loader for it by
+        # file name, so if the system copy is already in the process (brought in by this library) a later
+        # `import torch` loads a second runtime, which then reports "No HIP GPUs are available".  With torch
+        # imported first both share torch's copy (same soname).  Pure Fortran hosts never meet this.
+        try:
+            import torch  # noqa: F401
+        except Exception:      # noqa: BLE001 - harness without PyTorch
+            pass
         _hip = C.CDLL(HIP_LIB, mode=C.RTLD_LOCAL)
         _hip.dav_last_error.restype = C.c_char_p
     return _hip
