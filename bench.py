@@ -4,19 +4,26 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one complete `generalized_eigensolver` solve (Fortran driver loop on the HIP engine) of
-the workload BASELINE.json quotes the metric on that fits one GPU: configs[1] = N=20000 dense fp64,
-lowest=8, DPR, tol=1e-8, generate_diagonal_dominant(N, 1e-3) - the matrix is generated in HBM before
-the timed region and stays resident.  value = Davidson iterations per second over the K timed solves.
-N > 1: the same problem row-partitioned over the ranks (strong scaling), new-basis block exchanged with
-an RCCL all-gather inside libdavidson_hip.so; torch.distributed (gloo) is only the control plane
-(unique-id broadcast, barriers, max-over-ranks of the time).
+A "step" is one complete `generalized_eigensolver` solve (Fortran driver loop on the HIP engine) of the
+largest BASELINE.json configuration that fits one GPU: configs[2] = N=200000 dense fp64, lowest=16, DPR,
+subspace restart at 80 (max_dim_sub=80), tol=1e-8, generate_diagonal_dominant(N, 1e-3).  The matrix is
+generated in HBM before the timed region and stays resident: one GPU keeps its lower block triangle
+(symmetric-tiled storage, 160 GB), several GPUs keep full row slabs (N*N/P entries each) and exchange the
+new basis block with an RCCL all-gather inside libdavidson_hip.so; torch.distributed (gloo) is only the
+control plane (unique-id broadcast, barriers, max-over-ranks of the time).  value = Davidson iterations
+per second over the K timed solves (strong scaling: the problem is the same for every N).
 
-Extra objects in the JSON line: `roofline` (dominant kernel = dense block matvec, HIP-event timed on
-the engine's stream inside the timed region), `cpu_baseline` (the reference itself, oracle/_ref, on
-the host cores in a child process), `apply_k8` (the north-star microbenchmark: A*V at k=8) and
-`large` (configs[2]: N=200000, lowest=16, restart at 80 - symmetric-tiled storage on one GPU, full row
-slabs on several).
+Objects in the JSON line besides the contract's fields:
+  roofline       the dominant kernel of the timed region (the block matvec as the solve launches it: 32
+                 columns per launch - bound by the fp64 matrix pipe), HIP-event timed inside the solves
+  roofline_hbm   the north-star measurement: A*V at N=200000, k=8 on the same resident matrix, END TO END
+                 (operand packing + sweep kernel + fixed-order reduction) and the sweep kernel alone
+  apply          the same for k = 8, 16, 32
+  configs3_gjd   BASELINE configs[3]: N=200000 generalized (A, B), GJD correction, lowest=8
+  configs4_free  BASELINE configs[4]: matrix-free hashed diagonal-dominant operator, lowest=8, DPR
+  small          BASELINE configs[1]: N=20000 dense, lowest=8, DPR (full storage)
+  dropin         the reference-signature dense call (host matrix in, upload through PCIe included)
+  cpu_baseline   the reference itself (oracle/_ref: flang + MKL build) on the host cores, N=20000 sample
 """
 from __future__ import annotations
 
@@ -25,6 +32,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,23 +40,31 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+FP64_MFMA_PEAK_TFLOPS = 78.6    # 256 CUs x 4 SIMDs x (16x16x4 MACs / 64 cycles) x 2 x 2.4 GHz (measured: 64.0 cycles per
+                                # v_mfma_f64_16x16x4_f64, 16.3 per v_mfma_f64_4x4x4_4b_f64 - profiles/ubench)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", "--order", dest="n", type=int, default=20000,
-                    help="matrix order (use --order under torch.distributed.run, whose parser rejects the prefix --n)")
-    ap.add_argument("--lowest", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", "--order", dest="n", type=int, default=200000,
+                    help="order of the timed workload (use --order under torch.distributed.run, whose parser rejects --n)")
+    ap.add_argument("--lowest", type=int, default=16)
+    ap.add_argument("--max-dim", type=int, default=80)
     ap.add_argument("--sparsity", type=float, default=1e-3)
     ap.add_argument("--tol", type=float, default=1e-8)
-    ap.add_argument("--large-n", type=int, default=200000, help="order of the configs[2] solve (0 = skip)")
+    ap.add_argument("--storage", default="auto", help="auto = symmetric tiles on one GPU, full row slabs on several")
+    ap.add_argument("--small-n", type=int, default=20000, help="order of the configs[1] leg (0 = skip)")
+    ap.add_argument("--gjd-n", type=int, default=-1, help="order of the configs[3] leg (-1 = same as --order, 0 = skip)")
+    ap.add_argument("--free-n", type=int, default=1000000, help="order of the configs[4] leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed workload and its roofline objects")
     ap.add_argument("--control-plane-only", action="store_true",
                     help="exercise the launch plumbing (rendezvous, id broadcast, barrier, max over ranks) without a GPU")
-    ap.add_argument("--cpu-n", type=int, default=0, help="order for the CPU baseline (0 = same as --n)")
+    ap.add_argument("--cpu-n", type=int, default=0, help="order for the CPU baseline (0 = same as --small-n)")
     return ap.parse_args()
 
 
@@ -76,18 +92,13 @@ print("CPU_BASELINE " + json.dumps(out))
 """
 
 
-def cpu_baseline(n, lowest, sparsity, tol):
-    """The reference's own CPU+LAPACK path (oracle/_ref = the reference compiled with flang + MKL) on
-    the same generate_diagonal_dominant input, timed in a child process that never touches the GPU,
-    never imports torch (its libgomp breaks threaded MKL) and never loads the product libraries
-    (they pin MKL to its sequential layer).  The input is written by the host-side Fortran generator
-    of the product (bit-identical to the device generator) to a scratch file."""
-    import tempfile
-    import numpy as np
-    import fortran_davidson_amd as fd
-    path = os.path.join(tempfile.gettempdir(), f"davidson_cpu_baseline_{os.getpid()}.npy")
+def cpu_baseline(path, lowest, tol):
+    """The reference's own CPU+LAPACK path (oracle/_ref = the reference compiled with flang + MKL) on a
+    generate_diagonal_dominant input, timed in a child process that never touches the GPU, never imports
+    torch (its libgomp breaks threaded MKL) and never loads the product libraries (they pin MKL to its
+    sequential layer).  The input was written by the host-side Fortran generator of the product
+    (bit-identical to the device generator) to the scratch file `path`."""
     try:
-        np.save(path, fd.generate_diagonal_dominant(n, sparsity, None, 1))
         code = CPU_CHILD.format(root=ROOT, lowest=lowest, tol=tol, path=path)
         env = dict(os.environ)
         env["HIP_VISIBLE_DEVICES"] = ""
@@ -98,21 +109,19 @@ def cpu_baseline(n, lowest, sparsity, tol):
         return {"error": (res.stderr or res.stdout)[-400:]}
     except Exception as exc:       # noqa: BLE001
         return {"error": repr(exc)}
-    finally:
-        if os.path.exists(path):
-            os.remove(path)
 
 
-def pmc_traffic(n):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/), which
-    was collected with rocprofv3 on this same command; None when no summary matches the workload."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_n{n}.json")
+def pmc_traffic(n, storage):
+    """HBM bytes per launch of the roofline kernel from a rocprofv3 PMC summary under profiles/ - an OFFLINE
+    figure (counters cannot be read from inside the run): collected with `rocprofv3 --pmc` on this command
+    at the commit the file names.  None when no summary matches the workload."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_n{n}_{storage}.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"]
-        vals = [k[name]["hbm_bytes_per_launch_corrected"] for name in ("matvec_dense_kernel<1>", "matvec_dense_kernel<2>")
-                if name in k]
-        return round(sum(vals) / len(vals), 0) if vals else None
+            doc = json.load(f)
+        return {"bytes_per_launch": doc["hbm_bytes_per_launch_corrected"], "kernel": doc.get("kernel"),
+                "source": os.path.relpath(path, ROOT), "collected_at_commit": doc.get("commit"),
+                "note": "offline rocprofv3 --pmc pass (2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), not measured in this run"}
     except Exception:      # noqa: BLE001
         return None
 
@@ -161,8 +170,8 @@ def main():
     import fortran_davidson_amd as fd
     engines_made = [0]
 
-    def make_engine(n, lowest, max_dim=None, storage="full"):
-        eng = fd.DavidsonEngine(n, lowest, max_dim, gev=False, device=device, rank=rank, nranks=world, storage=storage)
+    def make_engine(n, lowest, max_dim=None, storage="full", gev=False):
+        eng = fd.DavidsonEngine(n, lowest, max_dim, gev=gev, device=device, rank=rank, nranks=world, storage=storage)
         if world > 1:
             engines_made[0] += 1
             if transport == "shm":
@@ -187,164 +196,236 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- the timed workload: configs[1] -----------------------------------------------------------
-    n, lowest = args.n, args.lowest
-    eng = make_engine(n, lowest)
+    def timed_solves(eng, method, reps, tol):
+        """reps solves bracketed by barrier + synchronize on both sides; max over ranks of the wall time"""
+        eng.c.synchronize(); barrier()
+        t0 = time.perf_counter()
+        its = 0
+        lam = None
+        for _ in range(reps):
+            lam, _, it = eng.solve(method, 1000, tol, want_vectors=False)
+            its += it
+        eng.c.synchronize(); barrier()
+        return max_over_ranks(time.perf_counter() - t0), its, lam
+
+    def apply_rooflines(eng, ks, reps):
+        out = {}
+        for k in ks:
+            ms, kms, nbytes, flops = eng.c.bench_apply2(k, reps)
+            out[f"k{k}"] = {"ms_end_to_end": round(ms, 4), "ms_kernel_only": round(kms, 4),
+                            "GBps_end_to_end": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                            "GBps_kernel_only": round(nbytes / (kms * 1e-3) / 1e9, 1),
+                            "frac_of_8TBps_end_to_end": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "frac_of_8TBps_kernel_only": round(nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "TFLOPs_kernel_only": round(flops / (kms * 1e-3) / 1e12, 2),
+                            "algorithmic_bytes": nbytes}
+        return out
+
+    storage = args.storage if args.storage != "auto" else ("symmetric" if world == 1 else "full")
+    storage_words = {"symmetric": "symmetric-tiled (lower block triangle, N(N+1)/2 entries)", "full": "full row slabs"}[storage]
+
+    # ---- the timed workload: configs[2] ---------------------------------------------------------------
+    n, lowest, max_dim = args.n, args.lowest, args.max_dim
+    eng = make_engine(n, lowest, max_dim, storage)
+    t_gen = time.perf_counter()
     eng.generate_diagonal_dominant(1, args.sparsity, seed=1)       # resident in HBM before timing
+    eng.c.synchronize()
+    t_gen = time.perf_counter() - t_gen
     for _ in range(args.warmup):
-        lam, _, iters = eng.solve("DPR", 1000, args.tol, want_vectors=False)
+        eng.solve("DPR", 1000, args.tol, want_vectors=False)
     eng.c.synchronize()
     eng.c.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    total_iters = 0
-    for _ in range(args.steps):
-        lam, _, iters = eng.solve("DPR", 1000, args.tol, want_vectors=False)
-        total_iters += iters
-    eng.c.synchronize()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed, total_iters, lam = timed_solves(eng, "DPR", args.steps, args.tol)
     st = eng.c.stats()
     value = total_iters / elapsed
 
-    # roofline of the dominant kernel over the timed region (HIP events on the engine's stream)
-    ach = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "matvec_dense_kernel<NT> (A*V block matvec, full storage)",
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": pmc_traffic(n) if world == 1 else None, "launches": int(st.applies), "avg_launch_ms": round(st.apply_ms / max(st.applies, 1), 4),
-                "algorithmic_bytes_per_launch": round(st.apply_bytes / max(st.applies, 1), 0),
-                "note": "per-rank; bytes = 8*nloc*N + 16*N*k per launch (SURVEY 8d)"}
-    # device time by phase: a separate, untimed pass with every phase bracketed by events (the timed region
-    # above only brackets the block matvec - an event pair costs ~5 us of host time per launch group)
-    eng.c.set_timing(2)
-    eng.c.reset_stats()
-    nph = min(args.steps, 5)
-    for _ in range(nph):
-        eng.solve("DPR", 1000, args.tol, want_vectors=False)
-    eng.c.synchronize()
-    sp = eng.c.stats()
-    phase = {"apply_ms": round(sp.apply_ms / nph, 4), "gram_ms": round(sp.gram_ms / nph, 4),
-             "panel_ms": round(sp.panel_ms / nph, 4), "comm_ms": round(sp.comm_ms / nph, 4)}
-    eng.c.set_timing(1)
+    # roofline of the dominant kernel over the timed region (HIP events on the engine's stream, inside the solves)
+    launches = max(int(st.apply_launches), 1)
+    kms = st.apply_kernel_ms / launches
+    tflops = st.apply_flops / (st.apply_kernel_ms * 1e-3) / 1e12 if st.apply_kernel_ms > 0 else 0.0
+    cols_per_launch = st.apply_cols / launches
+    kernel_name = "matvec_sym8_kernel<false> (K1s: symmetric-tiled sweep)" if storage == "symmetric" else "matvec_dense_kernel<NT> (K1: row slab)"
+    hbm_in_solve = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
+    mfma_bound = cols_per_launch > 16
+    roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kernel_name,
+                "achieved": round(tflops, 2) if mfma_bound else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9, 1),
+                "peak": FP64_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBPS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound
+                        else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "traffic": pmc_traffic(n, storage) if world == 1 else None,
+                "launches": launches, "avg_launch_ms": round(kms, 4), "columns_per_launch": round(cols_per_launch, 1),
+                "flops_per_launch": round(st.apply_flops / launches, 0),
+                "algorithmic_bytes_per_launch": round(st.apply_bytes / max(st.applies, 1) , 0),
+                "apply_ms_end_to_end_per_solve": round(st.apply_ms / args.steps, 3),
+                "apply_ms_kernel_only_per_solve": round(st.apply_kernel_ms / args.steps, 3),
+                "in_solve_GBps_end_to_end": round(hbm_in_solve, 1),
+                "note": "per rank, measured over the timed solves.  In-solve launches carry 32 columns (the reference's policy "
+                        "corrects every basis vector): 2*N*N*k flops against 8*S bytes is above the fp64 ridge, so this kernel "
+                        "is priced against the fp64 matrix peak; the HBM-bound case (k=8) is roofline_hbm"}
 
-    # north-star microbenchmark: A*V at k=8 (and 16, 32) on the resident matrix
-    apply_k = {}
-    for k in (8, 16, 32):
-        ms, nbytes = eng.c.bench_apply(k, 20)
-        apply_k[f"k{k}"] = {"ms": round(ms, 4), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                            "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
-    # opt-in correction policy (not the reference's, so never part of `value`): same workload,
-    # corrections only for the wanted pairs that have not converged
-    eng.set_correction_policy("unconverged")
-    eng.solve("DPR", 1000, args.tol, want_vectors=False)
-    eng.c.synchronize(); barrier()
-    t2 = time.perf_counter()
-    it_pol = 0
-    for _ in range(args.steps):
-        lam_pol, _, it = eng.solve("DPR", 1000, args.tol, want_vectors=False)
-        it_pol += it
-    eng.c.synchronize(); barrier()
-    dt_pol = max_over_ranks(time.perf_counter() - t2)
-    opt_in = {"policy": "unconverged (engine_set_correction_policy / DAVIDSON_CORRECTION_POLICY)",
-              "ms_per_solve": round(dt_pol / args.steps * 1e3, 4), "iters_per_solve": it_pol // args.steps,
-              "solves_per_s": round(args.steps / dt_pol, 2),
-              "reference_policy_solves_per_s": round(args.steps / elapsed, 2),
-              "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_pol - lam).max())}
+    # north-star microbenchmark: A*V at k = 8 (16, 32) on the same resident matrix, end to end and kernel only
+    apply_k = apply_rooflines(eng, (8, 16, 32), 10 if n >= 100000 else 20)
+    a8 = apply_k["k8"]
+    roofline_hbm = {"bound": "hbm", "kernel": kernel_name, "N": n, "k": 8,
+                    "achieved": a8["GBps_end_to_end"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a8["frac_of_8TBps_end_to_end"],
+                    "achieved_kernel_only": a8["GBps_kernel_only"], "frac_kernel_only": a8["frac_of_8TBps_kernel_only"],
+                    "ms_end_to_end": a8["ms_end_to_end"], "ms_kernel_only": a8["ms_kernel_only"],
+                    "algorithmic_bytes_per_launch": a8["algorithmic_bytes"], "traffic": None,
+                    "note": "bytes = 8*S + 16*N*k, S = N(N+1)/2 (symmetric-tiled) or nloc*N (row slab); end to end = "
+                            "pack_xt + sweep kernel + fixed-order reduction of the partial sums (HIP events on the engine's stream)"}
+
+    extras = {}
+    if not args.headline_only:
+        # opt-in correction policy (SURVEY 8f-2; not the reference's, so never part of `value`)
+        eng.set_correction_policy("unconverged")
+        eng.solve("DPR", 1000, args.tol, want_vectors=False)
+        dt_pol, it_pol, lam_pol = timed_solves(eng, "DPR", 2, args.tol)
+        eng.set_correction_policy("all")
+        extras["opt_in_policy"] = {"policy": "unconverged (engine_set_correction_policy / DAVIDSON_CORRECTION_POLICY)",
+                                   "ms_per_solve": round(dt_pol / 2 * 1e3, 3), "iters_per_solve": it_pol // 2,
+                                   "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_pol - lam).max())}
     eng.close()
 
-    # same workload with the matrix kept as its lower block triangle (engine option, single GPU): every
-    # off-diagonal tile is read once and used twice, so a sweep moves half the bytes
-    sym = None
-    if world == 1:
-        try:
-            es = make_engine(n, lowest, None, "symmetric")
-            es.generate_diagonal_dominant(1, args.sparsity, seed=1)
-            es.solve("DPR", 1000, args.tol, want_vectors=False)
-            es.c.synchronize()
-            t4 = time.perf_counter()
-            it_s = 0
-            for _ in range(args.steps):
-                lam_s, _, it = es.solve("DPR", 1000, args.tol, want_vectors=False)
-                it_s += it
-            es.c.synchronize()
-            dt_s = time.perf_counter() - t4
-            sym = {"storage": "symmetric-tiled (dav_set_storage / engine_set_storage)", "ms_per_solve": round(dt_s / args.steps * 1e3, 4),
-                   "iterations_per_s": round(it_s / dt_s, 2), "iters_per_solve": it_s // args.steps,
-                   "max_abs_eigenvalue_diff_vs_full_storage": float(np.abs(lam_s - lam).max())}
-            es.close()
-        except Exception as exc:       # noqa: BLE001
-            sym = {"error": repr(exc)[:300]}
+    if not args.headline_only:
+        # ---- configs[3]: generalized (A, B), GJD correction, lowest=8 ---------------------------------------
+        # A stored (symmetric tiles on one GPU), B = the same generator with unit diagonal evaluated on the fly:
+        # two stored 160 GB matrices do not fit one GPU
+        gn = n if args.gjd_n < 0 else args.gjd_n
+        if gn > 0:
+            try:
+                g = make_engine(gn, 8, 80, storage, gev=True)
+                g.generate_diagonal_dominant(1, args.sparsity, seed=1)
+                g.set_hashed_operator(2, args.sparsity, 1.0, seed=2)
+                g.solve("GJD", 1000, args.tol, want_vectors=False)        # warm-up (lazy workspace)
+                g.c.set_timing(2)
+                g.c.synchronize(); g.c.reset_stats()
+                dt_g, it_g, lam_g = timed_solves(g, "GJD", 1, args.tol)
+                sg = g.c.stats()
+                dev_other = sg.gram_ms + sg.panel_ms + sg.comm_ms       # panel_ms includes the sweeps of B
+                extras["configs3_gjd"] = {
+                    "workload": f"N={gn} generalized (A stored {storage}, B hashed unit-diagonal operator generated in the sweep), "
+                                f"GJD, lowest=8, max_dim_sub=80, tol={args.tol}, {world} GPU(s)",
+                    "iters": it_g, "seconds": round(dt_g, 4), "iterations_per_s": round(it_g / dt_g, 4),
+                    "sweeps_of_A": int(sg.applies), "columns_swept": int(sg.apply_cols),
+                    "ms_per_sweep_of_A_end_to_end": round(sg.apply_ms / max(sg.applies, 1), 3),
+                    "ms_in_sweeps_of_A": round(sg.apply_ms, 2),
+                    "ms_in_other_device_phases_incl_sweeps_of_B": round(dev_other, 2),
+                    "ms_latency_remainder": round(dt_g * 1e3 - sg.apply_ms - dev_other, 2),
+                    "eigenvalues": [float(x) for x in lam_g[:3]],
+                    "note": "sweeps_of_A x ms_per_sweep + the same number of generated-B sweeps is the device floor; the "
+                            "remainder is host latency of the inner MINRES (dot-product round trips, small uploads)"}
+                g.close()
+            except Exception as exc:       # noqa: BLE001
+                extras["configs3_gjd"] = {"error": repr(exc)[:300]}
 
-    # ---- configs[2]: N=200000 dense fp64, lowest=16, DPR, subspace restart at 80 ------------------------
-    # one GPU: symmetric-tiled storage (160 GB, K1s sweep); >= 2 GPUs: full row slabs + RCCL all-gather
-    large = None
-    if args.large_n > 0:
-        try:
-            storage = "symmetric" if world == 1 else "full"
-            big = make_engine(args.large_n, 16, 80, storage)
-            big.generate_diagonal_dominant(1, args.sparsity, seed=1)
-            big.solve("DPR", 1000, args.tol, want_vectors=False)
-            big.c.synchronize(); big.c.reset_stats(); barrier()
-            t1 = time.perf_counter()
-            reps = 2
-            it_big = 0
-            for _ in range(reps):
-                lam_big, _, it = big.solve("DPR", 1000, args.tol, want_vectors=False)
-                it_big += it
-            big.c.synchronize(); barrier()
-            dt = max_over_ranks(time.perf_counter() - t1)
-            sb = big.c.stats()
-            ms8, b8 = big.c.bench_apply(8, 5)
-            large = {"workload": f"N={args.large_n} dense fp64, lowest=16, DPR, max_dim_sub=80, storage={storage}, "
-                                 f"{world} GPU(s)",
-                     "iterations_per_s": round(it_big / dt, 3), "iters_per_solve": it_big // reps,
-                     "ms_per_solve": round(dt / reps * 1e3, 2),
-                     "apply_GBps_per_rank": round(sb.apply_bytes / (sb.apply_ms * 1e-3) / 1e9, 1),
-                     "apply_GBps_note": "stored bytes counted once per launch; a launch covers up to 32 columns "
-                                        "(symmetric storage: two paired 16-column groups, MFMA/issue bound)",
-                     "apply_k8": {"ms": round(ms8, 3), "GBps_per_rank": round(b8 / (ms8 * 1e-3) / 1e9, 1),
-                                  "frac_of_8TBps": round(b8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                  "algorithmic_bytes": b8,
-                                  "note": "bytes = 8*S + 16*N*k, S = N(N+1)/2 (symmetric-tiled) or nloc*N (full slab)"},
-                     "eigenvalues": [float(x) for x in lam_big[:3]]}
-            big.set_correction_policy("unconverged")
-            big.solve("DPR", 1000, args.tol, want_vectors=False)
-            big.c.synchronize(); barrier()
-            t3 = time.perf_counter()
-            lam_p, _, it_p = big.solve("DPR", 1000, args.tol, want_vectors=False)
-            big.c.synchronize(); barrier()
-            dt_p = max_over_ranks(time.perf_counter() - t3)
-            large["opt_in_policy_unconverged"] = {"ms_per_solve": round(dt_p * 1e3, 2), "iters_per_solve": int(it_p),
-                                                  "max_abs_eigenvalue_diff": float(np.abs(lam_p - lam_big).max())}
-            big.close()
-        except Exception as exc:       # noqa: BLE001
-            large = {"error": repr(exc)[:300]}
+        # ---- configs[4]: matrix-free hashed diagonal-dominant operator, lowest=8, DPR -------------------------
+        if args.free_n > 0:
+            try:
+                fn = args.free_n
+                f = make_engine(fn, 8, 80, storage, gev=True)
+                f.set_hashed_operator(1, args.sparsity, seed=1)
+                f.set_identity(2)                                        # B = I as src/benchmark_free.f90:65-76
+                f.c.synchronize(); f.c.reset_stats()
+                dt_f, it_f, lam_f = timed_solves(f, "DPR", 1, args.tol)
+                sf = f.c.stats()
+                entries = float(fn) * float(fn) / world                  # entries of A one rank's sweep stands for
+                per_launch_ms = sf.apply_kernel_ms / max(int(sf.apply_launches), 1)
+                extras["configs4_free"] = {
+                    "workload": f"N={fn} matrix-free hashed diagonal-dominant operator (entries generated in registers, "
+                                f"{'each symmetric pair once' if storage == 'symmetric' else 'row slab per rank'}), B = I, "
+                                f"lowest=8, DPR, tol={args.tol}, {world} GPU(s)",
+                    "iters": it_f, "seconds": round(dt_f, 3), "iterations_per_s": round(it_f / dt_f, 4),
+                    "sweeps": int(sf.applies), "launches": int(sf.apply_launches), "ms_per_launch": round(per_launch_ms, 2),
+                    "entries_of_A_per_s_per_rank": round(entries / (per_launch_ms * 1e-3), 0) if per_launch_ms > 0 else None,
+                    "eigenvalues": [float(x) for x in lam_f[:3]]}
+                f.close()
+            except Exception as exc:       # noqa: BLE001
+                extras["configs4_free"] = {"error": repr(exc)[:300]}
 
-    # ---- CPU baseline: rank 0, N=1 only -----------------------------------------------------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cn = args.cpu_n or n
-        raw = cpu_baseline(cn, lowest, args.sparsity, args.tol)
-        if "seconds" in raw:
-            cpu = {"value": round(raw["iters"] / raw["seconds"], 4), "unit": "Davidson iterations/s", "cores": raw["cores"],
-                   "kind": raw["kind"], "seconds": round(raw["seconds"], 3), "iters": raw["iters"],
-                   "sample": f"one full solve of the same workload (N={cn}, lowest={lowest}, DPR, tol={args.tol}) by the "
-                             "reference built with flang+MKL (oracle/_ref), all host threads",
-                   "max_abs_eigenvalue_diff_vs_gpu": float(np.abs(np.array(raw["evals"]) - lam).max()) if cn == n else None}
-        else:
-            cpu = raw
+        # ---- configs[1]: N=20000 dense, lowest=8, DPR (full storage; latency-bound at this size) ---------------
+        host_matrix_path = None
+        if args.small_n > 0:
+            try:
+                sn = args.small_n
+                s = make_engine(sn, 8, None, "full")
+                s.generate_diagonal_dominant(1, args.sparsity, seed=1)
+                for _ in range(5):
+                    s.solve("DPR", 1000, args.tol, want_vectors=False)
+                s.c.synchronize(); s.c.reset_stats()
+                dt_s, it_s, lam_s = timed_solves(s, "DPR", 50, args.tol)
+                ss = s.c.stats()
+                small = {"workload": f"N={sn} dense fp64 full storage, lowest=8, DPR, tol={args.tol}, {world} GPU(s)",
+                         "iterations_per_s": round(it_s / dt_s, 2), "ms_per_solve": round(dt_s / 50 * 1e3, 4), "iters_per_solve": it_s // 50,
+                         "apply_GBps_end_to_end": round(ss.apply_bytes / (ss.apply_ms * 1e-3) / 1e9, 1),
+                         "apply_GBps_kernel_only": round(ss.apply_bytes / (ss.apply_kernel_ms * 1e-3) / 1e9, 1),
+                         "eigenvalues": [float(x) for x in lam_s[:3]]}
+                s.c.set_timing(2); s.c.reset_stats()
+                for _ in range(5):
+                    s.solve("DPR", 1000, args.tol, want_vectors=False)
+                s.c.synchronize()
+                sp = s.c.stats()
+                small["phase_ms_per_solve"] = {"apply_ms": round(sp.apply_ms / 5, 4), "gram_ms": round(sp.gram_ms / 5, 4),
+                                               "panel_ms": round(sp.panel_ms / 5, 4), "comm_ms": round(sp.comm_ms / 5, 4)}
+                s.c.set_timing(1)
+                small["apply"] = apply_rooflines(s, (8, 16, 32), 20)
+                s.close()
+                extras["small"] = small
+            except Exception as exc:       # noqa: BLE001
+                extras["small"] = {"error": repr(exc)[:300]}
+
+        # ---- drop-in entry + CPU baseline: rank 0, one GPU only (both need the matrix in host memory) ---------
+        if rank == 0 and world == 1 and args.small_n > 0 and not (args.no_dropin and args.no_cpu_baseline):
+            cn = args.cpu_n or args.small_n
+            A_host = fd.generate_diagonal_dominant(cn, args.sparsity, None, 1)
+            if not args.no_dropin:
+                try:
+                    fd.generalized_eigensolver(A_host, 8, "DPR", 1000, args.tol)          # warm-up (pinned staging, first touch)
+                    t0 = time.perf_counter()
+                    lam_d, vec_d, it_d = fd.generalized_eigensolver(A_host, 8, "DPR", 1000, args.tol)
+                    dt_d = time.perf_counter() - t0
+                    extras["dropin"] = {"call": "generalized_eigensolver(matrix, eigenvalues, eigenvectors, lowest, method, max_iterations, "
+                                                "tolerance, iters) - src/davidson.f90:51-52: host matrix in, engine created, matrix uploaded "
+                                                "over PCIe, solved, eigenvectors downloaded, everything released",
+                                        "N": cn, "seconds": round(dt_d, 4), "iters": it_d, "iterations_per_s": round(it_d / dt_d, 2),
+                                        "upload_GB": round(8.0 * cn * cn / 1e9, 3)}
+                except Exception as exc:       # noqa: BLE001
+                    extras["dropin"] = {"error": repr(exc)[:300]}
+            if not args.no_cpu_baseline:
+                host_matrix_path = os.path.join(tempfile.gettempdir(), f"davidson_cpu_baseline_{os.getpid()}.npy")
+                try:
+                    np.save(host_matrix_path, A_host)
+                    del A_host
+                    raw = cpu_baseline(host_matrix_path, 8, args.tol)
+                finally:
+                    if os.path.exists(host_matrix_path):
+                        os.remove(host_matrix_path)
+                if "seconds" in raw:
+                    extras["cpu_baseline"] = {
+                        "value": round(raw["iters"] / raw["seconds"], 4), "unit": "iterations/s", "cores": raw["cores"],
+                        "kind": raw["kind"], "seconds": round(raw["seconds"], 3), "iters": raw["iters"],
+                        "sample": f"one full solve at N={cn}, lowest=8, DPR, tol={args.tol} (the configs[1] problem - the timed "
+                                  "N=200000 matrix needs 320 GB in the reference's full storage and (m+1) sweeps of it per iteration) "
+                                  "by the reference built with flang+MKL (oracle/_ref), all host threads",
+                        "max_abs_eigenvalue_diff_vs_gpu": float(np.abs(np.array(raw["evals"][:3]) - np.array(extras["small"]["eigenvalues"])).max())
+                        if cn == args.small_n and "eigenvalues" in extras.get("small", {}) else None}
+                else:
+                    extras["cpu_baseline"] = raw
 
     if rank == 0:
         line = {"metric": "Davidson iterations/sec (dense DPR solve, matrix resident in HBM) + A*V HBM GB/s vs roofline",
-                "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+                "value": round(value, 4), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": f"N={n} dense fp64 full storage, lowest={lowest}, DPR, tol={args.tol}, "
-                                       f"generate_diagonal_dominant(N,{args.sparsity}) seed 1, max_dim={10 * lowest}",
-                           "N": n, "lowest": lowest, "iters_per_solve": total_iters // args.steps,
-                           "basis_widths": "2L,4L,8L", "parallelism": f"row-slab x{world}"},
+                "config": {"workload": f"N={n} dense fp64, lowest={lowest}, DPR, max_dim_sub={max_dim} (subspace restart at {max_dim}), "
+                                       f"tol={args.tol}, generate_diagonal_dominant(N,{args.sparsity}) seed 1, storage: {storage_words}",
+                           "N": n, "lowest": lowest, "max_dim_sub": max_dim, "storage": storage,
+                           "iters_per_solve": total_iters // args.steps, "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
+                           "generate_seconds": round(t_gen, 2)},
                 "eigenvalues": [float(x) for x in lam[:3]],
-                "roofline": roofline, "phase_ms_per_step": phase, "apply": apply_k, "opt_in_policy": opt_in, "symmetric_storage": sym, "large": large, "cpu_baseline": cpu}
+                "roofline": roofline, "roofline_hbm": roofline_hbm, "apply": apply_k}
+        line.update(extras)
+        if "cpu_baseline" not in line:
+            line["cpu_baseline"] = None
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -40,11 +40,32 @@ def hip_lib() -> C.CDLL:
         # imported first both share torch's copy (same soname).  Pure Fortran hosts never meet this.
         try:
             import torch  # noqa: F401
-        except Exception:      # noqa: BLE001 - harness without PyTorch
+        except ImportError:    # harness without PyTorch: the system runtime is the only one
             pass
         _hip = C.CDLL(HIP_LIB, mode=C.RTLD_LOCAL)
         _hip.dav_last_error.restype = C.c_char_p
+        runtimes = hip_runtimes_mapped()
+        if len(runtimes) > 1:
+            raise RuntimeError("two HIP runtimes are mapped into this process (" + ", ".join(runtimes) + "): the "
+                               "engine and PyTorch would each see their own devices - import torch before "
+                               "fortran_davidson_amd, or unset LD_LIBRARY_PATH overrides")
+        if os.environ.get("DAVIDSON_VERBOSE"):
+            print("fortran_davidson_amd: HIP runtime bound:", runtimes[0] if runtimes else "(not found in /proc/self/maps)")
     return _hip
+
+
+def hip_runtimes_mapped() -> list:
+    """Distinct libamdhip64 files mapped into this process (one is the only healthy answer)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64" in os.path.basename(path) and os.path.realpath(path) not in found:
+                    found.append(os.path.realpath(path))
+    except OSError:
+        pass
+    return found
 
 
 def fortran_lib() -> C.CDLL:

@@ -182,7 +182,7 @@ struct dav_engine {
   hipEvent_t ev[N_EVPAIRS][2];
   double ev_bytes[N_EVPAIRS];
   int ev_kind[N_EVPAIRS];
-  int ev_used = 0;
+  int ev_used = 0, ev_open = 0;
   int timing_level = 1;           // 0 = nothing, 1 = block matvec only, 2 = every phase
 };
 typedef dav_engine E;
@@ -203,6 +203,10 @@ static int collect_events(E* e) {
       e->st.apply_bytes += e->ev_bytes[i];
       e->st.last_apply_ms = ms;
       e->st.last_apply_bytes = e->ev_bytes[i];
+    } else if (e->ev_kind[i] == 4) {           // the block-matvec kernel alone; ev_bytes carries its flops
+      e->st.apply_kernel_ms += ms;
+      e->st.apply_flops += e->ev_bytes[i];
+      e->st.apply_launches += 1;
     } else if (e->ev_kind[i] == 1) {
       e->st.gram_ms += ms;
     } else if (e->ev_kind[i] == 2) {
@@ -216,10 +220,14 @@ static int collect_events(E* e) {
 }
 // begin/end record an event pair on the stream; collect_events() turns pairs into milliseconds
 static int timed_begin(E* e, int kind, double bytes, int* slot) {
-  // an event pair costs ~5 us of host time: by default only the block matvec (kind 0, the roofline kernel)
-  // is timed; dav_set_timing(h, 2) adds the Gram / panel / collective phases
-  if (e->timing_level < 1 || (kind != 0 && e->timing_level < 2)) { *slot = -1; return 0; }
-  if (e->ev_used == N_EVPAIRS) CHK(collect_events(e));
+  // an event pair costs ~5 us of host time: by default only the block apply is timed - kind 0 = end to end
+  // (pack + all-gather + kernel + reduction), kind 4 = the block-matvec kernel alone (the roofline kernel);
+  // dav_set_timing(h, 2) adds the Gram / panel / collective phases
+  if (e->timing_level < 1 || (kind != 0 && kind != 4 && e->timing_level < 2)) { *slot = -1; return 0; }
+  // pairs nest (kernel inside apply): collect only while no pair is open, and leave room for the inner ones
+  if (e->ev_open == 0 && e->ev_used > N_EVPAIRS - 4) CHK(collect_events(e));
+  if (e->ev_used == N_EVPAIRS) { *slot = -1; return 0; }
+  ++e->ev_open;
   *slot = e->ev_used++;
   e->ev_kind[*slot] = kind;
   e->ev_bytes[*slot] = bytes;
@@ -228,6 +236,7 @@ static int timed_begin(E* e, int kind, double bytes, int* slot) {
 }
 static int timed_end(E* e, int slot) {
   if (slot < 0) return 0;
+  --e->ev_open;
   HIPCHK(hipEventRecord(e->ev[slot][1], e->stream));
   return 0;
 }
@@ -997,10 +1006,12 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;
-      launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
-      int slot = -1;
+      int slot = -1, kslot = -1;
       double bytes = (o.kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) : 0.0) + 16.0 * (double)e->n * kk;
+      // end to end: everything that turns the source columns into W - packing, the sweep, the fixed-order sum
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
+      launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
+      if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk, &kslot));
       double* slabT = e->sym_slab + e->sym_slabD_doubles;
       if (o.kind != DAV_KIND_DENSE)
         launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
@@ -1008,10 +1019,11 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       else
         launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair, e->xt_group_stride,
                           dstride, tstride);
-      if (timed) CHK(timed_end(e, slot));
+      CHK(timed_end(e, kslot));
       for (int g = 0; g < npair; ++g)
         launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, e->sym_nb, 1, e->nloc,
                           std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+      CHK(timed_end(e, slot));
       if (which == DAV_OP_A) {
         e->st.applies += 1;
         e->st.apply_cols += kk;
@@ -1024,32 +1036,34 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     int kk = std::min(64, k - c);
     int groups = (kk + 15) / 16;
     int ngroups = groups == 3 ? 4 : groups;
+    int slot = -1, kslot = -1;
+    double bytes = 8.0 * (double)e->nloc * (double)e->n + 16.0 * (double)e->n * kk;
+    if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
     launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
     if (has_comm(e)) {
-      int slot;
-      CHK(timed_begin(e, 3, 0, &slot));
+      int cslot;
+      CHK(timed_begin(e, 3, 0, &cslot));
       if (e->comm) NCCLCHK(g_rccl.GroupStart());
       for (int g = 0; g < groups; ++g) {
         double* base = e->xt + g * e->xt_group_stride;
         CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
       }
       if (e->comm) NCCLCHK(g_rccl.GroupEnd());
-      CHK(timed_end(e, slot));
+      CHK(timed_end(e, cslot));
     }
     int nsplit, jc;
     matvec_plan(e->nloc_pad, e->ncols_pad, ngroups, &nsplit, &jc);
     if (matvec_slab_doubles(e->nloc_pad, ngroups, nsplit) > e->scratch_doubles) return fail("matvec scratch too small");
-    int slot = -1;
-    double bytes = 8.0 * (double)e->nloc * (double)e->n + 16.0 * (double)e->n * kk;
-    if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
+    if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->nloc * (double)e->n * kk, &kslot));
     if (o.kind == DAV_KIND_DENSE)
       launch_matvec_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->xt, e->xt_group_stride, ngroups,
                           e->scratch, nsplit, jc);
     else
       launch_matvec_free(e->stream, op_params(o), e->row0, e->nloc, e->n, e->nloc_pad, e->ncols_pad, e->xt,
                          e->xt_group_stride, ngroups, e->scratch, nsplit, jc);
-    if (timed) CHK(timed_end(e, slot));     // the event pair brackets the block-matvec kernel alone
+    CHK(timed_end(e, kslot));               // inner pair: the block-matvec kernel alone
     launch_slab_reduce(e->stream, e->scratch, nsplit, e->nloc_pad, ngroups, e->nloc, kk, dst + (int64_t)c * e->ldp, e->ldp);
+    CHK(timed_end(e, slot));                // outer pair: pack + all-gather + kernel + reduction
     if (which == DAV_OP_A) {
       e->st.applies += 1;
       e->st.apply_cols += kk;
@@ -1410,27 +1424,41 @@ extern "C" int dav_set_width(dav_handle_t e, int m) {
 
 // ---- measurement --------------------------------------------------------------------------------
 extern "C" int dav_bench_apply(dav_handle_t e, int which, int k, int reps, double* avg_ms, double* bytes) {
+  double kernel_ms, flops;
+  return dav_bench_apply2(e, which, k, reps, avg_ms, &kernel_ms, bytes, &flops);
+}
+
+extern "C" int dav_bench_apply2(dav_handle_t e, int which, int k, int reps, double* avg_ms, double* kernel_ms, double* bytes,
+                                double* flops) {
   CHK(bind(e));
   if (which != DAV_OP_A) return fail("dav_bench_apply: only operator A is timed");
   if (k <= 0 || k > 64 || reps <= 0) return fail("dav_bench_apply: k must be in 1..64");
   CHK(collect_events(e));
   dav_stats saved = e->st;
-  // warm up once, then time the matvec + slab-reduce launches only (operands resident in HBM)
+  // warm up once, then time whole applies (pack + kernel + reduction; operands resident in HBM)
+  const int saved_level = e->timing_level;
+  e->timing_level = 1;
   CHK(apply_impl(e, which, DAV_PANEL_V, 0, k, DAV_PANEL_S, 0, false));
   HIPCHK(hipStreamSynchronize(e->stream));
-  double total = 0;
+  double total = 0, ktotal = 0;
   int done = 0;
   while (done < reps) {
-    int batch = std::min(reps - done, N_EVPAIRS / 2);
+    int batch = std::min(reps - done, N_EVPAIRS / 8);
     e->st.apply_ms = 0;
+    e->st.apply_kernel_ms = 0;
     for (int i = 0; i < batch; ++i) CHK(apply_impl(e, which, DAV_PANEL_V, 0, k, DAV_PANEL_S, 0, true));
     CHK(collect_events(e));
     total += e->st.apply_ms;
+    ktotal += e->st.apply_kernel_ms;
     done += batch;
   }
+  e->timing_level = saved_level;
   *avg_ms = total / reps;
-  *bytes = (e->op[which].storage == 1 ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0)
-                                      : 8.0 * (double)e->nloc * (double)e->n) + 16.0 * (double)e->n * k;
+  *kernel_ms = ktotal / reps;
+  const bool sym = e->op[which].storage == 1;
+  *bytes = (sym ? (e->op[which].kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) : 0.0)
+                : 8.0 * (double)e->nloc * (double)e->n) + 16.0 * (double)e->n * k;
+  *flops = 2.0 * (double)(sym ? e->n : e->nloc) * (double)e->n * k;
   e->st = saved;
   return 0;
 }

@@ -22,7 +22,8 @@ class Stats(C.Structure):
                 ("m", C.c_int32), ("applies", C.c_int32), ("apply_cols", C.c_int64),
                 ("apply_ms", C.c_double), ("apply_bytes", C.c_double), ("last_apply_ms", C.c_double),
                 ("last_apply_bytes", C.c_double), ("gram_ms", C.c_double), ("panel_ms", C.c_double),
-                ("comm_ms", C.c_double)]
+                ("comm_ms", C.c_double), ("apply_kernel_ms", C.c_double), ("apply_flops", C.c_double),
+                ("apply_launches", C.c_int64)]
 
 
 def _dp(a):
@@ -234,10 +235,18 @@ class CEngine:
         self._chk(self.lib.dav_set_width(self.h, C.c_int(m)))
 
     def bench_apply(self, k, reps, which=OP_A):
+        """(ms per apply END TO END: pack + kernel + reduction, algorithmic bytes per apply)"""
         ms, nbytes = C.c_double(), C.c_double()
         self._chk(self.lib.dav_bench_apply(self.h, C.c_int(which), C.c_int(k), C.c_int(reps), C.byref(ms),
                                            C.byref(nbytes)))
         return ms.value, nbytes.value
+
+    def bench_apply2(self, k, reps, which=OP_A):
+        """(ms per apply end to end, ms of the block-matvec kernel alone, algorithmic bytes, flops) per apply"""
+        ms, kms, nbytes, flops = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.dav_bench_apply2(self.h, C.c_int(which), C.c_int(k), C.c_int(reps), C.byref(ms), C.byref(kms),
+                                            C.byref(nbytes), C.byref(flops)))
+        return ms.value, kms.value, nbytes.value, flops.value
 
 
 def parse_text_f64(data: bytes) -> np.ndarray:

@@ -20,7 +20,7 @@ module davidson_device
   use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_cholesky_inverse, lapack_matmul
   implicit none
   private
-  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, &
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, &
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
@@ -34,6 +34,10 @@ module davidson_device
      integer :: max_cols = 0
      logical :: gev = .false.
      integer :: policy = 0          !< POLICY_ALL (the reference) or POLICY_UNCONVERGED (opt-in)
+     !> .true. when operator A is matrix-free (a device operator instead of a stored matrix): the solve then
+     !> follows the reference's matrix-free driver - convergence of all wanted pairs tested at once, no
+     !> sticky flags (src/davidson.f90:416) - instead of the dense one (:176)
+     logical :: free_semantics = .false.
   end type davidson_engine
 
   !> Wall time of the last solve by phase (seconds): 1 setup (init basis + first projection),
@@ -54,6 +58,17 @@ module davidson_device
   end interface
 
 contains
+
+  !> Device index from the environment (DAVIDSON_DEVICE, default 0): an engine knob that does not
+  !> touch the reference's argument lists (dense and matrix-free front ends alike).
+  function env_device() result(dev)
+    integer :: dev, stat, length
+    character(len=16) :: buf
+    dev = 0
+    call get_environment_variable("DAVIDSON_DEVICE", buf, length, stat)
+    if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) dev
+    if (stat /= 0) dev = 0
+  end function env_device
 
   !> Widest basis the reference's policy can reach: m starts at 2*lowest and doubles while
   !> m <= max_dim (src/davidson.f90:195-213), so it may overshoot max_dim once.
@@ -168,6 +183,7 @@ contains
     end if
     call check_dav(dav_set_dense_host(eng%h, int(which - 1, c_int), matrix, int(size(matrix, 1), c_int64_t)), &
          "dav_set_dense_host")
+    if (which == 1) eng%free_semantics = .false.
   end subroutine engine_set_dense
 
   !> Operator A (which=1) or B (which=2) from a file, streamed to HBM by blocks of rows - no host N x N
@@ -194,6 +210,7 @@ contains
     end if
     call check_dav(dav_set_dense_file(eng%h, int(which - 1, c_int), trim(path_file) // c_null_char, code), &
          "dav_set_dense_file")
+    if (which == 1) eng%free_semantics = .false.
   end subroutine engine_read_matrix
 
   !> Streaming upload for hosts that produce the matrix row by row: begin, any number of put_rows (each a
@@ -203,6 +220,7 @@ contains
     type(davidson_engine), intent(inout) :: eng
     integer, intent(in) :: which
     call check_dav(dav_dense_begin(eng%h, int(which - 1, c_int)), "dav_dense_begin")
+    if (which == 1) eng%free_semantics = .false.
   end subroutine engine_dense_begin
 
   subroutine engine_dense_put_rows(eng, which, row0, rows)
@@ -240,6 +258,7 @@ contains
     if (present(diag_val)) dv = diag_val
     call check_dav(dav_set_dense_generated(eng%h, int(which - 1, c_int), s, sparsity, &
          merge(1_c_int, 0_c_int, present(diag_val)), dv), "dav_set_dense_generated")
+    if (which == 1) eng%free_semantics = .false.
   end subroutine engine_generate_diagonal_dominant
 
   !> Same matrix as engine_generate_diagonal_dominant but never stored: entries are generated on
@@ -258,6 +277,7 @@ contains
     if (present(diag_val)) dv = diag_val
     call check_dav(dav_set_operator_hashed(eng%h, int(which - 1, c_int), s, sparsity, &
          merge(1_c_int, 0_c_int, present(diag_val)), dv), "dav_set_operator_hashed")
+    if (which == 1) eng%free_semantics = .true.
   end subroutine engine_set_hashed_operator
 
   !> The operators of the reference's matrix-free tests (src/tests/test_utils.f90:38-116) evaluated
@@ -272,6 +292,7 @@ contains
        e(i) = exp(real(i) / real(eng%n))      ! single precision on purpose (test_utils.f90:82)
     end do
     call check_dav(dav_set_operator_harness(eng%h, int(which - 1, c_int), e), "dav_set_operator_harness")
+    if (which == 1) eng%free_semantics = .true.
   end subroutine engine_set_harness_operator
 
   subroutine engine_set_identity(eng, which)
@@ -301,8 +322,10 @@ contains
        print *, "generalized_eigensolver: engine created for a narrower basis than lowest/max_dim_sub need"
        error stop
     end if
+    ! stored matrix: the dense driver's sticky convergence flags (src/davidson.f90:176); matrix-free operator A:
+    ! the matrix-free driver's all-at-once test (:416)
     call davidson_device_loop(eng%h, eng%n, lowest, method, max_iterations, tolerance, iters, max_dim, &
-         eng%gev, .true., eigenvalues, policy=eng%policy)
+         eng%gev, .not. eng%free_semantics, eigenvalues, policy=eng%policy)
     if (present(eigenvectors)) then
        call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), eigenvectors, &
             int(size(eigenvectors, 1), c_int64_t)), "dav_panel_get")
@@ -341,18 +364,21 @@ contains
     real(dp) :: t0, t1
 
     last_phase_seconds = 0.0_dp
-    select case (trim(method))
-    case ("DPR")
-       meth = DAV_METHOD_DPR
-    case ("GJD")
-       meth = DAV_METHOD_GJD
-    case default
-       ! the reference leaves the correction undefined here (src/davidson.f90:656-669)
-       print *, "generalized_eigensolver: unknown correction method '", trim(method), "' (DPR or GJD)"
-       error stop
-    end select
     host_ops = present(fun_a)
-    if (host_ops .and. meth == DAV_METHOD_GJD) meth = DAV_METHOD_DPR    ! free path is DPR only (:428)
+    if (host_ops) then
+       meth = DAV_METHOD_DPR       ! the matrix-free driver never looks at `method`: always DPR (src/davidson.f90:428)
+    else
+       select case (trim(method))
+       case ("DPR")
+          meth = DAV_METHOD_DPR
+       case ("GJD")
+          meth = DAV_METHOD_GJD
+       case default
+          ! the reference leaves the correction undefined here (src/davidson.f90:656-669)
+          print *, "generalized_eigensolver: unknown correction method '", trim(method), "' (DPR or GJD)"
+          error stop
+       end select
+    end if
     pol = POLICY_ALL
     if (present(policy)) pol = policy
 
@@ -387,8 +413,9 @@ contains
           expand_now = m <= max_dim
           ncorr = merge(m, lowest, expand_now)
        else
-          ! grow while the widest possible block still fits; a basis that has just been (re)started always grows
-          expand_now = (m + lowest <= max_dim) .or. (m <= initial_dimension)
+          ! grow while the widest possible block still fits; a basis that has just been (re)started always grows -
+          ! as long as the projected matrices (cap x cap) can take one more column
+          expand_now = ((m + lowest <= max_dim) .or. (m <= initial_dimension)) .and. m < cap
           ncorr = lowest
        end if
        ! Convergence usually arrives at the widest basis, exactly where the full Ritz problem is dearest
@@ -482,7 +509,7 @@ contains
              end if
           else
              ! only the wanted pairs that have not converged: keep their columns, drop the others
-             kt = min(count(errors >= tolerance), n - m)
+             kt = min(count(errors >= tolerance), n - m, cap - m)   ! cap - m: max_dim_sub < 2*lowest leaves cap = 2*lowest
              if (kt <= 0) exit outer_loop
              if (allocated(sel)) deallocate(sel, theta_sel)
              allocate(sel(kt), theta_sel(kt))
@@ -801,17 +828,6 @@ contains
     call engine_destroy(eng)
   end subroutine generalized_eigensolver_dense
 
-  !> Device index from the environment (DAVIDSON_DEVICE, default 0): an engine knob that does not
-  !> touch the reference's argument lists.
-  function env_device() result(dev)
-    integer :: dev, stat, length
-    character(len=16) :: buf
-    dev = 0
-    call get_environment_variable("DAVIDSON_DEVICE", buf, length, stat)
-    if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) dev
-    if (stat /= 0) dev = 0
-  end function env_device
-
 end module davidson_dense
 
 
@@ -866,7 +882,7 @@ contains
     call extract_diagonal_blocked(fun_matrix_gemv, n, diag_a)
     call extract_diagonal_blocked(fun_second_matrix_gemv, n, diag_b)
 
-    call engine_create(eng, n, lowest, max_dim, .true.)
+    call engine_create(eng, n, lowest, max_dim, .true., env_device())
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_A, diag_a), "dav_set_operator_host")
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_B, diag_b), "dav_set_operator_host")
     call davidson_device_loop(eng%h, n, lowest, method, max_iterations, tolerance, iters, max_dim, .true., &

@@ -15,6 +15,8 @@ module davidson_hip_c
      integer(c_int32_t) :: nranks, rank, m, applies
      integer(c_int64_t) :: apply_cols
      real(c_double) :: apply_ms, apply_bytes, last_apply_ms, last_apply_bytes, gram_ms, panel_ms, comm_ms
+     real(c_double) :: apply_kernel_ms, apply_flops
+     integer(c_int64_t) :: apply_launches
   end type dav_stats
 
   interface

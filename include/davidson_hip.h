@@ -51,11 +51,18 @@ typedef struct dav_stats {
   int32_t m;               /* current basis width                                                   */
   int32_t applies;         /* block applies of A so far                                             */
   int64_t apply_cols;      /* total columns A was applied to                                        */
-  double apply_ms;         /* device time in the A*X block matvec kernels (HIP events)              */
-  double apply_bytes;      /* algorithmic bytes of those applies: 8*nloc*N + 16*N*k each            */
-  double last_apply_ms;    /* duration of the most recent A apply                                   */
+  double apply_ms;         /* device time of the A*X block applies END TO END (HIP events): operand   */
+                           /* packing + (all-gather) + block-matvec kernel + partial-sum reduction   */
+  double apply_bytes;      /* algorithmic bytes of those applies: 8*S + 16*N*k each, S = nloc*N      */
+                           /* (full row slab) or N(N+1)/2 (symmetric-tiled)                          */
+  double last_apply_ms;    /* duration of the most recent A apply (end to end)                      */
   double last_apply_bytes;
   double gram_ms, panel_ms, comm_ms;
+  double apply_kernel_ms;  /* the block-matvec kernel alone inside apply_ms (same launches)          */
+  double apply_flops;      /* 2*nloc*N*k per apply (N*N*k with symmetric tiles: every stored entry   */
+                           /* is used twice)                                                         */
+  int64_t apply_launches;  /* launches of the block-matvec kernel (an apply of > 32 / 64 columns is  */
+                           /* several launches)                                                      */
 } dav_stats;
 
 const char* dav_last_error(void);
@@ -82,8 +89,9 @@ int dav_synchronize(dav_handle_t h);
 int dav_get_stats(dav_handle_t h, dav_stats* out);
 int dav_reset_stats(dav_handle_t h);
 /* What dav_get_stats measures with HIP events on the engine's stream: 0 = nothing, 1 (default) = the block
- * matvec only (apply_ms / apply_bytes: the roofline kernel), 2 = also the Gram, panel and collective phases
- * (gram_ms, panel_ms, comm_ms; each event pair costs ~5 us of host time per launch group). */
+ * applies (apply_ms: pack + kernel + reduction, apply_kernel_ms: the roofline kernel alone), 2 = also the
+ * Gram, panel and collective phases (gram_ms, panel_ms, comm_ms; each event pair costs ~5 us of host time
+ * per launch group). */
 int dav_set_timing(dav_handle_t h, int level);
 /* rows of this rank: [row0, row0+nloc) */
 int dav_local_rows(dav_handle_t h, int64_t* row0, int64_t* nloc);
@@ -215,10 +223,14 @@ int dav_panel_put(dav_handle_t h, int panel, int c0, int k, const double* in, in
 int dav_set_width(dav_handle_t h, int m);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
-/* Time `reps` launches of the A block matvec on k columns with HIP events on the engine's stream
- * (inputs resident).  Returns average milliseconds per launch and the algorithmic bytes per launch
- * (8*nloc*N + 16*N*k). */
+/* Time `reps` block applies of A on k columns with HIP events on the engine's stream (inputs resident).
+ * Returns the average milliseconds per apply END TO END (operand packing + block-matvec kernel + reduction
+ * of the partial sums - everything that produces W from V) and the algorithmic bytes per apply
+ * (8*S + 16*N*k).  dav_bench_apply2 also returns the average of the block-matvec kernel
+ * alone (kernel_ms) and the flops per apply. */
 int dav_bench_apply(dav_handle_t h, int which, int k, int reps, double* avg_ms, double* bytes);
+int dav_bench_apply2(dav_handle_t h, int which, int k, int reps, double* avg_ms, double* kernel_ms, double* bytes,
+                     double* flops);
 
 #ifdef __cplusplus
 }

@@ -38,16 +38,37 @@ def run_bench(nproc, extra):
 
 @pytest.mark.parametrize("nproc", [2, 3])
 def test_bench_multi_rank_flow_matches_single_rank(nproc):
-    extra = ["--steps", "2", "--warmup", "1", "--order", "6000", "--large-n", "5000", "--no-cpu-baseline"]
+    # the timed workload at a reduced order, full row slabs on both sides so that the runs are comparable;
+    # the configs[1] / configs[3] / configs[4] legs at small orders
+    extra = ["--steps", "2", "--warmup", "1", "--order", "6000", "--storage", "full", "--small-n", "3000", "--gjd-n", "2000",
+             "--free-n", "4000", "--no-cpu-baseline", "--no-dropin"]
     one = run_bench(1, extra)
     many = run_bench(nproc, extra)
     assert many["n_gpus"] == nproc and many["steps"] == 2 and many["scaling"] == "strong"
     assert many["config"]["iters_per_solve"] == one["config"]["iters_per_solve"]
     assert np.abs(np.array(many["eigenvalues"]) - np.array(one["eigenvalues"])).max() < 1e-10
-    assert many["roofline"]["achieved"] > 0 and many["phase_ms_per_step"]["comm_ms"] > 0
+    assert many["roofline"]["achieved"] > 0 and many["roofline_hbm"]["achieved"] > 0
+    assert many["roofline_hbm"]["ms_end_to_end"] >= many["roofline_hbm"]["ms_kernel_only"] > 0
+    assert many["small"]["phase_ms_per_solve"]["comm_ms"] > 0
     assert many["cpu_baseline"] is None
-    big1, bigp = one["large"], many["large"]
-    assert "error" not in bigp, bigp
-    assert bigp["iters_per_solve"] == big1["iters_per_solve"]
-    assert np.abs(np.array(bigp["eigenvalues"]) - np.array(big1["eigenvalues"])).max() < 1e-10
+    for key in ("small", "configs3_gjd", "configs4_free"):
+        a, b = one[key], many[key]
+        assert "error" not in a and "error" not in b, (a, b)
+        assert np.abs(np.array(a["eigenvalues"]) - np.array(b["eigenvalues"])).max() < 1e-8, key
+    assert many["small"]["iters_per_solve"] == one["small"]["iters_per_solve"]
+    assert many["configs4_free"]["iters"] == one["configs4_free"]["iters"]
     assert np.abs(many["opt_in_policy"]["max_abs_eigenvalue_diff_vs_reference_policy"]) < 1e-8
+
+
+def test_bench_single_gpu_default_shape_of_the_line():
+    """The one-GPU flow with symmetric tiles at a reduced order: every object the contract names is there."""
+    line = run_bench(1, ["--steps", "2", "--warmup", "1", "--order", "8000", "--small-n", "3000", "--gjd-n", "3000",
+                         "--free-n", "6000", "--no-cpu-baseline"])
+    assert line["config"]["storage"] == "symmetric" and line["config"]["N"] == 8000
+    for key in ("roofline", "roofline_hbm", "apply", "configs3_gjd", "configs4_free", "small", "dropin", "opt_in_policy"):
+        assert key in line and "error" not in line[key], (key, line.get(key))
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["launches"] > 0
+    assert 0 < line["roofline_hbm"]["frac"] <= line["roofline_hbm"]["frac_kernel_only"] < 1
+    assert line["configs3_gjd"]["sweeps_of_A"] > line["configs3_gjd"]["iters"]
+    assert line["dropin"]["iters"] == line["small"]["iters_per_solve"]

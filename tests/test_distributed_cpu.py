@@ -84,4 +84,4 @@ def test_bench_launch_plumbing_world_size_2():
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["control_plane"] == "ok" and out["world"] == 2 and out["rows_rank0"] == [0, 10000]
+    assert out["control_plane"] == "ok" and out["world"] == 2 and out["rows_rank0"] == [0, 100000]     # default order 200000 (configs[2]) over 2 ranks
