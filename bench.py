@@ -322,7 +322,10 @@ def main():
         if args.free_n > 0:
             try:
                 fn = args.free_n
-                f = make_engine(fn, 8, 80, storage, gev=True)
+                # symmetric generation keeps per-tile partial sums (N^2/2 bytes per 32 columns): beyond N ~ 600000 they
+                # do not fit next to nothing else, and the row-slab kernel (what several GPUs run anyway) is used
+                fstorage = storage if fn <= 500000 else "full"
+                f = make_engine(fn, 8, 80, fstorage, gev=True)
                 f.set_hashed_operator(1, args.sparsity, seed=1)
                 f.set_identity(2)                                        # B = I as src/benchmark_free.f90:65-76
                 f.c.synchronize(); f.c.reset_stats()
@@ -332,7 +335,7 @@ def main():
                 per_launch_ms = sf.apply_kernel_ms / max(int(sf.apply_launches), 1)
                 extras["configs4_free"] = {
                     "workload": f"N={fn} matrix-free hashed diagonal-dominant operator (entries generated in registers, "
-                                f"{'each symmetric pair once' if storage == 'symmetric' else 'row slab per rank'}), B = I, "
+                                f"{'each symmetric pair once' if fstorage == 'symmetric' else 'row slab per rank'}), B = I, "
                                 f"lowest=8, DPR, tol={args.tol}, {world} GPU(s)",
                     "iters": it_f, "seconds": round(dt_f, 3), "iterations_per_s": round(it_f / dt_f, 4),
                     "sweeps": int(sf.applies), "launches": int(sf.apply_launches), "ms_per_launch": round(per_launch_ms, 2),

@@ -256,7 +256,20 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
   __shared__ __attribute__((aligned(16))) double tr[8 * TRW];
   __shared__ __attribute__((aligned(16))) double xsT[16 * XT];
   __shared__ __attribute__((aligned(16))) double zred[2][4][2][128];   // [unit parity][column group][half of f64x4][lane x 2]
+  // Stage of the transposed partials: 32 rows of 256 tile columns = 4 tiles x 8 block columns (k <= 8) or 2 tiles
+  // x 16.  The units deposit their 16 x 16 pieces here; every 4 (2) tiles the stage leaves the chip as full 2 KB
+  // rows.  Why: global stores and loads share one in-order counter (vmcnt), so a wave that has stored cannot
+  // retire its NEXT tile loads before that store is acknowledged, and the per-unit barrier hands the stall to the
+  // whole workgroup.  Measured at N=200000, k=8 on one box: no Z stores at all 25.8 ms, stores into an 8 MB
+  // (cache-resident) window 27.8 ms, 32-byte fragments per unit straight to the slab 28.8 ms, one staged flush per
+  // tile 28.8 ms (N=100000: 7.9 -> 7.0 ms), non-temporal stores 29.8 ms: what costs is the number of store
+  // EVENTS a wave waits behind, hence as few flushes as the LDS allows.
+  constexpr int ZS = 258;         // padded row stride: the unit writes (c * ZS + g + 4 reg) are conflict free
+  constexpr int ZROWS = 32;
+  __shared__ __attribute__((aligned(16))) double zst[ZROWS * ZS];
   static_assert(TRW >= 16 * RS, "the end-of-run exchange reuses the transposition scratch");
+  const int zrows = kcols <= 8 ? 8 : 16;            // rows of one tile in the stage
+  const int zslots = ZROWS / zrows;                  // tiles the stage holds
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int w = wave & 3, h = wave >> 2;
@@ -334,6 +347,18 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
 #pragma unroll
   for (int d = 0; d < SYM8_DEPTH; ++d) load_hs(d, ra[d]);
 
+  const int nq_off = ((J1 - 1 == I ? J1 - 1 : J1) - J0) * 4;
+  // tiles [t0, t0 + cnt) of the run (J = J0 + t): stage -> slabT tile (I, J) = [16 block columns][256 tile columns]
+  auto flush_tiles = [&](int t0, int cnt) {
+    for (int sidx = 0; sidx < cnt; ++sidx) {
+      const double* zs = zst + (size_t)((t0 + sidx) % zslots) * zrows * ZS;
+      double* outT = slabT + ((int64_t)I * (I - 1) / 2 + J0 + t0 + sidx) * 16 * SYM_TB;
+      for (int e = threadIdx.x; e < kcols * (SYM_TB / 2); e += 512) {   // block columns beyond the k in use: nobody reads them
+        const int bc = e >> 7, pr = e & 127;
+        *reinterpret_cast<f64x2*>(outT + bc * SYM_TB + 2 * pr) = *reinterpret_cast<const f64x2*>(zs + bc * ZS + 2 * pr);
+      }
+    }
+  };
   auto unit = [&](auto off_tag, int q) {
     constexpr bool OFF = decltype(off_tag)::value;
     load_b(q + 1, bn);
@@ -392,20 +417,27 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
         const f64x2 z01 = *reinterpret_cast<const f64x2*>(zr + 2 * lane);
         const f64x2 z23 = *reinterpret_cast<const f64x2*>(zr + 128 + 2 * lane);
         z[0] += z01.x; z[1] += z01.y; z[2] += z23.x; z[3] += z23.y;
-        const int J = J0 + (q >> 2), col = (q & 3) * 64 + w * 16;
-        double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16 + c) * SYM_TB + col + g;
-        if (c < kcols) {          // block columns beyond the k in use carry zeros nobody reads
+        if (c < zrows) {          // block columns beyond the k in use carry zeros nobody reads
+          double* zs = zst + (size_t)(((q >> 2) % zslots) * zrows + c) * ZS + (q & 3) * 64 + w * 16 + g;
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
+          for (int reg = 0; reg < 4; ++reg) zs[4 * reg] = z[reg];
         }
+      }
+      if ((q & 3) == 3 && ((q >> 2) + 1) % zslots == 0) {    // the stage is full
+        __syncthreads();
+        flush_tiles((q >> 2) + 1 - zslots, zslots);
+        __syncthreads();
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) b[u] = bn[u];
   };
-  const int nq_off = ((J1 - 1 == I ? J1 - 1 : J1) - J0) * 4;
   int q = 0;
   for (; q < nq_off; ++q) unit(std::true_type{}, q);
+  if ((nq_off >> 2) % zslots != 0) {   // what the stage still holds
+    __syncthreads();
+    flush_tiles((nq_off >> 2) - (nq_off >> 2) % zslots, (nq_off >> 2) % zslots);
+  }
   for (; q < nunits; ++q) unit(std::false_type{}, q);
 
   // end of the run: sum the direct partials over the four column groups, one 32-row half-step at a time
