@@ -322,12 +322,11 @@ def main():
         if args.free_n > 0:
             try:
                 fn = args.free_n
-                # symmetric generation keeps per-tile partial sums (N^2/2 bytes per 32 columns): beyond N ~ 600000 they
-                # do not fit next to nothing else, and the row-slab kernel (what several GPUs run anyway) is used
-                fstorage = storage if fn <= 500000 else "full"
+                fstorage = storage      # one GPU: every symmetric pair generated once (partial-sum slabs at N=10^6: 133 GB)
                 f = make_engine(fn, 8, 80, fstorage, gev=True)
                 f.set_hashed_operator(1, args.sparsity, seed=1)
                 f.set_identity(2)                                        # B = I as src/benchmark_free.f90:65-76
+                f.c.bench_apply2(16, 1)                                  # untimed: lazy workspace (partial-sum slabs) allocated
                 f.c.synchronize(); f.c.reset_stats()
                 dt_f, it_f, lam_f = timed_solves(f, "DPR", 1, args.tol)
                 sf = f.c.stats()

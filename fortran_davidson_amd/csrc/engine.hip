@@ -161,7 +161,16 @@ struct dav_engine {
   int* sym_items = nullptr;       // device: (I, J0, J1) per item
   int* sym_row_begin = nullptr;   // device: first item of each block row (nb + 1)
   double* sym_slab = nullptr;     // device: direct slabs (per item) followed by transposed slabs (per tile)
-  size_t sym_slabD_doubles = 0, sym_slab_doubles = 0;
+  size_t sym_slab_doubles = 0;    // grown on demand: what the largest launch so far needed (schedule x column groups)
+  bool sym_no_pair = false;       // paired 32-column launches did not fit the memory: 16 columns per launch
+  // super-row schedules (k_matvec_sym9.hip): plan p = 0 / 1 for R = 2 / 4 block rows per workgroup
+  struct SymPlan {
+    int R = 0, nitems = 0, nsuper = 0;
+    int64_t zslots = 0;               // transposed-partial slots: one per (super row, tile column below its last block row)
+    int* items = nullptr;             // device: (super row, J0, J1, slab slot) per item, longest first
+    int* row_begin = nullptr;         // device: first item of each super row (nsuper + 1)
+    int* zslot_begin = nullptr;       // device: first slot of each super row (nsuper + 1)
+  } sym_plan[2];
   SmallBuf sm[N_SMALL];
   size_t small_doubles = 0;
   ncclComm_t comm = nullptr;
@@ -405,6 +414,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->sym_items);
   hipFree(e->sym_row_begin);
   hipFree(e->sym_slab);
+  for (auto& pl : e->sym_plan) { hipFree(pl.items); hipFree(pl.row_begin); hipFree(pl.zslot_begin); }
   for (int i = 0; i < N_SMALL; ++i) {
     hipFree(e->sm[i].dev);
     if (e->sm[i].host) hipHostFree(e->sm[i].host);
@@ -647,6 +657,20 @@ static int refresh_diag_host(E* e, int which) {
   return 0;
 }
 
+// Block rows per workgroup of the symmetric sweep for a block of kk <= 16 columns: 4 (k <= 8), 2, or 1 (the
+// one-block-row kernel of k_matvec_sym.hip: small matrices, where super rows leave too few work items and too much
+// of the matrix in the masked diagonal super blocks).  DAV_SYM_R = 1 | 2 | 4 forces a schedule (4 only if k <= 8).
+static int sym_schedule(const E* e, int kk) {
+  const char* ev = getenv("DAV_SYM_R");                 // read per call: A/B runs flip it inside one process
+  const int forced = ev ? atoi(ev) : 0;
+  const int nb = (int)(e->nloc_pad / SYM_TB);
+  int R = nb >= 96 ? (kk <= 8 ? 4 : 2) : 1;
+  if (forced == 1 || forced == 2 || forced == 4) R = forced;
+  if (R == 4 && kk > 8) R = 2;
+  if (R > 1 && !matvec_sym_can_pair()) R = 1;          // DAV_SYM_V8=0: the one-wave-per-SIMD kernel, A/B runs only
+  return R;
+}
+
 static int sym_setup(E* e) {
   // work list of the symmetric sweep: runs of <= C consecutive tiles of one block row
   if (e->sym_items) return 0;
@@ -678,14 +702,58 @@ static int sym_setup(E* e) {
   HIPCHK(hipMalloc(&e->sym_row_begin, sizeof(int) * row_begin.size()));
   HIPCHK(hipMemcpy(e->sym_items, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(e->sym_row_begin, row_begin.data(), sizeof(int) * row_begin.size(), hipMemcpyHostToDevice));
-  e->sym_slabD_doubles = (size_t)e->sym_nitems * 32 * SYM_TB;                      // up to 32 block columns per pass
-  size_t slabT = (size_t)((int64_t)nb * (nb - 1) / 2) * 32 * SYM_TB;
-  e->sym_slab_doubles = e->sym_slabD_doubles + slabT;
-  hipError_t r = hipMalloc(&e->sym_slab, sizeof(double) * e->sym_slab_doubles);
+  // Super-row schedules: items = (super row of R block rows) x (run of C tile columns).  Per tile the schedule
+  // writes 1/R of a transposed and 1/C of a direct partial; C is bounded by the tail of the sweep (an item is
+  // R*C tiles long) and below by the number of items that keeps 256 workgroups busy.
+  for (int p = 0; p < 2; ++p) {
+    E::SymPlan& pl = e->sym_plan[p];
+    pl.R = p == 0 ? 2 : 4;
+    pl.nsuper = (nb + pl.R - 1) / pl.R;
+    int64_t Cp = std::min<int64_t>(64 / pl.R, std::max<int64_t>(1, (ntiles + 3071) / (3072 * pl.R)));
+    if (const char* ev = getenv("DAV_SYM_RUN9")) Cp = std::max(1, atoi(ev));
+    std::vector<Item> plist;
+    std::vector<int> prow(pl.nsuper + 1, 0), zbeg(pl.nsuper + 1, 0);
+    for (int S = 0; S < pl.nsuper; ++S) {
+      prow[S] = (int)plist.size();
+      const int Imax = std::min(S * pl.R + pl.R - 1, nb - 1);
+      for (int J0 = 0; J0 <= Imax; J0 += (int)Cp)
+        plist.push_back({S, J0, (int)std::min<int64_t>(Imax + 1, J0 + Cp), (int)plist.size()});
+      zbeg[S + 1] = zbeg[S] + Imax;                // tile columns J < Imax receive a transposed partial
+    }
+    prow[pl.nsuper] = (int)plist.size();
+    std::stable_sort(plist.begin(), plist.end(), [](const Item& a, const Item& b) { return a.J1 - a.J0 > b.J1 - b.J0; });
+    std::vector<int> pitems;
+    pitems.reserve(plist.size() * 4);
+    for (const Item& it : plist) { pitems.push_back(it.I); pitems.push_back(it.J0); pitems.push_back(it.J1); pitems.push_back(it.slot); }
+    pl.nitems = prow[pl.nsuper];
+    pl.zslots = zbeg[pl.nsuper];
+    HIPCHK(hipMalloc(&pl.items, sizeof(int) * pitems.size()));
+    HIPCHK(hipMalloc(&pl.row_begin, sizeof(int) * prow.size()));
+    HIPCHK(hipMalloc(&pl.zslot_begin, sizeof(int) * zbeg.size()));
+    HIPCHK(hipMemcpy(pl.items, pitems.data(), sizeof(int) * pitems.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pl.row_begin, prow.data(), sizeof(int) * prow.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(pl.zslot_begin, zbeg.data(), sizeof(int) * zbeg.size(), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+// Slabs of the symmetric sweep - per launch [column groups x direct partials][column groups x transposed partials] -
+// grown on demand to what the schedule and the number of column groups of a launch need: one transposed partial per
+// TILE for the one-block-row kernel (N=200000, 32 columns: 20 GB), per (super row, tile column) for the super-row
+// schedules (5-10 GB); N=10^6 matrix-free, 16 columns, R=2: 125 GB.
+static int sym_ensure_slabs(E* e, size_t doubles) {
+  if (doubles <= e->sym_slab_doubles) return 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->sym_slab) HIPCHK(hipFree(e->sym_slab));
+  e->sym_slab = nullptr;
+  e->sym_slab_doubles = 0;
+  hipError_t r = hipMalloc(&e->sym_slab, sizeof(double) * doubles);
   if (r != hipSuccess) {
     (void)hipGetLastError();
+    e->sym_slab = nullptr;
     return fail("hipMalloc of the symmetric sweep slabs failed: " + std::string(hipGetErrorString(r)));
   }
+  e->sym_slab_doubles = doubles;
   return 0;
 }
 
@@ -1000,29 +1068,49 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     // symmetric-tiled sweep: every off-diagonal tile read (or generated) once, used twice.  16 columns per workgroup; 32
     // columns per launch as paired workgroups that share their tile reads through the memory-side cache
     static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
-    const int step = (pair_env && matvec_sym_can_pair()) ? 32 : 16;
-    const int64_t dstride = (int64_t)e->sym_nitems * 16 * SYM_TB;
-    const int64_t tstride = (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
+    // pairing shares the READS of stored tiles: nothing to share when the entries are generated
+    int step = (pair_env && matvec_sym_can_pair() && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;
+      const int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, std::min(kk, 16));
+      const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
+      const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)e->sym_nitems * 16 * SYM_TB;
+      const int64_t tstride = R > 1 ? pl->zslots * 16 * SYM_TB : (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
+      if (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride)) != 0) {
+        if (npair < 2) return 1;
+        e->sym_no_pair = true;               // not enough memory for two column groups per launch: one at a time from here on
+        step = 16; kk = 16; npair = 1;
+        CHK(sym_ensure_slabs(e, (size_t)(dstride + tstride)));
+      }
       int slot = -1, kslot = -1;
       double bytes = (o.kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) : 0.0) + 16.0 * (double)e->n * kk;
       // end to end: everything that turns the source columns into W - packing, the sweep, the fixed-order sum
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
       launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
       if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk, &kslot));
-      double* slabT = e->sym_slab + e->sym_slabD_doubles;
+      double* slabT = e->sym_slab + (int64_t)npair * dstride;
+      if (R > 1) {
+        launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, o.a, o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n,
+                           e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, e->xt, kk, e->sym_slab, slabT, npair,
+                           e->xt_group_stride, dstride, tstride);
+      } else {
       if (o.kind != DAV_KIND_DENSE)
         launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
                                     e->xt_group_stride, dstride, tstride);
       else
         launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair, e->xt_group_stride,
                           dstride, tstride);
+      }
       CHK(timed_end(e, kslot));
-      for (int g = 0; g < npair; ++g)
-        launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, e->sym_nb, 1, e->nloc,
-                          std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+      for (int g = 0; g < npair; ++g) {
+        if (R > 1)
+          launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, R, e->sym_nb,
+                             e->nloc, std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+        else
+          launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, e->sym_nb, 1, e->nloc,
+                            std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+      }
       CHK(timed_end(e, slot));
       if (which == DAV_OP_A) {
         e->st.applies += 1;

@@ -98,6 +98,12 @@ void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const i
 bool matvec_sym_can_pair();
 void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, int nb,
                        int ngroups, int64_t nloc, int k, double* dst, int64_t ldd);
+// super-row schedules (k_matvec_sym9.hip): R = 2 or 4 block rows per workgroup, transposed partials summed on chip
+void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, OpParams op, int64_t n, int nb, const int* items_dev,
+                        int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int npair,
+                        int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
+void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,
+                        const int* zslot_begin_dev, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd);
 void launch_generate_sym_tiles(hipStream_t st, double* tiles, int64_t ntiles, int64_t n, uint64_t seed, double sparsity,
                                int use_diag, double diag_val);
 void launch_diag_sym(hipStream_t st, const double* tiles, int64_t n, double* diag);

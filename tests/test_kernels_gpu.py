@@ -276,10 +276,14 @@ def test_dense_matrix_from_device_memory(storage):
         assert np.array_equal(e.get_diagonal(OP_A), np.diag(A))
 
 
-@pytest.mark.parametrize("env", [{"DAV_SYM_V8": "0"}, {"DAV_SYM_PAIR": "0"}, {"DAV_SYM_RUN": "1"}, {"DAV_SYM_RUN": "7"}])
+@pytest.mark.parametrize("env", [{"DAV_SYM_V8": "0"}, {"DAV_SYM_PAIR": "0"}, {"DAV_SYM_RUN": "1"}, {"DAV_SYM_RUN": "7"},
+                                 {"DAV_SYM_R": "2"}, {"DAV_SYM_R": "4"}, {"DAV_SYM_R": "4", "DAV_SYM_RUN9": "1"},
+                                 {"DAV_SYM_R": "2", "DAV_SYM_RUN9": "3"}, {"DAV_SYM_R": "2", "DAV_SYM_PAIR": "0"}])
 def test_symmetric_sweep_alternative_kernels_and_schedules(env):
     """The A/B knobs of the symmetric sweep (one-wave-per-SIMD kernel, unpaired 16-column launches, other run
-    lengths) are read once per process, so each runs in a child process; same product, bit-reproducible."""
+    lengths, the super-row schedules with 2 / 4 block rows per workgroup that large matrices select by
+    themselves) are read once per process, so each runs in a child process; same product, bit-reproducible.
+    Orders cover 1..10 block rows: ragged super rows, diagonal super blocks, a single block row."""
     import os
     import subprocess
     import sys
@@ -287,7 +291,8 @@ def test_symmetric_sweep_alternative_kernels_and_schedules(env):
 import numpy as np
 import fortran_davidson_amd as fd
 from fortran_davidson_amd.engine_c import OP_A, PANEL_V, PANEL_W, PANEL_S
-for n, k in [(300, 8), (1300, 40), (2500, 64)]:
+from oracle import davidson_oracle as O
+for n, k in [(300, 8), (1300, 40), (2500, 64), (200, 3), (1300, 5), (1800, 8), (2305, 7), (2500, 16), (1030, 24)]:
     rng = np.random.default_rng(n + k)
     A = rng.standard_normal((n, n)); A = A + A.T
     X = rng.standard_normal((n, k))
@@ -301,6 +306,17 @@ for n, k in [(300, 8), (1300, 40), (2500, 64)]:
         assert np.abs(W - ref).max() <= 1e-12 * n * np.abs(ref).max(), (n, k)
         e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
         assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
+# the hashed operator generated in the sweep (every symmetric pair once) under the same schedule
+for n, k in [(700, 8), (1027, 17), (2500, 40), (1500, 4)]:
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=13)
+    X = np.random.default_rng(n).standard_normal((n, k))
+    with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
+        e.set_storage(1)
+        e.set_operator_hashed(OP_A, 13, 1e-2)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        ref = A @ X
+        assert np.abs(e.panel_get(PANEL_W, 0, k) - ref).max() <= 1e-12 * np.abs(ref).max(), (n, k)
 print("OK")
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -334,3 +350,30 @@ def test_hashed_operator_symmetric_generation_equals_the_dense_generator(n, k):
         e.panel_put(PANEL_V, 0, X)
         e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
         assert np.abs(e.panel_get(PANEL_W, 0, k) - A @ X).max() <= 1e-12 * np.abs(A @ X).max()
+
+
+@pytest.mark.parametrize("k", [8, 16, 40])
+def test_symmetric_super_row_schedules_at_a_size_that_selects_them(k):
+    """From 96 block rows on the sweep runs the super-row schedules (4 block rows per workgroup for k <= 8, else 2)
+    by itself: N=25000 (98 block rows, a ragged last super row), the same generated matrix in full storage
+    as the reference, stored tiles and the hashed operator generated in the sweep."""
+    n = 25000
+    X = np.random.default_rng(k).standard_normal((n, k))
+    with fd.CEngine(n=n, max_cols=48) as e:
+        e.set_dense_generated(OP_A, 5, 1e-3)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        ref = e.panel_get(PANEL_W, 0, k)
+    for generated in (False, True):
+        with fd.CEngine(n=n, max_cols=48) as e:
+            e.set_storage(1)
+            if generated:
+                e.set_operator_hashed(OP_A, 5, 1e-3)
+            else:
+                e.set_dense_generated(OP_A, 5, 1e-3)
+            e.panel_put(PANEL_V, 0, X)
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+            W = e.panel_get(PANEL_W, 0, k)
+            assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
+            assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
