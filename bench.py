@@ -111,15 +111,18 @@ def cpu_baseline(path, lowest, tol):
         return {"error": repr(exc)}
 
 
-def pmc_traffic(n, storage):
-    """HBM bytes per launch of the roofline kernel from a rocprofv3 PMC summary under profiles/ - an OFFLINE
-    figure (counters cannot be read from inside the run): collected with `rocprofv3 --pmc` on this command
-    at the commit the file names.  None when no summary matches the workload."""
+def pmc_traffic(n, storage, kernel, rank_by_grid):
+    """HBM bytes per launch of a roofline kernel from the rocprofv3 PMC summary under profiles/ - an OFFLINE figure
+    (counters cannot be read from inside the run): collected with `rocprofv3 --pmc` on this command at the commit the
+    file names (profiles/summarize.py).  `kernel` = name prefix; launches of one kernel are grouped by grid size
+    (column groups per launch) - rank_by_grid 0 = largest grid.  None when no summary matches the workload."""
     path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_n{n}_{storage}.json")
     try:
         with open(path) as f:
             doc = json.load(f)
-        return {"bytes_per_launch": doc["hbm_bytes_per_launch_corrected"], "kernel": doc.get("kernel"),
+        rows = sorted((k for k in doc["kernels"] if k["kernel"].startswith(kernel)), key=lambda k: -k["grid_size"])
+        row = rows[rank_by_grid]
+        return {"bytes_per_launch": row["hbm_bytes_per_launch_corrected"], "kernel": row["kernel"], "grid_size": row["grid_size"],
                 "source": os.path.relpath(path, ROOT), "collected_at_commit": doc.get("commit"),
                 "note": "offline rocprofv3 --pmc pass (2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), not measured in this run"}
     except Exception:      # noqa: BLE001
@@ -244,7 +247,7 @@ def main():
     kms = st.apply_kernel_ms / launches
     tflops = st.apply_flops / (st.apply_kernel_ms * 1e-3) / 1e12 if st.apply_kernel_ms > 0 else 0.0
     cols_per_launch = st.apply_cols / launches
-    kernel_name = "matvec_sym8_kernel<false> (K1s: symmetric-tiled sweep)" if storage == "symmetric" else "matvec_dense_kernel<NT> (K1: row slab)"
+    kernel_name = "matvec_sym9_kernel<R, false> (K1s: symmetric-tiled sweep, R block rows per workgroup: 2 in the solve, 4 at k <= 8)" if storage == "symmetric" else "matvec_dense_kernel<NT> (K1: row slab)"
     hbm_in_solve = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
     mfma_bound = cols_per_launch > 16
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kernel_name,
@@ -252,7 +255,7 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBPS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound
                         else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "traffic": pmc_traffic(n, storage) if world == 1 else None,
+                "traffic": pmc_traffic(n, storage, "matvec_sym9_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", 0) if world == 1 else None,
                 "launches": launches, "avg_launch_ms": round(kms, 4), "columns_per_launch": round(cols_per_launch, 1),
                 "flops_per_launch": round(st.apply_flops / launches, 0),
                 "algorithmic_bytes_per_launch": round(st.apply_bytes / max(st.applies, 1) , 0),
@@ -270,7 +273,8 @@ def main():
                     "achieved": a8["GBps_end_to_end"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a8["frac_of_8TBps_end_to_end"],
                     "achieved_kernel_only": a8["GBps_kernel_only"], "frac_kernel_only": a8["frac_of_8TBps_kernel_only"],
                     "ms_end_to_end": a8["ms_end_to_end"], "ms_kernel_only": a8["ms_kernel_only"],
-                    "algorithmic_bytes_per_launch": a8["algorithmic_bytes"], "traffic": None,
+                    "algorithmic_bytes_per_launch": a8["algorithmic_bytes"],
+                    "traffic": pmc_traffic(n, storage, "matvec_sym9_kernel<4", 0) if (world == 1 and storage == "symmetric") else None,
                     "note": "bytes = 8*S + 16*N*k, S = N(N+1)/2 (symmetric-tiled) or nloc*N (row slab); end to end = "
                             "pack_xt + sweep kernel + fixed-order reduction of the partial sums (HIP events on the engine's stream)"}
 
