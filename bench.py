@@ -7,9 +7,9 @@
 A "step" is one complete `generalized_eigensolver` solve (Fortran driver loop on the HIP engine) of the
 largest BASELINE.json configuration that fits one GPU: configs[2] = N=200000 dense fp64, lowest=16, DPR,
 subspace restart at 80 (max_dim_sub=80), tol=1e-8, generate_diagonal_dominant(N, 1e-3).  The matrix is
-generated in HBM before the timed region and stays resident: one GPU keeps its lower block triangle
-(symmetric-tiled storage, 160 GB), several GPUs keep full row slabs (N*N/P entries each) and exchange the
-new basis block with an RCCL all-gather inside libdavidson_hip.so; torch.distributed (gloo) is only the
+generated in HBM before the timed region and stays resident as its lower block triangle (symmetric-tiled
+storage, 160 GB); several GPUs deal the block rows out among themselves (N*N/2P entries each), all-gather the
+new basis block and reduce-scatter the partial products with RCCL inside libdavidson_hip.so; torch.distributed (gloo) is only the
 control plane (unique-id broadcast, barriers, max-over-ranks of the time).  value = Davidson iterations
 per second over the K timed solves (strong scaling: the problem is the same for every N).
 
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--max-dim", type=int, default=80)
     ap.add_argument("--sparsity", type=float, default=1e-3)
     ap.add_argument("--tol", type=float, default=1e-8)
-    ap.add_argument("--storage", default="auto", help="auto = symmetric tiles on one GPU, full row slabs on several")
+    ap.add_argument("--storage", default="auto", help="auto = symmetric tiles (one GPU, or dealt out over the ranks); full = full row slabs")
     ap.add_argument("--small-n", type=int, default=20000, help="order of the configs[1] leg (0 = skip)")
     ap.add_argument("--gjd-n", type=int, default=-1, help="order of the configs[3] leg (-1 = same as --order, 0 = skip)")
     ap.add_argument("--free-n", type=int, default=1000000, help="order of the configs[4] leg (0 = skip)")
@@ -224,8 +224,10 @@ def main():
                             "algorithmic_bytes": nbytes}
         return out
 
-    storage = args.storage if args.storage != "auto" else ("symmetric" if world == 1 else "full")
-    storage_words = {"symmetric": "symmetric-tiled (lower block triangle, N(N+1)/2 entries)", "full": "full row slabs"}[storage]
+    storage = args.storage if args.storage != "auto" else "symmetric"
+    storage_words = {"symmetric": "symmetric-tiled (lower block triangle, N(N+1)/2 entries" +
+                                  (f", dealt out over the {world} ranks by groups of 4 block rows" if world > 1 else "") + ")",
+                     "full": "full row slabs"}[storage]
 
     # ---- the timed workload: configs[2] ---------------------------------------------------------------
     n, lowest, max_dim = args.n, args.lowest, args.max_dim
@@ -425,7 +427,7 @@ def main():
                 "config": {"workload": f"N={n} dense fp64, lowest={lowest}, DPR, max_dim_sub={max_dim} (subspace restart at {max_dim}), "
                                        f"tol={args.tol}, generate_diagonal_dominant(N,{args.sparsity}) seed 1, storage: {storage_words}",
                            "N": n, "lowest": lowest, "max_dim_sub": max_dim, "storage": storage,
-                           "iters_per_solve": total_iters // args.steps, "parallelism": f"row-slab x{world}" if world > 1 else "single GPU",
+                           "iters_per_solve": total_iters // args.steps, "parallelism": (f"block rows of the lower triangle over {world} GPUs, row slabs of the panels" if storage == "symmetric" else f"row-slab x{world}") if world > 1 else "single GPU",
                            "generate_seconds": round(t_gen, 2)},
                 "eigenvalues": [float(x) for x in lam[:3]],
                 "roofline": roofline, "roofline_hbm": roofline_hbm, "apply": apply_k}

@@ -51,6 +51,7 @@ struct Rccl {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -70,6 +71,7 @@ static int rccl_load() {
   SYM(AllGather, "ncclAllGather")
   SYM(AllReduce, "ncclAllReduce")
   SYM(Broadcast, "ncclBroadcast")
+  SYM(ReduceScatter, "ncclReduceScatter")
   SYM(GroupStart, "ncclGroupStart")
   SYM(GroupEnd, "ncclGroupEnd")
   SYM(GetErrorString, "ncclGetErrorString")
@@ -163,6 +165,14 @@ struct dav_engine {
   double* sym_slab = nullptr;     // device: direct slabs (per item) followed by transposed slabs (per tile)
   size_t sym_slab_doubles = 0;    // grown on demand: what the largest launch so far needed (schedule x column groups)
   bool sym_no_pair = false;       // paired 32-column launches did not fit the memory: 16 columns per launch
+  // Several ranks: the lower block triangle is dealt out by groups of 4 block rows (what every schedule's super rows
+  // nest in), boustrophedon over the ranks so that the long block rows spread evenly.  row_off[I] = first tile of
+  // block row I in this rank's storage, -1 = another rank's.
+  std::vector<int64_t> sym_row_off_h;
+  int64_t* sym_row_off = nullptr; // device copy
+  int64_t sym_ntiles_local = 0;
+  double* sym_wpart = nullptr;    // several ranks: this rank's partial of the whole product, [rank][column][row of its slab]
+  double* sym_wrecv = nullptr;    // ... and the summed chunk the reduce-scatter hands back (nslab x 32)
   // super-row schedules (k_matvec_sym9.hip): plan p = 0 / 1 for R = 2 / 4 block rows per workgroup
   struct SymPlan {
     int R = 0, nitems = 0, nsuper = 0;
@@ -346,7 +356,7 @@ static int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int r
   e->row0 = (int64_t)rank * e->nslab;
   e->nloc = std::max<int64_t>(0, std::min<int64_t>(e->nslab, n - e->row0));
   e->nloc_pad = roundup(e->nslab, MV_ROWS);
-  e->ncols_pad = roundup((int64_t)nranks * e->nslab, 64);
+  e->ncols_pad = roundup((int64_t)nranks * e->nslab, SYM_TB);   // whole 256-row blocks: the symmetric sweeps index Xt by tile
   e->ldp = e->nloc_pad;
   e->st.n = n;
   e->st.nloc = e->nloc;
@@ -414,6 +424,9 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->sym_items);
   hipFree(e->sym_row_begin);
   hipFree(e->sym_slab);
+  hipFree(e->sym_row_off);
+  hipFree(e->sym_wpart);
+  hipFree(e->sym_wrecv);
   for (auto& pl : e->sym_plan) { hipFree(pl.items); hipFree(pl.row_begin); hipFree(pl.zslot_begin); }
   for (int i = 0; i < N_SMALL; ++i) {
     hipFree(e->sm[i].dev);
@@ -569,6 +582,43 @@ static int coll_allreduce(E* e, double* buf, size_t count) {
   return 0;
 }
 
+// recv[0 .. count) = sum over ranks p of send_p[rank*count .. (rank+1)*count)  (send holds nranks chunks)
+static int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
+  if (e->lg) {
+    LocalGroup* g = e->lg;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    g->send[e->rank] = send;
+    pthread_barrier_wait(&g->bar);
+    std::vector<double> sum(count, 0.0), tmp(count);
+    for (int p = 0; p < g->n; ++p) {                  // rank order: reproducible
+      HIPCHK(hipMemcpy(tmp.data(), g->send[p] + (size_t)e->rank * count, sizeof(double) * count, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < count; ++i) sum[i] += tmp[i];
+    }
+    pthread_barrier_wait(&g->bar);
+    HIPCHK(hipMemcpy(recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
+  if (e->shm) {
+    ShmGroup* g = e->shm;
+    if (count * (size_t)e->nranks > g->hdr->slot_doubles)
+      return fail("shared-memory transport: reduce-scatter message larger than a slot (test transport: small orders only)");
+    HIPCHK(hipMemcpyAsync(g->slots + (size_t)e->rank * g->hdr->slot_doubles, send, sizeof(double) * count * e->nranks,
+                          hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
+    std::vector<double> sum(count, 0.0);
+    for (int p = 0; p < e->nranks; ++p) {
+      const double* src = g->slots + (size_t)p * g->hdr->slot_doubles + (size_t)e->rank * count;
+      for (size_t i = 0; i < count; ++i) sum[i] += src[i];
+    }
+    pthread_barrier_wait(&g->hdr->bar);
+    HIPCHK(hipMemcpy(recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
+  NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
+  return 0;
+}
+
 static void shm_release(E* e) {
   ShmGroup* g = e->shm;
   if (!g) return;
@@ -584,6 +634,8 @@ extern "C" int dav_comm_init_shm(dav_handle_t e, const char* name) {
   if (e->nranks == 1) return 0;
   // one slot holds the largest message: an all-gathered slab block (nslab x 16) or a small result matrix
   size_t slot = std::max<size_t>((size_t)e->nslab * 16, std::max(e->gram_doubles, (size_t)e->ncols_pad));
+  if ((size_t)e->ncols_pad * 32 * sizeof(double) * e->nranks <= ((size_t)1 << 30))     // symmetric storage: the partial products
+    slot = std::max(slot, (size_t)e->ncols_pad * 32);
   size_t bytes = sizeof(ShmHeader) + 64 + sizeof(double) * slot * (size_t)e->nranks;
   ShmGroup* g = new ShmGroup();
   g->name = name;
@@ -663,7 +715,7 @@ static int refresh_diag_host(E* e, int which) {
 static int sym_schedule(const E* e, int kk) {
   const char* ev = getenv("DAV_SYM_R");                 // read per call: A/B runs flip it inside one process
   const int forced = ev ? atoi(ev) : 0;
-  const int nb = (int)(e->nloc_pad / SYM_TB);
+  const int nb = (int)(e->ncols_pad / SYM_TB);          // block rows of the whole matrix
   int R = nb >= 96 ? (kk <= 8 ? 4 : 2) : 1;
   if (forced == 1 || forced == 2 || forced == 4) R = forced;
   if (R == 4 && kk > 8) R = 2;
@@ -671,11 +723,25 @@ static int sym_schedule(const E* e, int kk) {
   return R;
 }
 
+// owner of the group of 4 block rows q: boustrophedon over the ranks (0 1 .. P-1 P-1 .. 1 0 0 1 ..)
+static int sym_group_owner(int q, int nranks) {
+  const int cyc = q / nranks, pos = q % nranks;
+  return (cyc & 1) ? nranks - 1 - pos : pos;
+}
+
 static int sym_setup(E* e) {
-  // work list of the symmetric sweep: runs of <= C consecutive tiles of one block row
+  // work lists of the symmetric sweep over the block rows THIS rank stores
   if (e->sym_items) return 0;
-  int nb = (int)(e->nloc_pad / SYM_TB);
-  int64_t ntiles = (int64_t)nb * (nb + 1) / 2;
+  const int nb = (int)(e->ncols_pad / SYM_TB);
+  e->sym_row_off_h.assign(nb, -1);
+  int64_t ntiles = 0;
+  for (int I = 0; I < nb; ++I)
+    if (sym_group_owner(I / 4, e->nranks) == e->rank) { e->sym_row_off_h[I] = ntiles; ntiles += I + 1; }
+  e->sym_ntiles_local = ntiles;
+  HIPCHK(hipMalloc(&e->sym_row_off, sizeof(int64_t) * nb));
+  HIPCHK(hipMemcpy(e->sym_row_off, e->sym_row_off_h.data(), sizeof(int64_t) * nb, hipMemcpyHostToDevice));
+  auto owned = [&](int I) { return e->sym_row_off_h[I] >= 0; };
+  // One-block-row kernel: runs of <= C consecutive tiles of one block row.
   // Run length: ~12 rounds of the 256 resident workgroups, between 4 tiles (a workgroup costs ~7 us to start
   // and drain) and 32 (the tail of the sweep is at most one run long).  Slab slots stay in block-row order
   // (the reduction kernel walks them per block row); the dispatch order is longest run first, so the
@@ -688,14 +754,16 @@ static int sym_setup(E* e) {
   std::vector<int> row_begin(nb + 1, 0);
   for (int I = 0; I < nb; ++I) {
     row_begin[I] = (int)list.size();
+    if (!owned(I)) continue;
     for (int J0 = 0; J0 <= I; J0 += (int)C)
       list.push_back({I, J0, (int)std::min<int64_t>(I + 1, J0 + C), (int)list.size()});
   }
   row_begin[nb] = (int)list.size();
   std::stable_sort(list.begin(), list.end(), [](const Item& a, const Item& b) { return a.J1 - a.J0 > b.J1 - b.J0; });
   std::vector<int> items;
-  items.reserve(list.size() * 4);
+  items.reserve(list.size() * 4 + 4);
   for (const Item& it : list) { items.push_back(it.I); items.push_back(it.J0); items.push_back(it.J1); items.push_back(it.slot); }
+  items.resize(std::max<size_t>(items.size(), 4), 0);
   e->sym_nb = nb;
   e->sym_nitems = row_begin[nb];
   HIPCHK(hipMalloc(&e->sym_items, sizeof(int) * items.size()));
@@ -715,6 +783,8 @@ static int sym_setup(E* e) {
     std::vector<int> prow(pl.nsuper + 1, 0), zbeg(pl.nsuper + 1, 0);
     for (int S = 0; S < pl.nsuper; ++S) {
       prow[S] = (int)plist.size();
+      zbeg[S + 1] = zbeg[S];
+      if (!owned(S * pl.R)) continue;                // a super row nests in a group of 4 block rows: one owner
       const int Imax = std::min(S * pl.R + pl.R - 1, nb - 1);
       for (int J0 = 0; J0 <= Imax; J0 += (int)Cp)
         plist.push_back({S, J0, (int)std::min<int64_t>(Imax + 1, J0 + Cp), (int)plist.size()});
@@ -723,8 +793,9 @@ static int sym_setup(E* e) {
     prow[pl.nsuper] = (int)plist.size();
     std::stable_sort(plist.begin(), plist.end(), [](const Item& a, const Item& b) { return a.J1 - a.J0 > b.J1 - b.J0; });
     std::vector<int> pitems;
-    pitems.reserve(plist.size() * 4);
+    pitems.reserve(plist.size() * 4 + 4);
     for (const Item& it : plist) { pitems.push_back(it.I); pitems.push_back(it.J0); pitems.push_back(it.J1); pitems.push_back(it.slot); }
+    pitems.resize(std::max<size_t>(pitems.size(), 4), 0);
     pl.nitems = prow[pl.nsuper];
     pl.zslots = zbeg[pl.nsuper];
     HIPCHK(hipMalloc(&pl.items, sizeof(int) * pitems.size()));
@@ -734,6 +805,25 @@ static int sym_setup(E* e) {
     HIPCHK(hipMemcpy(pl.row_begin, prow.data(), sizeof(int) * prow.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pl.zslot_begin, zbeg.data(), sizeof(int) * zbeg.size(), hipMemcpyHostToDevice));
   }
+  if (e->nranks > 1) {
+    HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
+    HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
+  }
+  return 0;
+}
+
+// diagonal of a stored symmetric-tiled operator -> o.diag (this rank's rows); with several ranks the diagonal tiles
+// live where their block rows do: every rank contributes its pieces, one all-reduce of n doubles at set-up
+static int coll_allreduce(E* e, double* buf, size_t count);
+static int sym_diag(E* e, OpDesc& o) {
+  if (e->nranks == 1) {
+    launch_diag_sym(e->stream, o.a, e->sym_row_off, e->n, e->nloc_pad, o.diag);
+    return 0;
+  }
+  if (!(e->comm || e->lg || e->shm)) return fail("multi-rank engine used before dav_comm_init");
+  launch_diag_sym(e->stream, o.a, e->sym_row_off, e->n, e->ncols_pad, e->gather_dev);
+  CHK(coll_allreduce(e, e->gather_dev, (size_t)e->ncols_pad));
+  HIPCHK(hipMemcpyAsync(o.diag, e->gather_dev + e->row0, sizeof(double) * (size_t)e->nslab, hipMemcpyDeviceToDevice, e->stream));
   return 0;
 }
 
@@ -764,8 +854,8 @@ static int alloc_dense(E* e, int which) {
   if (!o.a) {
     size_t bytes;
     if (o.storage == 1) {
-      int64_t nb = e->nloc_pad / SYM_TB;
-      bytes = sizeof(double) * (size_t)(nb * (nb + 1) / 2) * SYM_TB * SYM_TB;
+      CHK(sym_setup(e));
+      bytes = sizeof(double) * (size_t)std::max<int64_t>(e->sym_ntiles_local, 1) * SYM_TB * SYM_TB;
     } else {
       bytes = sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
     }
@@ -781,7 +871,6 @@ static int alloc_dense(E* e, int which) {
 
 extern "C" int dav_set_storage(dav_handle_t e, int mode) {
   if (mode != 0 && mode != 1) return fail("dav_set_storage: mode must be 0 (full) or 1 (symmetric-tiled)");
-  if (mode == 1 && e->nranks != 1) return fail("dav_set_storage: symmetric-tiled storage needs a single rank (row slabs use full storage)");
   e->storage = mode;
   return 0;
 }
@@ -795,17 +884,19 @@ static int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemc
   if (o.storage == 1) {
     // lower block triangle, tile by tile (edge tiles zero padded)
     int nb = e->sym_nb;
-    HIPCHK(hipMemsetAsync(o.a, 0, sizeof(double) * (size_t)((int64_t)nb * (nb + 1) / 2) * SYM_TB * SYM_TB, e->stream));
-    for (int I = 0; I < nb; ++I)
+    HIPCHK(hipMemsetAsync(o.a, 0, sizeof(double) * (size_t)e->sym_ntiles_local * SYM_TB * SYM_TB, e->stream));
+    for (int I = 0; I < nb; ++I) {
+      if (e->sym_row_off_h[I] < 0) continue;             // block row of another rank
       for (int J = 0; J <= I; ++J) {
         int64_t r0 = (int64_t)I * SYM_TB, c0 = (int64_t)J * SYM_TB;
         int64_t nr = std::min<int64_t>(SYM_TB, e->n - r0), nc = std::min<int64_t>(SYM_TB, e->n - c0);
         if (nr <= 0 || nc <= 0) continue;
-        double* tile = o.a + ((int64_t)I * (I + 1) / 2 + J) * (int64_t)(SYM_TB * SYM_TB);
+        double* tile = o.a + (e->sym_row_off_h[I] + J) * (int64_t)(SYM_TB * SYM_TB);
         HIPCHK(hipMemcpy2DAsync(tile, sizeof(double) * SYM_TB, a + r0 + c0 * lda, sizeof(double) * lda, sizeof(double) * nr,
                                 (size_t)nc, kind, e->stream));
       }
-    launch_diag_sym(e->stream, o.a, e->n, o.diag);
+    }
+    CHK(sym_diag(e, o));
     CHK(refresh_diag_host(e, which));
     return 0;
   }
@@ -844,7 +935,7 @@ extern "C" int dav_dense_begin(dav_handle_t e, int which) {
   CHK(alloc_dense(e, which));
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_DENSE;
-  size_t bytes = o.storage == 1 ? sizeof(double) * (size_t)((int64_t)e->sym_nb * (e->sym_nb + 1) / 2) * SYM_TB * SYM_TB
+  size_t bytes = o.storage == 1 ? sizeof(double) * (size_t)e->sym_ntiles_local * SYM_TB * SYM_TB
                                 : sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
   HIPCHK(hipMemsetAsync(o.a, 0, bytes, e->stream));
   // ~128 MiB per staging buffer, whole rows, at least 32 of them
@@ -878,7 +969,7 @@ static int ingest_commit(E* e, int64_t row0, int64_t nrows) {
   OpDesc& o = e->op[e->ing_which];
   int b = e->ing_flip;
   HIPCHK(hipMemcpyAsync(e->ing_dev[b], e->ing_host[b], sizeof(double) * (size_t)(nrows * e->n), hipMemcpyHostToDevice, e->stream));
-  launch_rows_scatter(e->stream, e->ing_dev[b], e->n, row0, nrows, e->n, o.a, e->nloc_pad, e->row0, e->nloc, o.storage == 1);
+  launch_rows_scatter(e->stream, e->ing_dev[b], e->n, row0, nrows, e->n, o.a, e->nloc_pad, e->row0, e->nloc, o.storage == 1, e->sym_row_off);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ing_done[b], e->stream));
   e->ing_pending[b] = true;
@@ -925,9 +1016,10 @@ extern "C" int dav_dense_end(dav_handle_t e, int which) {
   if (e->ing_which != which) return fail("dav_dense_end: no streaming upload open for this operator");
   CHK(bind(e));
   OpDesc& o = e->op[which];
-  if (o.storage == 1) launch_diag_sym(e->stream, o.a, e->n, o.diag);
+  int rc = 0;
+  if (o.storage == 1) rc = sym_diag(e, o);
   else launch_diag_dense(e->stream, o.a, e->nloc_pad, e->row0, e->nloc, o.diag);
-  int rc = refresh_diag_host(e, which);
+  if (rc == 0) rc = refresh_diag_host(e, which);
   ingest_release(e);
   return rc;
 }
@@ -976,8 +1068,8 @@ extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed,
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_DENSE;
   if (o.storage == 1) {
-    launch_generate_sym_tiles(e->stream, o.a, (int64_t)e->sym_nb * (e->sym_nb + 1) / 2, e->n, seed, sparsity, use_diag_val, diag_val);
-    launch_diag_sym(e->stream, o.a, e->n, o.diag);
+    launch_generate_sym_tiles(e->stream, o.a, e->sym_row_off_h.data(), e->sym_nb, e->n, seed, sparsity, use_diag_val, diag_val);
+    CHK(sym_diag(e, o));
   } else {
     launch_generate_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->row0, e->nloc, e->n, seed, sparsity,
                           use_diag_val, diag_val);
@@ -1002,7 +1094,7 @@ extern "C" int dav_set_operator_hashed(dav_handle_t e, int which, uint64_t seed,
   o.kind = DAV_KIND_HASHED; o.seed = seed; o.sparsity = sparsity; o.use_diag = use_diag_val; o.diag_val = diag_val;
   // storage mode "symmetric" (single rank) also applies to the generated operator: every entry of the lower
   // block triangle is produced once and used for both products
-  o.storage = (e->storage == 1 && e->nranks == 1) ? 1 : 0;
+  o.storage = e->storage == 1 ? 1 : 0;
   if (o.storage == 1) CHK(sym_setup(e));
   launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
   CHK(refresh_diag_host(e, which));
@@ -1014,7 +1106,7 @@ extern "C" int dav_set_operator_harness(dav_handle_t e, int which, const double*
   CHK(bind(e));
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_HARNESS; o.trig = which == DAV_OP_A ? 0 : 1;
-  o.storage = (e->storage == 1 && e->nranks == 1) ? 1 : 0;      // symmetric mode: each entry generated once
+  o.storage = e->storage == 1 ? 1 : 0;      // symmetric mode: each entry generated once
   if (o.storage == 1) CHK(sym_setup(e));
   if (!o.e_table) HIPCHK(hipMalloc(&o.e_table, sizeof(double) * e->n));
   HIPCHK(hipMemcpyAsync(o.e_table, e_table, sizeof(double) * e->n, hipMemcpyHostToDevice, e->stream));
@@ -1066,10 +1158,15 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
   CHK(need_comm(e));
   if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS) && o.storage == 1) {
     // symmetric-tiled sweep: every off-diagonal tile read (or generated) once, used twice.  16 columns per workgroup; 32
-    // columns per launch as paired workgroups that share their tile reads through the memory-side cache
+    // columns per launch as paired workgroups that share their tile reads through the memory-side cache.
+    // Several ranks: each sweeps the block rows it stores against the all-gathered block and holds a partial of the
+    // WHOLE product; one reduce-scatter per 16 columns sums the partials and leaves every rank its row slab.
     static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
     // pairing shares the READS of stored tiles: nothing to share when the entries are generated
     int step = (pair_env && matvec_sym_can_pair() && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
+    const bool multi = e->nranks > 1;
+    const int64_t* owned = multi ? e->sym_row_off : nullptr;
+    const int64_t total_rows = (int64_t)e->nranks * e->nslab;
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;
@@ -1077,39 +1174,67 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
       const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)e->sym_nitems * 16 * SYM_TB;
       const int64_t tstride = R > 1 ? pl->zslots * 16 * SYM_TB : (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
-      if (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride)) != 0) {
+      if (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride) + 1) != 0) {
         if (npair < 2) return 1;
         e->sym_no_pair = true;               // not enough memory for two column groups per launch: one at a time from here on
         step = 16; kk = 16; npair = 1;
-        CHK(sym_ensure_slabs(e, (size_t)(dstride + tstride)));
+        CHK(sym_ensure_slabs(e, (size_t)(dstride + tstride) + 1));
       }
-      int slot = -1, kslot = -1;
-      double bytes = (o.kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) : 0.0) + 16.0 * (double)e->n * kk;
-      // end to end: everything that turns the source columns into W - packing, the sweep, the fixed-order sum
+      int slot = -1, kslot = -1, cslot = -1;
+      const double stored = o.kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
+      double bytes = stored + 16.0 * (double)e->n * kk;
+      // end to end: everything that turns the source columns into W - packing, (all-gather,) the sweep, the fixed-order sum(, reduce-scatter)
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
       launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
-      if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk, &kslot));
+      if (multi) {
+        CHK(timed_begin(e, 3, 0, &cslot));
+        if (e->comm) NCCLCHK(g_rccl.GroupStart());
+        for (int g = 0; g < npair; ++g) {
+          double* base = e->xt + g * e->xt_group_stride;
+          CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
+        }
+        if (e->comm) NCCLCHK(g_rccl.GroupEnd());
+        CHK(timed_end(e, cslot));
+      }
+      if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
       double* slabT = e->sym_slab + (int64_t)npair * dstride;
-      if (R > 1) {
-        launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, o.a, o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n,
-                           e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, e->xt, kk, e->sym_slab, slabT, npair,
-                           e->xt_group_stride, dstride, tstride);
-      } else {
-      if (o.kind != DAV_KIND_DENSE)
-        launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
-                                    e->xt_group_stride, dstride, tstride);
-      else
-        launch_matvec_sym(e->stream, o.a, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair, e->xt_group_stride,
-                          dstride, tstride);
+      const int nitems = R > 1 ? pl->nitems : e->sym_nitems;
+      if (nitems > 0) {                      // a rank can be left without a block row (more ranks than groups of block rows)
+        if (R > 1)
+          launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, o.a, e->sym_row_off, o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{},
+                             e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, e->xt, kk, e->sym_slab, slabT, npair,
+                             e->xt_group_stride, dstride, tstride);
+        else if (o.kind != DAV_KIND_DENSE)
+          launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
+                                      e->xt_group_stride, dstride, tstride);
+        else
+          launch_matvec_sym(e->stream, o.a, e->sym_row_off, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
+                            e->xt_group_stride, dstride, tstride);
       }
       CHK(timed_end(e, kslot));
       for (int g = 0; g < npair; ++g) {
+        const int kg = std::min(16, kk - 16 * g);
+        double* out = multi ? e->sym_wpart + (size_t)g * (size_t)total_rows * 16 : dst + (int64_t)(c + 16 * g) * e->ldp;
         if (R > 1)
-          launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, R, e->sym_nb,
-                             e->nloc, std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+          launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, owned, R, e->sym_nb,
+                             e->nloc, kg, out, e->ldp, multi ? e->nslab : 0, total_rows);
         else
-          launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, e->sym_nb, 1, e->nloc,
-                            std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+          launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, owned, e->sym_nb, e->nloc, kg,
+                            out, e->ldp, multi ? e->nslab : 0, total_rows);
+      }
+      if (multi) {
+        CHK(timed_begin(e, 3, 0, &cslot));
+        if (e->comm) NCCLCHK(g_rccl.GroupStart());
+        for (int g = 0; g < npair; ++g) {
+          const int kg = std::min(16, kk - 16 * g);
+          CHK(coll_reduce_scatter(e, e->sym_wpart + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16,
+                                  (size_t)e->nslab * kg));
+        }
+        if (e->comm) NCCLCHK(g_rccl.GroupEnd());
+        CHK(timed_end(e, cslot));
+        for (int g = 0; g < npair; ++g)
+          launch_chunk_to_panel(e->stream, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad,
+                                std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
       }
       CHK(timed_end(e, slot));
       if (which == DAV_OP_A) {
@@ -1269,9 +1394,9 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
   for (int w = 0; w < (e->gev ? 2 : 1); ++w) {
     OpDesc& o = e->op[w];
     int dst = w == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
-    if (o.kind == DAV_KIND_DENSE && o.storage == 1)
-      launch_gather_columns_sym(e->stream, o.a, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
-    else if (o.kind == DAV_KIND_DENSE)
+    if (o.kind == DAV_KIND_DENSE && o.storage == 1 && e->nranks == 1)
+      launch_gather_columns_sym(e->stream, o.a, e->sym_row_off, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
+    else if (o.kind == DAV_KIND_DENSE && o.storage == 0)
       launch_gather_columns(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
     else if (o.kind == DAV_KIND_HOST) {
       /* the driver fills W / BV through dav_panel_put */
@@ -1484,9 +1609,23 @@ extern "C" int dav_panel_get(dav_handle_t e, int panel, int c0, int k, double* o
     return 0;
   }
   CHK(need_comm(e));
-  for (int j = 0; j < k; ++j) {
-    CHK(coll_allgather(e, panel_ptr(e, panel, c0 + j), e->gather_dev, (size_t)e->nslab));
-    HIPCHK(hipMemcpyAsync(out + j * ld, e->gather_dev, sizeof(double) * e->n, hipMemcpyDeviceToHost, e->stream));
+  // ONE all-gather per batch of columns: the slabs go out as a contiguous nslab x kb block ([rank][column][row] on
+  // arrival), in batches the staging buffer holds
+  int kmax = (int)std::max<size_t>(1, e->scratch_doubles / ((size_t)e->nranks * (size_t)e->nslab));
+  if (e->shm) kmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)kmax, e->shm->hdr->slot_doubles / (size_t)e->nslab));
+  for (int j0 = 0; j0 < k; j0 += kmax) {
+    const int kb = std::min(kmax, k - j0);
+    const size_t chunk = (size_t)e->nslab * kb;
+    double* mine = e->scratch + (size_t)e->rank * chunk;
+    HIPCHK(hipMemcpy2DAsync(mine, sizeof(double) * e->nslab, panel_ptr(e, panel, c0 + j0), sizeof(double) * e->ldp,
+                            sizeof(double) * e->nslab, (size_t)kb, hipMemcpyDeviceToDevice, e->stream));
+    CHK(coll_allgather(e, mine, e->scratch, chunk));
+    for (int p = 0; p < e->nranks; ++p) {
+      const int64_t r0 = (int64_t)p * e->nslab, nr = std::min<int64_t>(e->nslab, e->n - r0);
+      if (nr <= 0) break;
+      HIPCHK(hipMemcpy2DAsync(out + (int64_t)j0 * ld + r0, sizeof(double) * ld, e->scratch + (size_t)p * chunk, sizeof(double) * e->nslab,
+                              sizeof(double) * nr, (size_t)kb, hipMemcpyDeviceToHost, e->stream));
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
   }
   return 0;

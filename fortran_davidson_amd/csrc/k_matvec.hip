@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t r
   const int64_t gr0 = row0 + (int64_t)blockIdx.x * MV_ROWS;
   const bool rows_inside = (int64_t)(blockIdx.x + 1) * MV_ROWS <= nloc;
   if (KIND == DAV_KIND_HASHED && rows_inside) {
-    const int64_t jn = j1 < n ? j1 : (n / 4 * 4);                       // columns [jn, j1) may cross the matrix edge
+    int64_t jn = j1 < n ? j1 : (n / 4 * 4);                             // columns [jn, j1) may cross the matrix edge
+    if (jn < j0) jn = j0;                                               // a column chunk that lies wholly in the padding
     int64_t jlo = gr0 / 4 * 4;                                          // first column step that can touch the diagonal band
     int64_t jhi = (gr0 + MV_ROWS + 3) / 4 * 4;                          // first column step strictly above it
     jlo = jlo < j0 ? j0 : (jlo > jn ? jn : jlo);

@@ -42,16 +42,18 @@
 #include <cstdlib>
 #include <type_traits>
 
-// tile (I, J), J <= I, at tiles + (I (I+1)/2 + J) * TB*TB, column-major with leading dimension TB
-__device__ __forceinline__ const double* sym_tile(const double* tiles, int I, int J) {
-  return tiles + ((int64_t)I * (I + 1) / 2 + J) * (int64_t)(SYM_TB * SYM_TB);
+// tile (I, J), J <= I, at tiles + (row_off[I] + J) * TB*TB, column-major with leading dimension TB.  row_off[I] = first
+// tile of block row I in THIS rank's storage: I (I+1)/2 on a single rank; with several ranks only the block rows a rank
+// owns are stored (the others carry -1 and are never addressed)
+__device__ __forceinline__ const double* sym_tile(const double* tiles, const int64_t* __restrict__ row_off, int I, int J) {
+  return tiles + (row_off[I] + J) * (int64_t)(SYM_TB * SYM_TB);
 }
 
 constexpr int SYM_DEPTH = 3;      // steps of load lookahead (ring of 4 slots)
 
-__global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
-                                                            const double* __restrict__ xt, double* __restrict__ slabD,
-                                                            double* __restrict__ slabT, int kcols) {
+__global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
+                                                            const int* __restrict__ items, const double* __restrict__ xt,
+                                                            double* __restrict__ slabD, double* __restrict__ slabT, int kcols) {
   constexpr int RS = 65;          // padded stride of the end-of-run exchange of the direct partials
   constexpr int TRS = 66;         // padded column stride of the transposition scratch (528 B)
   constexpr int XT = 258;         // padded column stride of the transposed X_I copy (b128 reads conflict free)
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __rest
     s = s < nsteps ? s : nsteps - 1;                // clamped at the end of the run: a harmless re-read
     const int q = s >> 2, rg = s & 3;
     const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
-    const double* ad = sym_tile(tiles, I, J) + (int64_t)col * SYM_TB + rg * 64 + dlane;
+    const double* ad = sym_tile(tiles, row_off, I, J) + (int64_t)col * SYM_TB + rg * 64 + dlane;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       a[u][0] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
@@ -221,7 +223,8 @@ constexpr int SYM8_DEPTH = 3;     // half-steps of load lookahead (ring of 4 slo
 // the dense generator) are produced in registers instead of being loaded, ONCE per symmetric pair: half the
 // hash evaluations of the row-slab kernel (matvec_free_kernel), which is what that VALU-bound path is made of.
 template <bool GEN>
-__global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
+__global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
+                                                             const int* __restrict__ items,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
                                                              double* __restrict__ slabT, int kcols, int npair,
                                                              int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride,
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
         }
       }
     } else {
-      const double* ad = sym_tile(tiles, I, J) + (int64_t)col * SYM_TB + 32 * hs + dlane;
+      const double* ad = sym_tile(tiles, row_off, I, J) + (int64_t)col * SYM_TB + 32 * hs + dlane;
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
     }
@@ -460,21 +463,21 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
   }
 }
 
-void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev, int nitems, const double* xt, int kcols,
+void launch_matvec_sym(hipStream_t st, const double* tiles, const int64_t* row_off, const int* items_dev, int nitems, const double* xt, int kcols,
                        double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   // kcols <= 16 * npair block columns are in use; npair = 2 runs two 16-column groups as paired workgroups
   // DAV_SYM_V8=0 selects the one-wave-per-SIMD kernel (kept for A/B measurements; one group per launch)
   static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
   if (v8)
-    hipLaunchKernelGGL(matvec_sym8_kernel<false>, dim3(nitems * npair), dim3(512), 0, st, tiles, items_dev, xt, slabD, slabT, kcols,
+    hipLaunchKernelGGL(matvec_sym8_kernel<false>, dim3(nitems * npair), dim3(512), 0, st, tiles, row_off, items_dev, xt, slabD, slabT, kcols,
                        npair, xt_gstride, slabD_gstride, slabT_gstride, OpParams{}, (int64_t)0);
   else
-    hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, items_dev, xt, slabD, slabT, kcols);
+    hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, row_off, items_dev, xt, slabD, slabT, kcols);
 }
 void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const int* items_dev, int nitems, const double* xt, int kcols,
                                  double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride,
                                  int64_t slabT_gstride) {
-  hipLaunchKernelGGL(matvec_sym8_kernel<true>, dim3(nitems * npair), dim3(512), 0, st, (const double*)nullptr, items_dev, xt, slabD,
+  hipLaunchKernelGGL(matvec_sym8_kernel<true>, dim3(nitems * npair), dim3(512), 0, st, (const double*)nullptr, (const int64_t*)nullptr, items_dev, xt, slabD,
                      slabT, kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, op, n);
 }
 bool matvec_sym_can_pair() {
@@ -482,47 +485,46 @@ bool matvec_sym_can_pair() {
   return v8 != 0;
 }
 
-// W[J*256 + r, col] = sum over runs of block row J of slabD + sum over I > J of slabT(I, J), fixed order.
+// W[J*256 + r, col] = sum over runs of block row J of slabD + sum over I > J of slabT(I, J), fixed order.  With several
+// ranks (owned != nullptr) only the block rows this rank owns contribute and the result is this rank's PARTIAL of the
+// whole product, laid out for the reduce-scatter that follows: [rank p][column][row of p's slab] (chunk_rows = nslab).
 __global__ __launch_bounds__(256) void sym_reduce_kernel(const double* __restrict__ slabD, const double* __restrict__ slabT,
-                                                         const int* __restrict__ row_item_begin, int nb, int ncol16,
-                                                         int64_t nloc, int k, double* __restrict__ dst, int64_t ldd) {
+                                                         const int* __restrict__ row_item_begin, const int64_t* __restrict__ owned,
+                                                         int nb, int ncol16, int64_t nloc, int k, double* __restrict__ dst, int64_t ldd,
+                                                         int64_t chunk_rows, int64_t total_rows) {
   const int J = blockIdx.x, col = blockIdx.y, r = threadIdx.x;
   if (col >= k) return;
   double sum = 0.0;
   for (int it = row_item_begin[J]; it < row_item_begin[J + 1]; ++it)
     sum += slabD[((int64_t)it * ncol16 + col) * SYM_TB + r];
   // four interleaved partial sums (fixed order, so still reproducible): four loads in flight per thread
-  auto zt = [&](int I) { return slabT[((((int64_t)I * (I - 1) / 2 + J) * ncol16) + col) * SYM_TB + r]; };
+  auto zt = [&](int I) { return (!owned || owned[I] >= 0) ? slabT[((((int64_t)I * (I - 1) / 2 + J) * ncol16) + col) * SYM_TB + r] : 0.0; };
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int I = J + 1;
   for (; I + 3 < nb; I += 4) { s0 += zt(I); s1 += zt(I + 1); s2 += zt(I + 2); s3 += zt(I + 3); }
   for (; I < nb; ++I) s0 += zt(I);
   sum += (s0 + s1) + (s2 + s3);
   int64_t row = (int64_t)J * SYM_TB + r;
-  dst[(int64_t)col * ldd + row] = row < nloc ? sum : 0.0;
+  if (chunk_rows > 0) {
+    if (row < total_rows) dst[(row / chunk_rows) * (chunk_rows * k) + (int64_t)col * chunk_rows + row % chunk_rows] = sum;
+  } else {
+    dst[(int64_t)col * ldd + row] = row < nloc ? sum : 0.0;
+  }
 }
 
-void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, int nb,
-                       int ngroups, int64_t nloc, int k, double* dst, int64_t ldd) {
-  (void)ngroups;
-  hipLaunchKernelGGL(sym_reduce_kernel, dim3(nb, k), dim3(256), 0, st, slabD, slabT, row_item_begin_dev, nb, 16, nloc, k,
-                     dst, ldd);
+void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, const int64_t* owned,
+                       int nb, int64_t nloc, int k, double* dst, int64_t ldd, int64_t chunk_rows, int64_t total_rows) {
+  hipLaunchKernelGGL(sym_reduce_kernel, dim3(nb, k), dim3(256), 0, st, slabD, slabT, row_item_begin_dev, owned, nb, 16, nloc, k,
+                     dst, ldd, chunk_rows, total_rows);
 }
 
 // ---- storage helpers ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void generate_sym_tiles_kernel(double* __restrict__ tiles, int64_t tile0, int64_t ntiles,
-                                                                 int64_t n, uint64_t seed, double sparsity, int use_diag,
-                                                                 double diag_val) {
-  // blockIdx.x = tile (relative to tile0), blockIdx.y = 16 columns of the tile; thread = row
-  int64_t t = tile0 + blockIdx.x;
-  if (t >= ntiles) return;
-  // invert t = I (I+1)/2 + J
-  int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while (I * (I + 1) / 2 > t) --I;
-  while ((I + 1) * (I + 2) / 2 <= t) ++I;
-  int64_t J = t - I * (I + 1) / 2;
-  double* tile = tiles + t * (int64_t)(SYM_TB * SYM_TB);
-  int64_t gi = I * SYM_TB + threadIdx.x;
+__global__ __launch_bounds__(256) void generate_sym_tiles_kernel(double* __restrict__ row_tiles, int I, int64_t n, uint64_t seed,
+                                                                 double sparsity, int use_diag, double diag_val) {
+  // blockIdx.x = tile column J of block row I, blockIdx.y = 16 columns of the tile; thread = row
+  const int64_t J = blockIdx.x;
+  double* tile = row_tiles + J * (int64_t)(SYM_TB * SYM_TB);
+  int64_t gi = (int64_t)I * SYM_TB + threadIdx.x;
   for (int cc = 0; cc < 16; ++cc) {
     int64_t lc = blockIdx.y * 16 + cc, gj = J * SYM_TB + lc;
     double v = 0.0;
@@ -531,38 +533,41 @@ __global__ __launch_bounds__(256) void generate_sym_tiles_kernel(double* __restr
   }
 }
 
-void launch_generate_sym_tiles(hipStream_t st, double* tiles, int64_t ntiles, int64_t n, uint64_t seed, double sparsity,
-                               int use_diag, double diag_val) {
-  const int64_t batch = 32768;
-  for (int64_t t0 = 0; t0 < ntiles; t0 += batch) {
-    int64_t nt = ntiles - t0 < batch ? ntiles - t0 : batch;
-    hipLaunchKernelGGL(generate_sym_tiles_kernel, dim3((unsigned)nt, SYM_TB / 16), dim3(SYM_TB), 0, st, tiles, t0, ntiles, n,
-                       seed, sparsity, use_diag, diag_val);
-  }
+// tiles (I, 0..I) of every block row this rank stores (row_off_host[I] >= 0)
+void launch_generate_sym_tiles(hipStream_t st, double* tiles, const int64_t* row_off_host, int nb, int64_t n, uint64_t seed,
+                               double sparsity, int use_diag, double diag_val) {
+  for (int I = 0; I < nb; ++I)
+    if (row_off_host[I] >= 0)
+      hipLaunchKernelGGL(generate_sym_tiles_kernel, dim3((unsigned)(I + 1), SYM_TB / 16), dim3(SYM_TB), 0, st,
+                         tiles + row_off_host[I] * (int64_t)(SYM_TB * SYM_TB), I, n, seed, sparsity, use_diag, diag_val);
 }
 
-__device__ __forceinline__ double sym_entry(const double* tiles, int64_t i, int64_t j) {
+__device__ __forceinline__ double sym_entry(const double* tiles, const int64_t* __restrict__ row_off, int64_t i, int64_t j) {
   if (i < j) { int64_t t = i; i = j; j = t; }
   int I = (int)(i / SYM_TB), J = (int)(j / SYM_TB);
-  return sym_tile(tiles, I, J)[(j % SYM_TB) * SYM_TB + (i % SYM_TB)];
+  if (row_off[I] < 0) return 0.0;                       // block row of another rank
+  return sym_tile(tiles, row_off, I, J)[(j % SYM_TB) * SYM_TB + (i % SYM_TB)];
 }
 
-__global__ void diag_sym_kernel(const double* __restrict__ tiles, int64_t n, double* __restrict__ diag) {
+// diag[i] for the global rows [0, nrows): entries of block rows this rank does not store are written as 0 (several
+// ranks: the caller sums the pieces)
+__global__ void diag_sym_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off, int64_t n, int64_t nrows,
+                                double* __restrict__ diag) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) diag[i] = sym_entry(tiles, i, i);
+  if (i < nrows) diag[i] = i < n ? sym_entry(tiles, row_off, i, i) : 0.0;
 }
-void launch_diag_sym(hipStream_t st, const double* tiles, int64_t n, double* diag) {
-  hipLaunchKernelGGL(diag_sym_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tiles, n, diag);
+void launch_diag_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows, double* diag) {
+  hipLaunchKernelGGL(diag_sym_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, tiles, row_off, n, nrows, diag);
 }
 
-__global__ void gather_columns_sym_kernel(const double* __restrict__ tiles, int64_t n, int64_t nrows_pad,
-                                          const int64_t* __restrict__ idx, double* __restrict__ dst, int64_t ldd) {
+__global__ void gather_columns_sym_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off, int64_t n,
+                                          int64_t nrows_pad, const int64_t* __restrict__ idx, double* __restrict__ dst, int64_t ldd) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int c = blockIdx.y;
-  if (i < nrows_pad) dst[(int64_t)c * ldd + i] = i < n ? sym_entry(tiles, i, idx[c]) : 0.0;
+  if (i < nrows_pad) dst[(int64_t)c * ldd + i] = i < n ? sym_entry(tiles, row_off, i, idx[c]) : 0.0;
 }
-void launch_gather_columns_sym(hipStream_t st, const double* tiles, int64_t n, int64_t nrows_pad, const int64_t* idx_dev,
-                               int k, double* dst, int64_t ldd) {
-  hipLaunchKernelGGL(gather_columns_sym_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, tiles, n,
+void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows_pad,
+                               const int64_t* idx_dev, int k, double* dst, int64_t ldd) {
+  hipLaunchKernelGGL(gather_columns_sym_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, tiles, row_off, n,
                      nrows_pad, idx_dev, dst, ldd);
 }

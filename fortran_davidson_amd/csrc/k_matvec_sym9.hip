@@ -25,12 +25,14 @@
 #include "kernels.h"
 #include <cstdlib>
 
-__device__ __forceinline__ const double* sym9_tile(const double* tiles, int I, int J) {
-  return tiles + ((int64_t)I * (I + 1) / 2 + J) * (int64_t)(SYM_TB * SYM_TB);
+// row_off[I] = first tile of block row I in this rank's storage (k_matvec_sym.hip)
+__device__ __forceinline__ const double* sym9_tile(const double* tiles, const int64_t* __restrict__ row_off, int I, int J) {
+  return tiles + (row_off[I] + J) * (int64_t)(SYM_TB * SYM_TB);
 }
 
 template <int R, bool GEN>
-__global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __restrict__ tiles, const int* __restrict__ items,
+__global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
+                                                             const int* __restrict__ items,
                                                              const int* __restrict__ zslot_begin, const double* __restrict__ xt,
                                                              double* __restrict__ slabD, double* __restrict__ slabT, int kcols,
                                                              int npair, int64_t xt_gstride, int64_t slabD_gstride,
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __res
         }
       }
     } else {
-      const double* ad = sym9_tile(tiles, Ie, J) + (int64_t)(col + g) * SYM_TB + 128 * rhalf + 32 * hs + 2 * c;
+      const double* ad = sym9_tile(tiles, row_off, Ie, J) + (int64_t)(col + g) * SYM_TB + 128 * rhalf + 32 * hs + 2 * c;
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
     }
@@ -254,12 +256,13 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __res
   }
 }
 
-void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, OpParams op, int64_t n, int nb, const int* items_dev,
+void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, const int64_t* row_off, OpParams op, int64_t n, int nb,
+                        const int* items_dev,
                         int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int npair,
                         int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   dim3 grid(nitems * npair), block(512);
 #define DAV_SYM9_LAUNCH(RR, GG)                                                                                              \
-  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG>), grid, block, 0, st, tiles, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
+  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
                      npair, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
   if (R == 4) { if (gen) DAV_SYM9_LAUNCH(4, true); else DAV_SYM9_LAUNCH(4, false); }
   else        { if (gen) DAV_SYM9_LAUNCH(2, true); else DAV_SYM9_LAUNCH(2, false); }
@@ -268,17 +271,22 @@ void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, Op
 
 // W[J*256 + r, col] = sum over the items of super row J / R of slabD (block row J % R of the item)
 //                   + sum over the super rows S that reach below block row J of slabT(S, J), fixed order.
+// Several ranks (owned != nullptr): only the super rows this rank owns contribute; the partial product goes out in the
+// layout of the reduce-scatter that follows, [rank p][column][row of p's slab] (chunk_rows = nslab).
 __global__ __launch_bounds__(256) void sym9_reduce_kernel(const double* __restrict__ slabD, const double* __restrict__ slabT,
                                                           const int* __restrict__ row_item_begin, const int* __restrict__ zslot_begin,
-                                                          int R, int nb, int nsuper, int64_t nloc, int k, double* __restrict__ dst,
-                                                          int64_t ldd) {
+                                                          const int64_t* __restrict__ owned, int R, int nb, int nsuper, int64_t nloc,
+                                                          int k, double* __restrict__ dst, int64_t ldd, int64_t chunk_rows,
+                                                          int64_t total_rows) {
   const int J = blockIdx.x, col = blockIdx.y, r = threadIdx.x;
   if (col >= k) return;
   double sum = 0.0;
   const int Sown = J / R, sub = J % R;
   for (int it = row_item_begin[Sown]; it < row_item_begin[Sown + 1]; ++it)
     sum += slabD[(((int64_t)it * R + sub) * 16 + col) * SYM_TB + r];
-  auto zt = [&](int S) { return slabT[(((int64_t)zslot_begin[S] + J) * 16 + col) * SYM_TB + r]; };
+  auto zt = [&](int S) {
+    return (!owned || owned[S * R] >= 0) ? slabT[(((int64_t)zslot_begin[S] + J) * 16 + col) * SYM_TB + r] : 0.0;
+  };
   // super row S holds a partial for tile column J iff its last existing block row lies below J
   int S = (J + 1) / R;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -287,12 +295,17 @@ __global__ __launch_bounds__(256) void sym9_reduce_kernel(const double* __restri
   for (; S < Send; ++S) s0 += zt(S);
   sum += (s0 + s1) + (s2 + s3);
   const int64_t row = (int64_t)J * SYM_TB + r;
-  dst[(int64_t)col * ldd + row] = row < nloc ? sum : 0.0;
+  if (chunk_rows > 0) {
+    if (row < total_rows) dst[(row / chunk_rows) * (chunk_rows * k) + (int64_t)col * chunk_rows + row % chunk_rows] = sum;
+  } else {
+    dst[(int64_t)col * ldd + row] = row < nloc ? sum : 0.0;
+  }
 }
 
 void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,
-                        const int* zslot_begin_dev, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd) {
+                        const int* zslot_begin_dev, const int64_t* owned, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd,
+                        int64_t chunk_rows, int64_t total_rows) {
   const int nsuper = (nb + R - 1) / R;
-  hipLaunchKernelGGL(sym9_reduce_kernel, dim3(nb, k), dim3(256), 0, st, slabD, slabT, row_item_begin_dev, zslot_begin_dev, R, nb,
-                     nsuper, nloc, k, dst, ldd);
+  hipLaunchKernelGGL(sym9_reduce_kernel, dim3(nb, k), dim3(256), 0, st, slabD, slabT, row_item_begin_dev, zslot_begin_dev, owned, R,
+                     nb, nsuper, nloc, k, dst, ldd, chunk_rows, total_rows);
 }

@@ -71,7 +71,7 @@ void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double*
 // stage: nrows complete rows, row-major (ld = ldr), global rows grow0...; dst = full slab (lda, rows
 // [slab_row0, slab_row0 + slab_rows) kept) or, sym != 0, the lower block triangle of SYM_TB tiles.
 void launch_rows_scatter(hipStream_t st, const double* stage, int64_t ldr, int64_t grow0, int64_t nrows, int64_t n,
-                         double* dst, int64_t lda, int64_t slab_row0, int64_t slab_rows, int sym);
+                         double* dst, int64_t lda, int64_t slab_row0, int64_t slab_rows, int sym, const int64_t* row_off);
 
 // ---- K7 helpers (k_gjd.hip) ------------------------------------------------------------------------
 struct LincombArgs {      // out[:, j] = sum_t coef[t*ldc + j] * in[t][:, j]
@@ -87,25 +87,31 @@ struct DotsArgs {         // partial[block][s*m + j] = <a[s][:, j], b[s][:, j]> 
 int coldots_blocks(int64_t nrows_pad);
 void launch_coldots(hipStream_t st, const DotsArgs& a);
 
-// ---- K1s: symmetric-tiled storage (k_matvec_sym.hip) -----------------------------------------------
+// ---- K1s: symmetric-tiled storage (k_matvec_sym.hip, k_matvec_sym9.hip) ------------------------------------
 constexpr int SYM_TB = 256;     // tile edge; tiles (I, J<=I) contiguous, column-major, ld = SYM_TB
-void launch_matvec_sym(hipStream_t st, const double* tiles, const int* items_dev, int nitems, const double* xt, int kcols,
+// row_off (device, one entry per block row): first tile of block row I in this rank's storage, -1 = stored by another rank
+void launch_matvec_sym(hipStream_t st, const double* tiles, const int64_t* row_off, const int* items_dev, int nitems, const double* xt, int kcols,
                        double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
 // the same sweep with the entries of the hashed operator generated in registers (no stored matrix)
 void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const int* items_dev, int nitems, const double* xt, int kcols,
                                  double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride,
                                  int64_t slabT_gstride);
 bool matvec_sym_can_pair();
-void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, int nb,
-                       int ngroups, int64_t nloc, int k, double* dst, int64_t ldd);
+// chunk_rows = 0: dst = panel columns (ldd), rows >= nloc zeroed.  chunk_rows = nslab (several ranks): dst = this rank's
+// partial product in reduce-scatter layout [rank][column][row of the rank's slab], rows < total_rows
+void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, const int64_t* owned,
+                       int nb, int64_t nloc, int k, double* dst, int64_t ldd, int64_t chunk_rows, int64_t total_rows);
 // super-row schedules (k_matvec_sym9.hip): R = 2 or 4 block rows per workgroup, transposed partials summed on chip
-void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, OpParams op, int64_t n, int nb, const int* items_dev,
-                        int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int npair,
-                        int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
+void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, const int64_t* row_off, OpParams op, int64_t n, int nb,
+                        const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
+                        double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
 void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,
-                        const int* zslot_begin_dev, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd);
-void launch_generate_sym_tiles(hipStream_t st, double* tiles, int64_t ntiles, int64_t n, uint64_t seed, double sparsity,
-                               int use_diag, double diag_val);
-void launch_diag_sym(hipStream_t st, const double* tiles, int64_t n, double* diag);
-void launch_gather_columns_sym(hipStream_t st, const double* tiles, int64_t n, int64_t nrows_pad, const int64_t* idx_dev,
-                               int k, double* dst, int64_t ldd);
+                        const int* zslot_begin_dev, const int64_t* owned, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd,
+                        int64_t chunk_rows, int64_t total_rows);
+void launch_generate_sym_tiles(hipStream_t st, double* tiles, const int64_t* row_off_host, int nb, int64_t n, uint64_t seed,
+                               double sparsity, int use_diag, double diag_val);
+void launch_diag_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows, double* diag);
+void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows_pad,
+                               const int64_t* idx_dev, int k, double* dst, int64_t ldd);
+// dst[i, c] = i < nloc ? src[c * lds + i] : 0 for i < nrows_pad (the received chunk of a reduce-scatter -> panel columns)
+void launch_chunk_to_panel(hipStream_t st, const double* src, int64_t lds, int64_t nloc, int64_t nrows_pad, int k, double* dst, int64_t ldd);

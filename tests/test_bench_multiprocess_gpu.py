@@ -36,11 +36,12 @@ def run_bench(nproc, extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
-def test_bench_multi_rank_flow_matches_single_rank(nproc):
-    # the timed workload at a reduced order, full row slabs on both sides so that the runs are comparable;
+@pytest.mark.parametrize("nproc,storage", [(2, "full"), (3, "full"), (2, "symmetric"), (3, "symmetric")])
+def test_bench_multi_rank_flow_matches_single_rank(nproc, storage):
+    # the timed workload at a reduced order, the same storage on both sides so that the runs are comparable (full
+    # row slabs / the lower block triangle dealt out over the ranks: all-gather + reduce-scatter per sweep);
     # the configs[1] / configs[3] / configs[4] legs at small orders
-    extra = ["--steps", "2", "--warmup", "1", "--order", "6000", "--storage", "full", "--small-n", "3000", "--gjd-n", "2000",
+    extra = ["--steps", "2", "--warmup", "1", "--order", "6000", "--storage", storage, "--small-n", "3000", "--gjd-n", "2000",
              "--free-n", "4000", "--no-cpu-baseline", "--no-dropin"]
     one = run_bench(1, extra)
     many = run_bench(nproc, extra)

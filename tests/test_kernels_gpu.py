@@ -251,8 +251,6 @@ def test_symmetric_tiled_generated_matrix_and_solver_phases():
         e.panel_put(PANEL_S, 0, X)
         e.apply(OP_A, PANEL_S, 0, 5, PANEL_R, 0)
         assert relerr(e.panel_get(PANEL_R, 0, 5), A @ X) < 1e-12
-        with pytest.raises(fd.DavidsonHipError):
-            fd.CEngine(n=100, max_cols=16, rank=0, nranks=2).set_storage(1)
 
 
 @pytest.mark.parametrize("storage", [0, 1])
@@ -377,3 +375,67 @@ def test_symmetric_super_row_schedules_at_a_size_that_selects_them(k):
             assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
             e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
             assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
+
+
+def _run_ranks(nranks, make, work):
+    """nranks engines as threads of this process on one GPU, collectives through the loopback transport"""
+    import ctypes as C
+    import threading
+    engs = [make(r) for r in range(nranks)]
+    handles = (C.c_void_p * nranks)(*[e.h for e in engs])
+    assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    out, err = [None] * nranks, [None] * nranks
+
+    def run(r):
+        try:
+            out[r] = work(r, engs[r])
+        except Exception as exc:      # noqa: BLE001
+            err[r] = exc
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    [t.start() for t in threads]
+    [t.join(timeout=300) for t in threads]
+    for e in engs:
+        e.close()
+    assert all(x is None for x in err), err
+    assert all(o is not None for o in out), "a rank did not finish"
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+@pytest.mark.parametrize("sched", ["1", "2", "4"])
+def test_symmetric_sweep_over_several_ranks(nranks, sched, monkeypatch):
+    """Symmetric-tiled storage dealt out over ranks by groups of 4 block rows: every rank stores and sweeps only its
+    block rows against the all-gathered block, one reduce-scatter sums the partial products into row slabs.
+    Stored tiles (host upload and device generator), the hashed operator generated in the sweep, every schedule,
+    ragged orders, more ranks than groups of block rows (a rank without a single tile)."""
+    monkeypatch.setenv("DAV_SYM_R", sched)
+    for n, k in [(300, 8), (1300, 5), (2305, 16), (2500, 40), (700, 3)]:
+        rng = np.random.default_rng(n + k)
+        A = rng.standard_normal((n, n)); A = A + A.T
+        G = O.generate_diagonal_dominant(n, 1e-2, seed=13)
+        X = rng.standard_normal((n, k))
+
+        def work(r, e):
+            res = []
+            e.set_storage(1)
+            e.set_dense_host(OP_A, A)
+            assert np.array_equal(e.get_diagonal(OP_A), np.diag(A))
+            e.panel_put(PANEL_V, 0, X)
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+            res.append(e.panel_get(PANEL_W, 0, k))
+            e.set_dense_generated(OP_A, 13, 1e-2)
+            assert np.array_equal(e.get_diagonal(OP_A), np.diag(G))
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+            res.append(e.panel_get(PANEL_W, 0, k))
+            e.set_operator_hashed(OP_A, 13, 1e-2)
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
+            res.append(e.panel_get(PANEL_S, 0, k))
+            return res
+
+        out = _run_ranks(nranks, lambda r: fd.CEngine(n=n, max_cols=max(k, 16), rank=r, nranks=nranks), work)
+        for res in out:
+            assert relerr(res[0], A @ X) < RTOL * n
+            assert relerr(res[1], G @ X) < 1e-12
+            assert relerr(res[2], G @ X) < 1e-12
+            for a, b in zip(res, out[0]):
+                assert np.array_equal(a, b)              # every rank gathers the same bits

@@ -262,8 +262,9 @@ def test_generalized_matrix_free_with_callbacks_and_general_b():
     assert it == it_o
 
 
+@pytest.mark.parametrize("storage", ["full", "symmetric"])
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_multi_rank_engine_on_one_gpu_through_loopback_transport(golden, nranks):
+def test_multi_rank_engine_on_one_gpu_through_loopback_transport(golden, nranks, storage):
     """The row-slab engine with nranks > 1, every rank a thread of this process on the same GPU,
     collectives through the loopback transport (device copies + barriers; RCCL semantics).  Checks the
     slab offsets, padded gathers, gathered diagonal / top-k selection and the gathered eigenvectors."""
@@ -272,7 +273,7 @@ def test_multi_rank_engine_on_one_gpu_through_loopback_transport(golden, nranks)
     manifest, arrays = golden
     for name in ("n1000_restart_dpr", "n1000_gev_restart_dpr", "n400_gev_gjd"):
         case = manifest["dense"][name]
-        engs = [fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=case["gev"], rank=r, nranks=nranks)
+        engs = [fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=case["gev"], rank=r, nranks=nranks, storage=storage)
                 for r in range(nranks)]
         handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
         assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
@@ -300,12 +301,14 @@ def test_multi_rank_engine_on_one_gpu_through_loopback_transport(golden, nranks)
             e.close()
 
 
-def test_multi_rank_matrix_free_operator_through_loopback_transport():
-    """configs[4] shape in miniature: hashed matrix-free operator, B = I, row-partitioned over 4 ranks."""
+@pytest.mark.parametrize("storage", ["full", "symmetric"])
+def test_multi_rank_matrix_free_operator_through_loopback_transport(storage):
+    """configs[4] shape in miniature: hashed matrix-free operator, B = I, over 4 ranks - row slabs (every rank generates
+    its rows) or symmetric generation (every rank generates the lower-triangle tiles of its block rows once)."""
     import ctypes as C
     import threading
     n, L, sp, nranks = 3000, 4, 3e-3, 4
-    engs = [fd.DavidsonEngine(n, L, gev=True, rank=r, nranks=nranks) for r in range(nranks)]
+    engs = [fd.DavidsonEngine(n, L, gev=True, rank=r, nranks=nranks, storage=storage) for r in range(nranks)]
     handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
     assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
     out = [None] * nranks
