@@ -96,3 +96,53 @@ def test_config5_shape_matrix_free_matches_dense():
         lam_dense, _, it_dense = eng.solve("DPR", 100, TOL, want_vectors=False)
     assert it_free == it_dense
     assert np.abs(lam_free - lam_dense).max() < 1e-10
+
+
+def test_config5_n1000000_matrix_free_one_rank():
+    """configs[4] at its stated order on ONE GPU: N=10^6, hashed diagonal-dominant operator (never stored; every
+    symmetric pair generated once per sweep), B = I (src/benchmark_free.f90:65-76), lowest=8, DPR."""
+    n, L, sp = 1000000, 8, 1e-3
+    with fd.DavidsonEngine(n, L, 80, gev=True, storage="symmetric") as eng:
+        eng.set_hashed_operator(1, sp, seed=1)
+        eng.set_identity(2)
+        lam, _, iters = eng.solve("DPR", 100, TOL, want_vectors=False)
+        assert 0 < iters <= 100
+        verify_on_device(eng, lam, True, n, sp)
+
+
+@pytest.mark.parametrize("storage", ["full", "symmetric"])
+def test_config5_n1000000_matrix_free_four_ranks(storage):
+    """configs[4] as BASELINE.json partitions it - rows over the ranks, all-gather of the new block each iteration -
+    with 4 ranks as threads on one GPU (loopback transport): row slabs (every rank generates its N/4 rows) and
+    symmetric generation (every rank generates the lower-triangle tiles of its block rows; reduce-scatter of the
+    partial products).  Same eigenvalues and iteration count on every rank as the one-rank run."""
+    import ctypes as C
+    import threading
+    n, L, sp, nranks = 1000000, 8, 1e-3, 4
+    engs = [fd.DavidsonEngine(n, L, 80, gev=True, rank=r, nranks=nranks, storage=storage) for r in range(nranks)]
+    handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+    assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            engs[r].set_hashed_operator(1, sp, seed=1)
+            engs[r].set_identity(2)
+            lam, _, iters = engs[r].solve("DPR", 100, TOL, want_vectors=False)
+            verify_on_device(engs[r], lam, True, n, sp)
+            out[r] = (lam, iters)
+        except Exception as exc:      # noqa: BLE001
+            err[r] = exc
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in threads]
+    [t.join(timeout=600) for t in threads]
+    for e in engs:
+        e.close()
+    assert all(x is None for x in err), err
+    assert all(o is not None for o in out)
+    for lam, iters in out:
+        assert np.array_equal(lam, out[0][0]) and iters == out[0][1]
+    # the one-rank run of this problem (bench.py configs4_free leg, same seed): first three eigenvalues
+    assert np.abs(out[0][0][:3] - np.array([0.9999946355480692, 1.9999955176766737, 2.9999964218285395])).max() < 1e-9
+    assert out[0][1] == 4
