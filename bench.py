@@ -375,6 +375,16 @@ def main():
                 small["phase_ms_per_solve"] = {"apply_ms": round(sp.apply_ms / 5, 4), "gram_ms": round(sp.gram_ms / 5, 4),
                                                "panel_ms": round(sp.panel_ms / 5, 4), "comm_ms": round(sp.comm_ms / 5, 4)}
                 s.c.set_timing(1)
+                # opt-in device-side Rayleigh-Ritz: same solve, eigenpairs of the projected problem kept in HBM
+                s.set_device_rr(True)
+                for _ in range(5):
+                    s.solve("DPR", 1000, args.tol, want_vectors=False)
+                dt_r, it_r, lam_r = timed_solves(s, "DPR", 50, args.tol)
+                s.set_device_rr(False)
+                small["device_rr"] = {"ms_per_solve": round(dt_r / 50 * 1e3, 4), "iterations_per_s": round(it_r / dt_r, 2),
+                                      "iters_per_solve": it_r // 50,
+                                      "max_abs_eigenvalue_diff_vs_host_rr": float(np.abs(lam_r - lam_s).max()),
+                                      "note": "one-workgroup Jacobi eigensolver on the device instead of host DSYEV/DSYEVD; not the default"}
                 small["apply"] = apply_rooflines(s, (8, 16, 32), 20)
                 s.close()
                 extras["small"] = small

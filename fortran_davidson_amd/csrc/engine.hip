@@ -181,6 +181,11 @@ struct dav_engine {
     int* row_begin = nullptr;         // device: first item of each super row (nsuper + 1)
     int* zslot_begin = nullptr;       // device: first slot of each super row (nsuper + 1)
   } sym_plan[2];
+  // device-resident Rayleigh-Ritz (dav_rr_enable): projected matrices, eigenpairs and their operand images stay in HBM
+  bool rr_on = false;
+  int64_t rr_ld = 0;
+  double *rr_H = nullptr, *rr_S = nullptr, *rr_Y = nullptr, *rr_theta = nullptr, *rr_work = nullptr, *rr_info = nullptr;
+  double *rr_Ypk = nullptr, *rr_Y2pk = nullptr, *rr_thpk = nullptr;
   SmallBuf sm[N_SMALL];
   size_t small_doubles = 0;
   ncclComm_t comm = nullptr;
@@ -424,6 +429,8 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->sym_items);
   hipFree(e->sym_row_begin);
   hipFree(e->sym_slab);
+  hipFree(e->rr_H); hipFree(e->rr_S); hipFree(e->rr_Y); hipFree(e->rr_theta); hipFree(e->rr_work); hipFree(e->rr_info);
+  hipFree(e->rr_Ypk); hipFree(e->rr_Y2pk); hipFree(e->rr_thpk);
   hipFree(e->sym_row_off);
   hipFree(e->sym_wpart);
   hipFree(e->sym_wrecv);
@@ -1339,9 +1346,9 @@ extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh
   CHK(bind(e));
   int mt = c0 + k;
   CHK(check_panel(e, DAV_PANEL_V, 0, mt));
-  if (k <= 0 || ldh < mt) return fail("dav_project: bad shape");
-  const bool both = e->gev && S != nullptr;
-  if (both && lds < mt) return fail("dav_project: bad shape");
+  if (k <= 0 || (H && ldh < mt)) return fail("dav_project: bad shape");
+  const bool both = e->gev && (S != nullptr || (!H && e->rr_on));
+  if (both && S && lds < mt) return fail("dav_project: bad shape");
   const size_t blk = (size_t)mt * k;
   if ((both ? 2 : 1) * blk > e->gram_doubles) return fail("gram result exceeds engine capacity");
   if (gram_scratch_doubles(mt, k, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
@@ -1355,7 +1362,20 @@ extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh
                 e->scratch, result_target(e) + blk);
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
-  CHK(result_fetch(e, (both ? 2 : 1) * blk));
+  if (e->rr_on) {
+    // device-resident Rayleigh-Ritz: the new columns also go into the projected matrices kept in HBM; a caller that
+    // passes H = NULL (the device-RR driver) gets no host copy and no synchronisation at all
+    if (mt > e->rr_ld) return fail("dav_project: basis wider than the device-resident projected matrices");
+    if (has_comm(e)) CHK(coll_allreduce(e, e->gram_dev, (both ? 2 : 1) * blk));
+    launch_rr_scatter(e->stream, result_target(e), mt, k, c0, e->rr_H, e->rr_ld);
+    if (both) launch_rr_scatter(e->stream, result_target(e) + blk, mt, k, c0, e->rr_S, e->rr_ld);
+    if (!H) return 0;
+    if (has_comm(e)) HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * (both ? 2 : 1) * blk, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  } else {
+    if (!H) return fail("dav_project: H is NULL (only with dav_rr_enable)");
+    CHK(result_fetch(e, (both ? 2 : 1) * blk));
+  }
   for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
     double* out = pass == 0 ? H : S;
     int64_t ld = pass == 0 ? ldh : lds;
@@ -1412,33 +1432,44 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
 
 // ---- K3 -----------------------------------------------------------------------------------------
 static int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, const double* theta, int method,
-                     double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg);
+                     double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg, double* theta_out, double* info_out);
 
 extern "C" int dav_ritz_residual_correction_n(dav_handle_t e, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
                                               const double* theta, int method, double* resnorm) {
-  return ritz_impl(e, m, ncorr, lowest, Y, ldy, theta, method, resnorm, nullptr, 0, nullptr, 0);
+  return ritz_impl(e, m, ncorr, lowest, Y, ldy, theta, method, resnorm, nullptr, 0, nullptr, 0, nullptr, nullptr);
 }
 
 extern "C" int dav_ritz_residual_correction_g(dav_handle_t e, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
                                               const double* theta, double* resnorm, double* C, int64_t ldc, double* G,
                                               int64_t ldg) {
   if (!C || !G || ldc < m || ldg < ncorr) return fail("dav_ritz_residual_correction_g: bad shape");
-  return ritz_impl(e, m, ncorr, lowest, Y, ldy, theta, DAV_METHOD_DPR, resnorm, C, ldc, G, ldg);
+  return ritz_impl(e, m, ncorr, lowest, Y, ldy, theta, DAV_METHOD_DPR, resnorm, C, ldc, G, ldg, nullptr, nullptr);
 }
 
+// Y == nullptr: the eigenpairs are the device-resident ones of dav_rr_ritz (theta_out receives all m Ritz values)
 static int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, const double* theta, int method,
-                     double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg) {
+                     double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg, double* theta_out,
+                     double* info_out) {
   CHK(bind(e));
-  if (m <= 0 || lowest <= 0 || lowest > ncorr || ncorr > m || ldy < m) return fail("dav_ritz_residual_correction: bad shape");
+  const bool dev = Y == nullptr;
+  if (m <= 0 || lowest <= 0 || lowest > ncorr || ncorr > m || (!dev && ldy < m)) return fail("dav_ritz_residual_correction: bad shape");
   if (method == DAV_METHOD_DPR && m + ncorr > e->cols_alloc) return fail("basis panel too narrow for the correction block");
   CHK(check_panel(e, DAV_PANEL_V, 0, m));
-  std::vector<double> y2((size_t)m * ncorr);
-  for (int j = 0; j < ncorr; ++j)
-    for (int i = 0; i < m; ++i) y2[(size_t)j * m + i] = -Y[j * ldy + i] * theta[j];
-  SmallMat sm3[3] = {{Y, ldy, m, ncorr, nullptr, 0}, {y2.data(), m, m, ncorr, nullptr, 0}, {theta, ncorr, ncorr, 1, nullptr, 0}};
-  CHK(small_upload_multi(e, 0, sm3, 3));
-  const double* dY = sm3[0].dev; const double* dY2 = sm3[1].dev; const double* dTheta = sm3[2].dev;
-  const int64_t ldm_y = sm3[0].ldm, ldm_y2 = sm3[1].ldm;
+  const double *dY, *dY2, *dTheta;
+  int64_t ldm_y, ldm_y2;
+  std::vector<double> y2;
+  if (dev) {
+    dY = e->rr_Ypk; dY2 = e->rr_Y2pk; dTheta = e->rr_thpk;
+    ldm_y = ldm_y2 = roundup(m, 4);
+  } else {
+    y2.resize((size_t)m * ncorr);
+    for (int j = 0; j < ncorr; ++j)
+      for (int i = 0; i < m; ++i) y2[(size_t)j * m + i] = -Y[j * ldy + i] * theta[j];
+    SmallMat sm3[3] = {{Y, ldy, m, ncorr, nullptr, 0}, {y2.data(), m, m, ncorr, nullptr, 0}, {theta, ncorr, ncorr, 1, nullptr, 0}};
+    CHK(small_upload_multi(e, 0, sm3, 3));
+    dY = sm3[0].dev; dY2 = sm3[1].dev; dTheta = sm3[2].dev;
+    ldm_y = sm3[0].ldm; ldm_y2 = sm3[1].ldm;
+  }
 
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
@@ -1478,7 +1509,20 @@ static int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_
   }
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
-  CHK(result_fetch(e, count));
+  if (dev) {
+    // the Ritz values (and the eigensolver's status word) ride on the same fetch, behind the all-reduced part
+    const size_t toff = (count + 7) / 8 * 8;
+    if (toff + (size_t)m + 1 > e->gram_doubles) return fail("gram result exceeds engine capacity");
+    if (has_comm(e)) CHK(coll_allreduce(e, e->gram_dev, count));
+    launch_copy_columns(e->stream, e->rr_thpk + roundup(ncorr, 64), 2 * (int64_t)roundup(m + 1, 2), result_target(e) + toff,
+                        2 * (int64_t)roundup(m + 1, 2), roundup(m + 1, 2), 1);
+    if (has_comm(e)) HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * (toff + m + 1), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int j = 0; j < m; ++j) theta_out[j] = e->gram_host[toff + j];
+    if (info_out) *info_out = e->gram_host[toff + m];
+  } else {
+    CHK(result_fetch(e, count));
+  }
   for (int j = 0; j < lowest; ++j) resnorm[j] = std::sqrt(e->gram_host[j]);
   if (C) {
     const double* gh = e->gram_host + goff;
@@ -1593,6 +1637,90 @@ extern "C" int dav_restart(dav_handle_t e, int m, int keep, const double* Yk, in
   if (keep <= 0 || keep > m) return fail("dav_restart: bad shape");
   CHK(dav_panel_transform(e, DAV_PANEL_V, 0, m, Yk, ldy, keep, DAV_PANEL_V, 0));
   e->m = keep;
+  return 0;
+}
+
+// ---- device-resident Rayleigh-Ritz -----------------------------------------------------------------
+extern "C" int dav_rr_enable(dav_handle_t e, int on) {
+  CHK(bind(e));
+  if (on && !e->rr_H) {
+    if (e->cols_alloc > 144) return fail("dav_rr_enable: the device eigensolver handles projected problems of order <= 128");
+    e->rr_ld = e->cols_alloc;
+    const size_t sq = (size_t)e->rr_ld * e->rr_ld, pk = (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
+    HIPCHK(hipMalloc(&e->rr_H, sizeof(double) * sq));
+    HIPCHK(hipMalloc(&e->rr_S, sizeof(double) * sq));
+    HIPCHK(hipMalloc(&e->rr_Y, sizeof(double) * sq));
+    HIPCHK(hipMalloc(&e->rr_theta, sizeof(double) * e->rr_ld));
+    HIPCHK(hipMalloc(&e->rr_work, sizeof(double) * small_eig_work_doubles((int)e->rr_ld)));
+    HIPCHK(hipMalloc(&e->rr_info, sizeof(double) * 8));
+    HIPCHK(hipMalloc(&e->rr_Ypk, sizeof(double) * pk));
+    HIPCHK(hipMalloc(&e->rr_Y2pk, sizeof(double) * pk));
+    HIPCHK(hipMalloc(&e->rr_thpk, sizeof(double) * (roundup(e->cols_alloc, 64) + e->rr_ld + 8)));
+    HIPCHK(hipMemsetAsync(e->rr_H, 0, sizeof(double) * sq, e->stream));
+    HIPCHK(hipMemsetAsync(e->rr_S, 0, sizeof(double) * sq, e->stream));
+  }
+  e->rr_on = on != 0;
+  return 0;
+}
+
+// dav_project without a host copy of the new block and without a synchronisation (device-resident Rayleigh-Ritz only)
+extern "C" int dav_project_dev(dav_handle_t e, int c0, int k) {
+  if (!e->rr_on) return fail("dav_project_dev: call dav_rr_enable first");
+  return dav_project(e, c0, k, nullptr, 0, nullptr, 0);
+}
+
+// Rayleigh-Ritz on the device-resident projected matrices (filled by dav_project) followed by the Ritz phase of
+// dav_ritz_residual_correction_n / _g from the eigenpairs where they lie: ONE host synchronisation returns all m Ritz
+// values, the residual norms of the first `lowest` pairs and (C != NULL) the Gram blocks of the first
+// orthonormalisation pass.  Replaces lapack_generalized_eigensolver (src/lapack_wrapper.f90:14-91) + the H-down /
+// Y-up transfers.  sweeps_out: Jacobi sweeps used.
+extern "C" int dav_rr_ritz(dav_handle_t e, int m, int ncorr, int lowest, int method, double* theta_out, double* resnorm, double* C,
+                           int64_t ldc, double* G, int64_t ldg, int* sweeps_out) {
+  CHK(bind(e));
+  if (!e->rr_on) return fail("dav_rr_ritz: call dav_rr_enable first");
+  if (m <= 0 || m > 128 || m > e->rr_ld || !theta_out || !resnorm) return fail("dav_rr_ritz: bad arguments (order <= 128)");
+  if (C && (!G || ldc < m || ldg < ncorr)) return fail("dav_rr_ritz: bad shape");
+  int slot;
+  CHK(timed_begin(e, 1, 0, &slot));
+  if (!launch_small_eig(e->stream, e->rr_H, e->rr_ld, e->rr_S, e->rr_ld, m, e->gev != 0, e->rr_theta, e->rr_Y, e->rr_ld, e->rr_work, e->rr_info))
+    return fail("dav_rr_ritz: order out of range");
+  const int nq = method == DAV_METHOD_GJD ? ncorr : std::max(ncorr, lowest);
+  launch_rr_pack(e->stream, e->rr_Y, e->rr_ld, e->rr_theta, m, nq, (int)roundup(m, 4), (int)roundup(nq, 64), e->rr_Ypk, e->rr_Y2pk, e->rr_thpk,
+                 e->rr_info, e->rr_thpk + roundup(ncorr, 64));
+  CHK(timed_end(e, slot));
+  double info = 0.0;
+  CHK(ritz_impl(e, m, ncorr, lowest, nullptr, 0, nullptr, method, resnorm, C, ldc, G, ldg, theta_out, &info));
+  if (info < 0.0) return fail("dav_rr_ritz: the projected overlap matrix is not positive definite (pivot " + std::to_string((int)-info) + ")");
+  if (sweeps_out) *sweeps_out = (int)info;
+  return 0;
+}
+
+// collapse restart with the device-resident eigenvectors: V <- V * Y(:, 1:keep)   (src/davidson.f90:218)
+extern "C" int dav_rr_restart(dav_handle_t e, int m, int keep) {
+  CHK(bind(e));
+  if (!e->rr_on || keep <= 0 || keep > m || m > e->rr_ld) return fail("dav_rr_restart: bad shape");
+  launch_rr_pack(e->stream, e->rr_Y, e->rr_ld, e->rr_theta, m, keep, (int)roundup(m, 4), (int)roundup(keep, 64), e->rr_Ypk, e->rr_Y2pk,
+                 e->rr_thpk, e->rr_info, nullptr);
+  PanelGemmArgs a{};
+  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = e->rr_Ypk; a.ldm1 = roundup(m, 4);
+  a.p2 = 0;
+  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = keep; a.ldo = e->ldp;
+  a.out = panel_ptr(e, DAV_PANEL_S, 0);
+  launch_panel_gemm(e->stream, a);
+  launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, e->nloc_pad, keep);
+  e->m = keep;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// the device-resident eigenvectors (m x ncols) and Ritz values, for tests and for callers that want them on the host
+extern "C" int dav_rr_get(dav_handle_t e, int m, int ncols, double* theta, double* Y, int64_t ldy) {
+  CHK(bind(e));
+  if (!e->rr_on || m <= 0 || m > e->rr_ld || ncols > m || ldy < m) return fail("dav_rr_get: bad shape");
+  if (theta) HIPCHK(hipMemcpyAsync(theta, e->rr_theta, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
+  if (Y) HIPCHK(hipMemcpy2DAsync(Y, sizeof(double) * ldy, e->rr_Y, sizeof(double) * e->rr_ld, sizeof(double) * m, (size_t)ncols,
+                                 hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
 

@@ -1,0 +1,256 @@
+// Device-side Rayleigh-Ritz: all eigenpairs of the projected problem H y = theta y or H y = theta S y,
+// order m <= 128, by ONE workgroup - what lapack_generalized_eigensolver (src/lapack_wrapper.f90:14-91: DSYEV / DSYGV
+// itype = 1, 'V', 'U') computes on the host.  With it theta and Y never leave HBM and the H-down / Y-up round trip
+// of an iteration disappears.
+//
+//   generalized:  S = L L^T (Cholesky, in place);  C = L^-1 H L^-T;  C = Z Theta Z^T;  Y = L^-T Z   (Y^T S Y = I)
+//   standard:     H = Y Theta Y^T                                                                    (Y^T Y = I)
+//
+// Eigen-decomposition: cyclic two-sided Jacobi with the round-robin ("tournament") ordering - m/2 disjoint rotations
+// per step, m - 1 steps per sweep, until a whole sweep finds no |a_pq| > 1e-16 sqrt(|a_pp a_qq|); the projected matrices
+// of a Davidson basis are close to diagonal (after a restart exactly diagonal), so 3-6 sweeps suffice.  The symmetric matrix lives in LDS (column-major, odd
+// stride); the accumulated rotations too when both fit (m <= 96), else in global memory (L2).  Eigenvalues leave
+// ascending (ties by index), eigenvectors in the matching order.  One workgroup: the order is at most 128, the sweeps
+// are latency (barrier) bound, not throughput bound - measured against the host in DESIGN.md.
+#include "kernels.h"
+
+namespace {
+constexpr int EIG_THREADS = 1024;
+
+__device__ __forceinline__ void tournament_pair(int M, int s, int k, int* p, int* q) {
+  // round-robin over M (even) players, step s in [0, M-1), table k in [0, M/2): player M-1 stays, the others rotate
+  int a, b;
+  if (k == 0) { a = M - 1; b = s; }
+  else { a = (s + k) % (M - 1); b = (s - k + (M - 1)) % (M - 1); }
+  *p = a < b ? a : b;
+  *q = a < b ? b : a;
+}
+}  // namespace
+
+// H, S: device, column-major (ld), full symmetric m x m (S ignored unless gev).  On exit theta[0..m), Y (ldy) as above.
+// work: >= 2 * m * m doubles of global scratch.  info[0] = sweeps used, or -j if the Cholesky met a non-positive pivot j
+// (then nothing else is written).
+template <bool VLDS>
+__global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __restrict__ H, int64_t ldh, const double* __restrict__ S,
+                                                               int64_t lds_, int m, int gev, double* __restrict__ theta,
+                                                               double* __restrict__ Y, int64_t ldy, double* __restrict__ work,
+                                                               double* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int la = m | 1;                        // odd leading dimension: column and row walks are both conflict free
+  double* As = smem;                           // m x m
+  double* Vs = VLDS ? smem + (size_t)la * m : work;   // accumulated rotations (ld = lv)
+  const int lv = VLDS ? la : m;
+  double* Lg = work + (size_t)m * m;           // generalized: the Cholesky factor (global, ld = m)
+  __shared__ double rot_c[64], rot_s[64];
+  __shared__ int flag;
+
+  // ---- load; generalized: reduce to the standard problem ------------------------------------------------------
+  for (int e = tid; e < m * m; e += EIG_THREADS) {
+    const int i = e % m, j = e / m;
+    As[i + j * la] = H[i + (int64_t)j * ldh];
+  }
+  if (tid == 0) flag = 0;
+  __syncthreads();
+  if (gev) {
+    // Cholesky S = L L^T, right-looking, in global scratch (m steps, the whole workgroup updates the trailing block)
+    for (int e = tid; e < m * m; e += EIG_THREADS) Lg[e] = S[(e % m) + (int64_t)(e / m) * lds_];
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+      const double d = Lg[j + j * m];
+      if (!(d > 0.0)) { if (tid == 0) flag = -(j + 1); }
+      __syncthreads();
+      if (flag != 0) break;
+      const double sd = sqrt(d);
+      for (int i = j + tid; i < m; i += EIG_THREADS) Lg[i + j * m] = i == j ? sd : Lg[i + j * m] / sd;
+      __syncthreads();
+      // trailing update: S[i, k] -= L[i, j] L[k, j] for j < k <= i
+      const int nt = m - j - 1;
+      for (int e = tid; e < nt * nt; e += EIG_THREADS) {
+        const int i = j + 1 + e % nt, k = j + 1 + e / nt;
+        if (k <= i) Lg[i + k * m] -= Lg[i + j * m] * Lg[k + j * m];
+      }
+      __syncthreads();
+    }
+    if (flag != 0) { if (tid == 0) info[0] = (double)flag; return; }
+    // C = L^-1 H L^-T.  X = L^-1 H: forward substitution down the rows, all columns at once (thread = column)
+    for (int i = 0; i < m; ++i) {
+      for (int j = tid; j < m; j += EIG_THREADS) {
+        double acc = As[i + j * la];
+        for (int k = 0; k < i; ++k) acc -= Lg[i + k * m] * As[k + j * la];
+        As[i + j * la] = acc / Lg[i + i * m];
+      }
+      __syncthreads();
+    }
+    // C = X L^-T: the same substitution on the rows of X (thread = row), i.e. C^T = L^-1 X^T
+    for (int jc = 0; jc < m; ++jc) {
+      for (int i = tid; i < m; i += EIG_THREADS) {
+        double acc = As[i + jc * la];
+        for (int k = 0; k < jc; ++k) acc -= Lg[jc + k * m] * As[i + k * la];
+        As[i + jc * la] = acc / Lg[jc + jc * m];
+      }
+      __syncthreads();
+    }
+    // symmetrise (rounding): the Jacobi sweeps read both triangles
+    for (int e = tid; e < m * m; e += EIG_THREADS) {
+      const int i = e % m, j = e / m;
+      if (i > j) { const double v = 0.5 * (As[i + j * la] + As[j + i * la]); As[i + j * la] = v; As[j + i * la] = v; }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < m * m; e += EIG_THREADS) Vs[(e % m) + (size_t)(e / m) * lv] = (e % m) == (e / m) ? 1.0 : 0.0;
+  __syncthreads();
+
+  // ---- cyclic Jacobi ------------------------------------------------------------------------------------------------
+  const int M = (m + 1) & ~1, half = M / 2;
+  int sweeps = 0;
+  for (; sweeps < 30; ++sweeps) {
+    if (tid == 0) flag = 0;
+    __syncthreads();
+    for (int s = 0; s < M - 1; ++s) {
+      // rotations of this step.  A pair is rotated while |a_pq| > 1e-16 sqrt(|a_pp a_qq|): the criterion that gives the
+      // small eigenvalues of a graded matrix their relative accuracy (a norm-wise test would stop at 1e-16 |H|, and the
+      // projected matrices carry diagonal entries five orders of magnitude above the wanted Ritz values)
+      if (tid < half) {
+        int p, q;
+        tournament_pair(M, s, tid, &p, &q);
+        double c = 1.0, sn = 0.0;
+        if (q < m) {
+          const double apq = As[p + q * la], app = As[p + p * la], aqq = As[q + q * la];
+          if (fabs(apq) > 1e-16 * sqrt(fabs(app * aqq)) + 1e-300) {
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            sn = t * c;
+            flag = 1;
+          }
+        }
+        rot_c[tid] = c; rot_s[tid] = sn;
+      }
+      __syncthreads();
+      // columns: A <- A J, V <- V J
+      for (int e = tid; e < half * m; e += EIG_THREADS) {
+        const int k = e / m, i = e % m;
+        int p, q;
+        tournament_pair(M, s, k, &p, &q);
+        const double c = rot_c[k], sn = rot_s[k];
+        if (q >= m || sn == 0.0) continue;
+        const double ap = As[i + p * la], aq = As[i + q * la];
+        As[i + p * la] = c * ap - sn * aq;
+        As[i + q * la] = sn * ap + c * aq;
+        const double vp = Vs[i + (size_t)p * lv], vq = Vs[i + (size_t)q * lv];
+        Vs[i + (size_t)p * lv] = c * vp - sn * vq;
+        Vs[i + (size_t)q * lv] = sn * vp + c * vq;
+      }
+      __syncthreads();
+      // rows: A <- J^T A
+      for (int e = tid; e < half * m; e += EIG_THREADS) {
+        const int k = e / m, j = e % m;
+        int p, q;
+        tournament_pair(M, s, k, &p, &q);
+        const double c = rot_c[k], sn = rot_s[k];
+        if (q >= m || sn == 0.0) continue;
+        const double ap = As[p + j * la], aq = As[q + j * la];
+        As[p + j * la] = c * ap - sn * aq;
+        As[q + j * la] = sn * ap + c * aq;
+      }
+      __syncthreads();
+    }
+    if (flag == 0) break;                            // a whole sweep without a rotation
+  }
+
+  // ---- ascending order (ties by index), Y ---------------------------------------------------------------------------
+  // rank of eigenvalue j = number of eigenvalues that sort before it
+  __shared__ int ranks[128];
+  for (int j = tid; j < m; j += EIG_THREADS) {
+    const double dj = As[j + j * la];
+    int r = 0;
+    for (int i = 0; i < m; ++i) {
+      const double di = As[i + i * la];
+      r += (di < dj) || (di == dj && i < j);
+    }
+    ranks[j] = r;
+    theta[r] = dj;
+  }
+  __syncthreads();
+  if (!gev) {
+    for (int e = tid; e < m * m; e += EIG_THREADS) {
+      const int i = e % m, j = e / m;
+      Y[i + (int64_t)ranks[j] * ldy] = Vs[i + (size_t)j * lv];
+    }
+  } else {
+    // Y = L^-T Z: back substitution up the rows, thread = column
+    for (int j = tid; j < m; j += EIG_THREADS) {
+      double* y = Y + (int64_t)ranks[j] * ldy;
+      for (int i = m - 1; i >= 0; --i) {
+        double acc = Vs[i + (size_t)j * lv];
+        for (int k = i + 1; k < m; ++k) acc -= Lg[k + i * m] * y[k];
+        y[i] = acc / Lg[i + i * m];
+      }
+    }
+  }
+  if (tid == 0) info[0] = (double)sweeps;
+}
+
+size_t small_eig_work_doubles(int m) { return (size_t)2 * m * m + 64; }
+
+// all on `st`; returns false if m is out of range
+bool launch_small_eig(hipStream_t st, const double* H, int64_t ldh, const double* S, int64_t lds, int m, bool gev, double* theta,
+                      double* Y, int64_t ldy, double* work, double* info) {
+  if (m < 1 || m > 128) return false;
+  const int la = m | 1;
+  const bool vlds = (size_t)2 * la * m * sizeof(double) <= (size_t)150 * 1024;
+  const size_t shmem = sizeof(double) * (size_t)la * m * (vlds ? 2 : 1);
+  if (vlds) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_eig_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
+    hipLaunchKernelGGL(small_eig_kernel<true>, dim3(1), dim3(EIG_THREADS), shmem, st, H, ldh, S, lds, m, gev ? 1 : 0, theta, Y, ldy, work, info);
+  } else {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_eig_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
+    hipLaunchKernelGGL(small_eig_kernel<false>, dim3(1), dim3(EIG_THREADS), shmem, st, H, ldh, S, lds, m, gev ? 1 : 0, theta, Y, ldy, work, info);
+  }
+  return true;
+}
+
+// ---- glue kernels of the device-resident Rayleigh-Ritz step --------------------------------------------------------
+// new columns c0..c0+k of the projected matrix: block (mt x k, ld = mt) -> Hd[:, c0:c0+k] and its mirror image
+__global__ __launch_bounds__(256) void rr_scatter_kernel(const double* __restrict__ blk, int mt, int k, int c0, double* __restrict__ Hd,
+                                                         int64_t ld) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < mt * k; e += gridDim.x * 256) {
+    const int i = e % mt, j = e / mt;
+    const double v = blk[e];
+    Hd[i + (int64_t)(c0 + j) * ld] = v;
+    if (i < c0) Hd[(c0 + j) + (int64_t)i * ld] = v;
+  }
+}
+void launch_rr_scatter(hipStream_t st, const double* blk, int mt, int k, int c0, double* Hd, int64_t ld) {
+  hipLaunchKernelGGL(rr_scatter_kernel, dim3((mt * k + 255) / 256), dim3(256), 0, st, blk, mt, k, c0, Hd, ld);
+}
+
+// Y (m x m, ld) and theta -> the operand images the panel kernels read: Ypk = Y[:, 0:q] and Y2pk = -Y diag(theta)
+// with leading dimension ldm (rows m..ldm zero) and qpad columns (columns q.. zero), theta_pk[0:q], and theta[0:m] +
+// info appended to the result buffer the host fetches
+__global__ __launch_bounds__(256) void rr_pack_kernel(const double* __restrict__ Y, int64_t ld, const double* __restrict__ theta, int m, int q,
+                                                      int ldm, int qpad, double* __restrict__ Ypk, double* __restrict__ Y2pk,
+                                                      double* __restrict__ theta_pk, const double* __restrict__ info,
+                                                      double* __restrict__ result_tail) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < ldm * qpad; e += gridDim.x * 256) {
+    const int i = e % ldm, j = e / ldm;
+    const double v = (i < m && j < q) ? Y[i + (int64_t)j * ld] : 0.0;
+    Ypk[e] = v;
+    Y2pk[e] = (i < m && j < q) ? -v * theta[j] : 0.0;
+  }
+  if (blockIdx.x == 0) {
+    for (int j = threadIdx.x; j < qpad; j += 256) theta_pk[j] = j < q ? theta[j] : 0.0;
+    if (result_tail) {
+      for (int j = threadIdx.x; j < m; j += 256) result_tail[j] = theta[j];
+      if (threadIdx.x == 0) result_tail[m] = info[0];
+    }
+  }
+}
+void launch_rr_pack(hipStream_t st, const double* Y, int64_t ld, const double* theta, int m, int q, int ldm, int qpad, double* Ypk,
+                    double* Y2pk, double* theta_pk, const double* info, double* result_tail) {
+  hipLaunchKernelGGL(rr_pack_kernel, dim3((ldm * qpad + 255) / 256), dim3(256), 0, st, Y, ld, theta, m, q, ldm, qpad, Ypk, Y2pk,
+                     theta_pk, info, result_tail);
+}

@@ -115,3 +115,11 @@ void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_
                                const int64_t* idx_dev, int k, double* dst, int64_t ldd);
 // dst[i, c] = i < nloc ? src[c * lds + i] : 0 for i < nrows_pad (the received chunk of a reduce-scatter -> panel columns)
 void launch_chunk_to_panel(hipStream_t st, const double* src, int64_t lds, int64_t nloc, int64_t nrows_pad, int k, double* dst, int64_t ldd);
+
+// ---- device-side Rayleigh-Ritz (k_smalleig.hip): all eigenpairs of H y = theta y / H y = theta S y, order m <= 128 ------
+size_t small_eig_work_doubles(int m);
+bool launch_small_eig(hipStream_t st, const double* H, int64_t ldh, const double* S, int64_t lds, int m, bool gev, double* theta,
+                      double* Y, int64_t ldy, double* work, double* info);
+void launch_rr_scatter(hipStream_t st, const double* blk, int mt, int k, int c0, double* Hd, int64_t ld);
+void launch_rr_pack(hipStream_t st, const double* Y, int64_t ld, const double* theta, int m, int q, int ldm, int qpad, double* Ypk,
+                    double* Y2pk, double* theta_pk, const double* info, double* result_tail);

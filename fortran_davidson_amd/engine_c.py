@@ -234,6 +234,29 @@ class CEngine:
     def set_width(self, m):
         self._chk(self.lib.dav_set_width(self.h, C.c_int(m)))
 
+    def rr_enable(self, on=True):
+        self._chk(self.lib.dav_rr_enable(self.h, C.c_int(1 if on else 0)))
+
+    def project_dev(self, c0, k):
+        self._chk(self.lib.dav_project_dev(self.h, C.c_int(c0), C.c_int(k)))
+
+    def rr_ritz(self, m, ncorr, lowest, method=METHOD_DPR, want_gram=False):
+        """(theta[m], resnorm[lowest], sweeps[, C, G]) from the device-resident projected matrices"""
+        theta, res, sweeps = np.zeros(m), np.zeros(lowest), C.c_int(0)
+        if want_gram:
+            Cm, G = np.zeros((m, ncorr), order="F"), np.zeros((ncorr, ncorr), order="F")
+            self._chk(self.lib.dav_rr_ritz(self.h, C.c_int(m), C.c_int(ncorr), C.c_int(lowest), C.c_int(method), _dp(theta), _dp(res),
+                                           _dp(Cm), C.c_int64(m), _dp(G), C.c_int64(ncorr), C.byref(sweeps)))
+            return theta, res, sweeps.value, Cm, G
+        self._chk(self.lib.dav_rr_ritz(self.h, C.c_int(m), C.c_int(ncorr), C.c_int(lowest), C.c_int(method), _dp(theta), _dp(res),
+                                       None, C.c_int64(0), None, C.c_int64(0), C.byref(sweeps)))
+        return theta, res, sweeps.value
+
+    def rr_get(self, m, ncols):
+        theta, Y = np.zeros(m), np.zeros((m, ncols), order="F")
+        self._chk(self.lib.dav_rr_get(self.h, C.c_int(m), C.c_int(ncols), _dp(theta), _dp(Y), C.c_int64(m)))
+        return theta, Y
+
     def bench_apply(self, k, reps, which=OP_A):
         """(ms per apply END TO END: pack + kernel + reduction, algorithmic bytes per apply)"""
         ms, nbytes = C.c_double(), C.c_double()

@@ -20,7 +20,7 @@ module davidson_device
   use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_cholesky_inverse, lapack_matmul
   implicit none
   private
-  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, &
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, engine_set_device_rr, &
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
@@ -38,6 +38,9 @@ module davidson_device
      !> follows the reference's matrix-free driver - convergence of all wanted pairs tested at once, no
      !> sticky flags (src/davidson.f90:416) - instead of the dense one (:176)
      logical :: free_semantics = .false.
+     !> opt-in (engine_set_device_rr / DAVIDSON_DEVICE_RR=1): the Rayleigh-Ritz problem is solved on the device
+     !> (one-workgroup Jacobi, order <= 128) and the projected matrices, Ritz values and vectors never leave HBM
+     logical :: device_rr = .false.
   end type davidson_engine
 
   !> Wall time of the last solve by phase (seconds): 1 setup (init basis + first projection),
@@ -105,7 +108,19 @@ contains
     call get_environment_variable("DAVIDSON_CORRECTION_POLICY", envbuf, envlen, envstat)
     eng%policy = POLICY_ALL
     if (envstat == 0 .and. envlen > 0) call engine_set_correction_policy(eng, envbuf(1:envlen))
+    call get_environment_variable("DAVIDSON_DEVICE_RR", envbuf, envlen, envstat)
+    eng%device_rr = (envstat == 0 .and. envlen > 0 .and. envbuf(1:1) == "1")
   end subroutine engine_create
+
+  !> Device-side Rayleigh-Ritz (SURVEY 8f-1) on or off for the solves of this engine.  Off (default): the projected
+  !> problem is solved by host LAPACK, as the reference does (src/lapack_wrapper.f90:14-91).  On: one-workgroup Jacobi
+  !> eigensolver on the device for bases up to 128 columns (wider bases fall back to the host); same Ritz pairs to
+  !> rounding, same iteration counts; the H-down / Y-up transfers and one synchronisation per iteration disappear.
+  subroutine engine_set_device_rr(eng, on)
+    type(davidson_engine), intent(inout) :: eng
+    logical, intent(in) :: on
+    eng%device_rr = on
+  end subroutine engine_set_device_rr
 
   !> Which Ritz pairs get a correction vector each iteration.  "all" (default) is the reference's policy:
   !> one correction per basis vector, the basis doubles (src/davidson.f90:195-213), sticky convergence on the
@@ -325,7 +340,7 @@ contains
     ! stored matrix: the dense driver's sticky convergence flags (src/davidson.f90:176); matrix-free operator A:
     ! the matrix-free driver's all-at-once test (:416)
     call davidson_device_loop(eng%h, eng%n, lowest, method, max_iterations, tolerance, iters, max_dim, &
-         eng%gev, .not. eng%free_semantics, eigenvalues, policy=eng%policy)
+         eng%gev, .not. eng%free_semantics, eigenvalues, policy=eng%policy, device_rr=eng%device_rr)
     if (present(eigenvectors)) then
        call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), eigenvectors, &
             int(size(eigenvectors, 1), c_int64_t)), "dav_panel_get")
@@ -337,7 +352,7 @@ contains
   !> matrix-free path's all-at-once test (:416).  fun_a/fun_b present = operators applied by the
   !> host through callbacks (API-faithful matrix-free path).
   subroutine davidson_device_loop(h, n, lowest, method, max_iterations, tolerance, iters, max_dim, gev, &
-       sticky, eigenvalues, fun_a, fun_b, policy)
+       sticky, eigenvalues, fun_a, fun_b, policy, device_rr)
     type(c_ptr), intent(in) :: h
     integer, intent(in) :: n, lowest, max_iterations, max_dim
     character(len=*), intent(in) :: method
@@ -350,10 +365,15 @@ contains
     !> POLICY_UNCONVERGED (opt-in, changes iters): corrections only for those of the `lowest` wanted pairs
     !> whose residual is still above the tolerance; all-at-once convergence test.
     integer, intent(in), optional :: policy
+    !> Rayleigh-Ritz on the device (engine_set_device_rr); bases wider than 128 columns use the host
+    logical, intent(in), optional :: device_rr
 
     integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr, nvec
     integer(c_int), allocatable :: sel(:)
-    real(dp), allocatable :: theta_sel(:), tols(:), c_pre(:, :), g_pre(:, :)
+    integer(c_int) :: sweeps
+    logical :: drr
+    real(dp), allocatable :: theta_sel(:), tols(:)
+    real(dp), allocatable, target :: c_pre(:, :), g_pre(:, :)
     logical :: have_pre
     logical :: expand_now
     integer(c_int64_t) :: ld
@@ -389,6 +409,9 @@ contains
     hm = 0.0_dp
     sm = 0.0_dp
     has_converged = .false.
+    drr = .false.
+    if (present(device_rr)) drr = device_rr .and. cap <= 128
+    call check_dav(dav_rr_enable(h, merge(1_c_int, 0_c_int, drr)), "dav_rr_enable")
 
     ! 1. initial basis: unit vectors at the lowest diagonal entries; W0 = A*V0
     m = initial_dimension
@@ -396,7 +419,11 @@ contains
     call check_dav(dav_init_basis(h, int(m, c_int), idx), "dav_init_basis")
     if (host_ops) call apply_host_block(h, n, 0, m, fun_a, fun_b)
     ! 2. projected matrices
-    call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
+    if (drr) then
+       call check_dav(dav_project_dev(h, 0_c_int, int(m, c_int)), "dav_project")
+    else
+       call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
+    end if
     call lap(1)
 
     iters = max_iterations + 1
@@ -422,7 +449,7 @@ contains
        ! (order 64: 150-200 us on the host) although a converged iteration only needs the `lowest` wanted pairs.
        ! When the previous residues say convergence is near, solve for those pairs first (MRRR on a subset) and
        ! test them; only if the test fails is the full problem solved.  Same Ritz pairs, same iteration count.
-       if (pol == POLICY_ALL .and. expand_now .and. i > 1 .and. m >= 48 .and. 2 * lowest <= m) then
+       if (.not. drr .and. pol == POLICY_ALL .and. expand_now .and. i > 1 .and. m >= 48 .and. 2 * lowest <= m) then
           if (maxval(errors) < sqrt(tolerance)) then
              if (gev) then
                 call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, lowest, sm(1:m, 1:m))
@@ -450,10 +477,12 @@ contains
        end if
        nvec = min(m, initial_dimension)
        if (pol == POLICY_ALL .and. expand_now) nvec = m
-       if (gev) then
-          call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, nvec, sm(1:m, 1:m))
-       else
-          call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, nvec)
+       if (.not. drr) then
+          if (gev) then
+             call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, nvec, sm(1:m, 1:m))
+          else
+             call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, nvec)
+          end if
        end if
        call lap(2)
 
@@ -461,7 +490,20 @@ contains
        phase = meth
        if (.not. expand_now) phase = DAV_METHOD_NONE      ! this iteration ends in a restart: no correction block
        have_pre = .false.
-       if (phase == DAV_METHOD_DPR) then
+       if (drr) then
+          ! 3 + 4 on the device: eigenpairs of the device-resident projected matrices, then the same fused phase from
+          ! where they lie; one synchronisation brings back the Ritz values, the residual norms and the Gram blocks
+          if (phase == DAV_METHOD_DPR) then
+             if (allocated(c_pre)) deallocate(c_pre, g_pre)
+             allocate(c_pre(m, ncorr), g_pre(ncorr, ncorr))
+             call check_dav(dav_rr_ritz(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), int(phase, c_int), theta, &
+                  errors, c_loc(c_pre), int(m, c_int64_t), c_loc(g_pre), int(ncorr, c_int64_t), sweeps), "dav_rr_ritz")
+             have_pre = .true.
+          else
+             call check_dav(dav_rr_ritz(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), int(phase, c_int), theta, &
+                  errors, c_null_ptr, 0_c_int64_t, c_null_ptr, 0_c_int64_t, sweeps), "dav_rr_ritz")
+          end if
+       else if (phase == DAV_METHOD_DPR) then
           ! the Gram blocks of the first orthonormalisation pass come back with the residual norms
           if (allocated(c_pre)) deallocate(c_pre, g_pre)
           allocate(c_pre(m, ncorr), g_pre(ncorr, ncorr))
@@ -548,13 +590,21 @@ contains
           call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
           if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
           call lap(5)
-          call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          if (drr) then
+             call check_dav(dav_project_dev(h, int(m, c_int), int(kt, c_int)), "dav_project")
+          else
+             call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          end if
           call lap(6)
           m = m + kt
        else
           ! collapse restart: V <- V*Y(:, 1:2L)   (src/davidson.f90:218)
           kt = initial_dimension
-          call check_dav(dav_restart(h, int(m, c_int), int(kt, c_int), y, int(m, c_int64_t)), "dav_restart")
+          if (drr) then
+             call check_dav(dav_rr_restart(h, int(m, c_int), int(kt, c_int)), "dav_rr_restart")
+          else
+             call check_dav(dav_restart(h, int(m, c_int), int(kt, c_int), y, int(m, c_int64_t)), "dav_restart")
+          end if
           ! Y is S-orthonormal in the generalized case: make V Euclidean-orthonormal again (the
           ! reference gets this from its next QR of the whole basis)
           if (gev) call block_orthonormalise(h, n, 0, kt)
@@ -564,7 +614,11 @@ contains
           call lap(5)
           hm = 0.0_dp
           sm = 0.0_dp
-          call check_dav(dav_project(h, 0_c_int, int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          if (drr) then
+             call check_dav(dav_project_dev(h, 0_c_int, int(kt, c_int)), "dav_project")
+          else
+             call check_dav(dav_project(h, 0_c_int, int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          end if
           call lap(6)
           m = kt
        end if
@@ -886,7 +940,7 @@ contains
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_A, diag_a), "dav_set_operator_host")
     call check_dav(dav_set_operator_host(eng%h, DAV_OP_B, diag_b), "dav_set_operator_host")
     call davidson_device_loop(eng%h, n, lowest, method, max_iterations, tolerance, iters, max_dim, .true., &
-         .false., eigenvalues, fun_matrix_gemv, fun_second_matrix_gemv, eng%policy)
+         .false., eigenvalues, fun_matrix_gemv, fun_second_matrix_gemv, eng%policy, eng%device_rr)
     call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), ritz_vectors, &
          int(size(ritz_vectors, 1), c_int64_t)), "dav_panel_get")
     call engine_destroy(eng)

@@ -143,6 +143,14 @@ contains
     end if
   end subroutine fd_engine_set_storage
 
+  subroutine fd_engine_set_device_rr(p, on) bind(C, name="fd_engine_set_device_rr")
+    type(c_ptr), value :: p
+    integer(c_int), value :: on
+    type(davidson_engine), pointer :: eng
+    call c_f_pointer(p, eng)
+    call engine_set_device_rr(eng, on /= 0)
+  end subroutine fd_engine_set_device_rr
+
   subroutine fd_engine_set_policy(p, code) bind(C, name="fd_engine_set_policy")
     type(c_ptr), value :: p
     integer(c_int), value :: code

@@ -258,6 +258,36 @@ module davidson_hip_c
        integer(c_int), value :: m, kt
        integer(c_int) :: ierr
      end function
+     !> device-resident Rayleigh-Ritz (opt-in): the projected matrices, Ritz values and vectors stay in HBM
+     function dav_rr_enable(h, on) bind(C, name="dav_rr_enable") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: on
+       integer(c_int) :: ierr
+     end function
+     function dav_project_dev(h, c0, k) bind(C, name="dav_project_dev") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: c0, k
+       integer(c_int) :: ierr
+     end function
+     function dav_rr_ritz(h, m, ncorr, lowest, method, theta, resnorm, c, ldc, g, ldg, sweeps) &
+          bind(C, name="dav_rr_ritz") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, ncorr, lowest, method
+       real(c_double), intent(out) :: theta(*), resnorm(*)
+       type(c_ptr), value :: c, g                       ! c_null_ptr: no Gram blocks wanted
+       integer(c_int64_t), value :: ldc, ldg
+       integer(c_int), intent(out) :: sweeps
+       integer(c_int) :: ierr
+     end function
+     function dav_rr_restart(h, m, keep) bind(C, name="dav_rr_restart") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, keep
+       integer(c_int) :: ierr
+     end function
      function dav_restart(h, m, keep, yk, ldy) bind(C, name="dav_restart") result(ierr)
        import :: c_ptr, c_int, c_int64_t, c_double
        type(c_ptr), value :: h

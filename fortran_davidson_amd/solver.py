@@ -114,6 +114,10 @@ class DavidsonEngine:
         that have not converged (Fortran: engine_set_correction_policy)."""
         self.lib.fd_engine_set_policy(self.p, C.c_int({"all": 0, "unconverged": 1}[policy]))
 
+    def set_device_rr(self, on=True):
+        """Rayleigh-Ritz on the device (Fortran: engine_set_device_rr); default off = host LAPACK as the reference."""
+        self.lib.fd_engine_set_device_rr(self.p, C.c_int(1 if on else 0))
+
     def read_matrix(self, which, path, fmt="text"):
         """Operator from a file, streamed to HBM (Fortran: engine_read_matrix): "text" = the reference's
         write_matrix/read_matrix dump format, "f64" = raw row-major float64."""

@@ -210,6 +210,24 @@ int dav_expand(dav_handle_t h, int m, int kt);
 /* K5 - replaces V = V * Y(:, 1:keep) (src/davidson.f90:218): V, W and B*V are contracted with the
  * same keep columns of Yk (m x keep); sets m = keep. */
 int dav_restart(dav_handle_t h, int m, int keep, const double* Yk, int64_t ldy);
+/* ---- device-resident Rayleigh-Ritz (opt-in) -------------------------------------------------------
+ * Replaces lapack_generalized_eigensolver (src/lapack_wrapper.f90:14-91: DSYEV / DSYGV itype=1,'V','U', called at
+ * src/davidson.f90:152-156 and :394) together with the transfers around it: after dav_rr_enable(h, 1) dav_project also
+ * keeps the projected matrices H (and S) in HBM, dav_rr_ritz solves H y = theta y / H y = theta S y for ALL m pairs
+ * on the device (one-workgroup cyclic Jacobi, generalized case through a Cholesky factor of S; m <= 128) and runs the
+ * Ritz phase of dav_ritz_residual_correction_n / _g from the eigenpairs where they lie.  One synchronisation returns
+ * theta_out[0..m) (ascending), resnorm[0..lowest) and, if C != NULL, the Gram blocks C (m x ncorr) and G (ncorr x
+ * ncorr) of the first orthonormalisation pass.  Eigenvectors are normalised as DSYEV / DSYGV normalise them (Y^T Y = I,
+ * Y^T S Y = I); their signs are the eigensolver's own.  sweeps_out: Jacobi sweeps used (may be NULL). */
+int dav_rr_enable(dav_handle_t h, int on);
+/* dav_project without host copies and without a synchronisation (the device keeps H and S) */
+int dav_project_dev(dav_handle_t h, int c0, int k);
+int dav_rr_ritz(dav_handle_t h, int m, int ncorr, int lowest, int method, double* theta_out, double* resnorm, double* C,
+                int64_t ldc, double* G, int64_t ldg, int* sweeps_out);
+/* collapse restart with the device-resident eigenvectors: V = V * Y(:, 1:keep) (src/davidson.f90:218) */
+int dav_rr_restart(dav_handle_t h, int m, int keep);
+/* the device-resident Ritz values / eigenvectors (m x ncols) on the host (either pointer may be NULL) */
+int dav_rr_get(dav_handle_t h, int m, int ncols, double* theta, double* Y, int64_t ldy);
 /* Generic block transform dst[:, d0:d0+q] = src[:, s0:s0+p] * M (p x q); used for the basis
  * re-orthonormalisation after a generalized restart. */
 int dav_panel_transform(dav_handle_t h, int src_panel, int s0, int p, const double* M, int64_t ldm,
