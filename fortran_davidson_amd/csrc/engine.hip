@@ -85,33 +85,8 @@ static int rccl_load() {
     if (r_ != ncclSuccess) return fail(std::string(#call) + " failed: " + g_rccl.GetErrorString(r_)); \
   } while (0)
 
-// ---- loopback transport: several ranks of one problem as threads of ONE process on ONE GPU ----------
-// Same collective semantics as the RCCL path (in-place all-gather of equal slabs, sum all-reduce with
-// a rank-ordered, hence identical, result on every rank).  It exists so that the row-slab logic of a
-// multi-rank engine (offsets, padding, gathered indices) can be verified on a single-GPU box; the
-// multi-GPU data path is RCCL.
-struct LocalGroup {
-  int n = 0;
-  pthread_barrier_t bar;
-  const double* send[16] = {nullptr};
-};
-
-// ---- shared-memory transport: several ranks of one problem as PROCESSES that share one GPU ---------------
-// Same collective semantics again, through a POSIX shared-memory segment (staging via the host).  It lets
-// the complete multi-process launch flow (torch.distributed.run, id broadcast, one engine per process,
-// barriers) run on a single-GPU box; the multi-GPU data path is RCCL.
-struct ShmHeader {
-  pthread_barrier_t bar;
-  int nranks;
-  size_t slot_doubles;
-};
-struct ShmGroup {
-  ShmHeader* hdr = nullptr;
-  double* slots = nullptr;      // nranks x slot_doubles
-  size_t bytes = 0;
-  std::string name;
-  bool owner = false;
-};
+struct LocalGroup;
+struct ShmGroup;
 
 // ------------------------------------------------------------------------------------------------
 struct OpDesc {
@@ -522,8 +497,44 @@ static int need_comm(E* e) {
   return 0;
 }
 
-// recv[p*count .. (p+1)*count) = send of rank p, for every rank (send may alias recv + rank*count)
-static int coll_allgather(E* e, const double* send, double* recv, size_t count) {
+// ---- test transports (build flag DAV_TEST_TRANSPORTS, on in this repository's Makefile because the GPU tests run on a
+// one-GPU box; `make DAV_TEST_TRANSPORTS=0` builds the library without them) ---------------------------------------
+#ifndef DAV_TEST_TRANSPORTS
+#define DAV_TEST_TRANSPORTS 1
+#endif
+#if DAV_TEST_TRANSPORTS
+// ---- loopback transport: several ranks of one problem as threads of ONE process on ONE GPU ----------
+// Same collective semantics as the RCCL path (in-place all-gather of equal slabs, sum all-reduce with
+// a rank-ordered, hence identical, result on every rank).  It exists so that the row-slab logic of a
+// multi-rank engine (offsets, padding, gathered indices) can be verified on a single-GPU box; the
+// multi-GPU data path is RCCL.
+struct LocalGroup {
+  int n = 0;
+  pthread_barrier_t bar;
+  const double* send[16] = {nullptr};
+};
+
+// ---- shared-memory transport: several ranks of one problem as PROCESSES that share one GPU ---------------
+// Same collective semantics again, through a POSIX shared-memory segment (staging via the host).  It lets
+// the complete multi-process launch flow (torch.distributed.run, id broadcast, one engine per process,
+// barriers) run on a single-GPU box; the multi-GPU data path is RCCL.
+struct ShmHeader {
+  pthread_barrier_t bar;
+  int nranks;
+  size_t slot_doubles;
+};
+struct ShmGroup {
+  ShmHeader* hdr = nullptr;
+  double* slots = nullptr;      // nranks x slot_doubles
+  size_t bytes = 0;
+  std::string name;
+  bool owner = false;
+};
+
+static bool has_test_transport(const E* e) { return e->lg != nullptr || e->shm != nullptr; }
+static size_t test_transport_max_message(const E* e) { return e->shm ? e->shm->hdr->slot_doubles : (size_t)-1; }
+
+static int test_allgather(E* e, const double* send, double* recv, size_t count) {
   if (e->lg) {
     LocalGroup* g = e->lg;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -550,12 +561,10 @@ static int coll_allgather(E* e, const double* send, double* recv, size_t count) 
     pthread_barrier_wait(&g->hdr->bar);
     return 0;
   }
-  NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
-  return 0;
+  return fail("no test transport");
 }
 
-// buf <- sum over ranks of buf (same bits on every rank)
-static int coll_allreduce(E* e, double* buf, size_t count) {
+static int test_allreduce(E* e, double* buf, size_t count) {
   if (e->lg) {
     LocalGroup* g = e->lg;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -585,12 +594,10 @@ static int coll_allreduce(E* e, double* buf, size_t count) {
     HIPCHK(hipMemcpy(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
     return 0;
   }
-  NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
-  return 0;
+  return fail("no test transport");
 }
 
-// recv[0 .. count) = sum over ranks p of send_p[rank*count .. (rank+1)*count)  (send holds nranks chunks)
-static int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
+static int test_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
   if (e->lg) {
     LocalGroup* g = e->lg;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -622,8 +629,7 @@ static int coll_reduce_scatter(E* e, const double* send, double* recv, size_t co
     HIPCHK(hipMemcpy(recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
     return 0;
   }
-  NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
-  return 0;
+  return fail("no test transport");
 }
 
 static void shm_release(E* e) {
@@ -696,6 +702,38 @@ extern "C" int dav_local_group_join(dav_handle_t* handles, int n) {
   g->n = n;
   pthread_barrier_init(&g->bar, nullptr, (unsigned)n);
   for (int r = 0; r < n; ++r) handles[r]->lg = g;
+  return 0;
+}
+
+#else
+static bool has_test_transport(const E*) { return false; }
+static size_t test_transport_max_message(const E*) { return (size_t)-1; }
+static int test_allgather(E*, const double*, double*, size_t) { return fail("built without test transports"); }
+static int test_allreduce(E*, double*, size_t) { return fail("built without test transports"); }
+static int test_reduce_scatter(E*, const double*, double*, size_t) { return fail("built without test transports"); }
+static void shm_release(E*) {}
+extern "C" int dav_comm_init_shm(dav_handle_t, const char*) { return fail("dav_comm_init_shm: built without DAV_TEST_TRANSPORTS"); }
+extern "C" int dav_local_group_join(dav_handle_t*, int) { return fail("dav_local_group_join: built without DAV_TEST_TRANSPORTS"); }
+#endif
+
+// recv[p*count .. (p+1)*count) = send of rank p, for every rank (send may alias recv + rank*count)
+static int coll_allgather(E* e, const double* send, double* recv, size_t count) {
+  if (has_test_transport(e)) return test_allgather(e, send, recv, count);
+  NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
+  return 0;
+}
+
+// buf <- sum over ranks of buf (same bits on every rank)
+static int coll_allreduce(E* e, double* buf, size_t count) {
+  if (has_test_transport(e)) return test_allreduce(e, buf, count);
+  NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
+  return 0;
+}
+
+// recv[0 .. count) = sum over ranks p of send_p[rank*count .. (rank+1)*count)  (send holds nranks chunks)
+static int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
+  if (has_test_transport(e)) return test_reduce_scatter(e, send, recv, count);
+  NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
   return 0;
 }
 
@@ -1740,7 +1778,7 @@ extern "C" int dav_panel_get(dav_handle_t e, int panel, int c0, int k, double* o
   // ONE all-gather per batch of columns: the slabs go out as a contiguous nslab x kb block ([rank][column][row] on
   // arrival), in batches the staging buffer holds
   int kmax = (int)std::max<size_t>(1, e->scratch_doubles / ((size_t)e->nranks * (size_t)e->nslab));
-  if (e->shm) kmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)kmax, e->shm->hdr->slot_doubles / (size_t)e->nslab));
+  kmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)kmax, test_transport_max_message(e) / (size_t)e->nslab));
   for (int j0 = 0; j0 < k; j0 += kmax) {
     const int kb = std::min(kmax, k - j0);
     const size_t chunk = (size_t)e->nslab * kb;

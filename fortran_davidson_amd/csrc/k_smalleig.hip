@@ -13,6 +13,7 @@
 // ascending (ties by index), eigenvectors in the matching order.  One workgroup: the order is at most 128, the sweeps
 // are latency (barrier) bound, not throughput bound - measured against the host in DESIGN.md.
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 constexpr int EIG_THREADS = 1024;
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
                                                                double* __restrict__ Y, int64_t ldy, double* __restrict__ work,
                                                                double* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, NT = blockDim.x;   // as many waves as a step has work for: a barrier costs per wave
   const int la = m | 1;                        // odd leading dimension: column and row walks are both conflict free
   double* As = smem;                           // m x m
   double* Vs = VLDS ? smem + (size_t)la * m : work;   // accumulated rotations (ld = lv)
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
   __shared__ int flag;
 
   // ---- load; generalized: reduce to the standard problem ------------------------------------------------------
-  for (int e = tid; e < m * m; e += EIG_THREADS) {
+  for (int e = tid; e < m * m; e += NT) {
     const int i = e % m, j = e / m;
     As[i + j * la] = H[i + (int64_t)j * ldh];
   }
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
   __syncthreads();
   if (gev) {
     // Cholesky S = L L^T, right-looking, in global scratch (m steps, the whole workgroup updates the trailing block)
-    for (int e = tid; e < m * m; e += EIG_THREADS) Lg[e] = S[(e % m) + (int64_t)(e / m) * lds_];
+    for (int e = tid; e < m * m; e += NT) Lg[e] = S[(e % m) + (int64_t)(e / m) * lds_];
     __syncthreads();
     for (int j = 0; j < m; ++j) {
       const double d = Lg[j + j * m];
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
       __syncthreads();
       if (flag != 0) break;
       const double sd = sqrt(d);
-      for (int i = j + tid; i < m; i += EIG_THREADS) Lg[i + j * m] = i == j ? sd : Lg[i + j * m] / sd;
+      for (int i = j + tid; i < m; i += NT) Lg[i + j * m] = i == j ? sd : Lg[i + j * m] / sd;
       __syncthreads();
       // trailing update: S[i, k] -= L[i, j] L[k, j] for j < k <= i
       const int nt = m - j - 1;
-      for (int e = tid; e < nt * nt; e += EIG_THREADS) {
+      for (int e = tid; e < nt * nt; e += NT) {
         const int i = j + 1 + e % nt, k = j + 1 + e / nt;
         if (k <= i) Lg[i + k * m] -= Lg[i + j * m] * Lg[k + j * m];
       }
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
     if (flag != 0) { if (tid == 0) info[0] = (double)flag; return; }
     // C = L^-1 H L^-T.  X = L^-1 H: forward substitution down the rows, all columns at once (thread = column)
     for (int i = 0; i < m; ++i) {
-      for (int j = tid; j < m; j += EIG_THREADS) {
+      for (int j = tid; j < m; j += NT) {
         double acc = As[i + j * la];
         for (int k = 0; k < i; ++k) acc -= Lg[i + k * m] * As[k + j * la];
         As[i + j * la] = acc / Lg[i + i * m];
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
     }
     // C = X L^-T: the same substitution on the rows of X (thread = row), i.e. C^T = L^-1 X^T
     for (int jc = 0; jc < m; ++jc) {
-      for (int i = tid; i < m; i += EIG_THREADS) {
+      for (int i = tid; i < m; i += NT) {
         double acc = As[i + jc * la];
         for (int k = 0; k < jc; ++k) acc -= Lg[jc + k * m] * As[i + k * la];
         As[i + jc * la] = acc / Lg[jc + jc * m];
@@ -92,13 +93,13 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
       __syncthreads();
     }
     // symmetrise (rounding): the Jacobi sweeps read both triangles
-    for (int e = tid; e < m * m; e += EIG_THREADS) {
+    for (int e = tid; e < m * m; e += NT) {
       const int i = e % m, j = e / m;
       if (i > j) { const double v = 0.5 * (As[i + j * la] + As[j + i * la]); As[i + j * la] = v; As[j + i * la] = v; }
     }
     __syncthreads();
   }
-  for (int e = tid; e < m * m; e += EIG_THREADS) Vs[(e % m) + (size_t)(e / m) * lv] = (e % m) == (e / m) ? 1.0 : 0.0;
+  for (int e = tid; e < m * m; e += NT) Vs[(e % m) + (size_t)(e / m) * lv] = (e % m) == (e / m) ? 1.0 : 0.0;
   __syncthreads();
 
   // ---- cyclic Jacobi ------------------------------------------------------------------------------------------------
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
       }
       __syncthreads();
       // columns: A <- A J, V <- V J
-      for (int e = tid; e < half * m; e += EIG_THREADS) {
+      for (int e = tid; e < half * m; e += NT) {
         const int k = e / m, i = e % m;
         int p, q;
         tournament_pair(M, s, k, &p, &q);
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
       }
       __syncthreads();
       // rows: A <- J^T A
-      for (int e = tid; e < half * m; e += EIG_THREADS) {
+      for (int e = tid; e < half * m; e += NT) {
         const int k = e / m, j = e % m;
         int p, q;
         tournament_pair(M, s, k, &p, &q);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
   // ---- ascending order (ties by index), Y ---------------------------------------------------------------------------
   // rank of eigenvalue j = number of eigenvalues that sort before it
   __shared__ int ranks[128];
-  for (int j = tid; j < m; j += EIG_THREADS) {
+  for (int j = tid; j < m; j += NT) {
     const double dj = As[j + j * la];
     int r = 0;
     for (int i = 0; i < m; ++i) {
@@ -174,13 +175,13 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
   }
   __syncthreads();
   if (!gev) {
-    for (int e = tid; e < m * m; e += EIG_THREADS) {
+    for (int e = tid; e < m * m; e += NT) {
       const int i = e % m, j = e / m;
       Y[i + (int64_t)ranks[j] * ldy] = Vs[i + (size_t)j * lv];
     }
   } else {
     // Y = L^-T Z: back substitution up the rows, thread = column
-    for (int j = tid; j < m; j += EIG_THREADS) {
+    for (int j = tid; j < m; j += NT) {
       double* y = Y + (int64_t)ranks[j] * ldy;
       for (int i = m - 1; i >= 0; --i) {
         double acc = Vs[i + (size_t)j * lv];
@@ -201,14 +202,16 @@ bool launch_small_eig(hipStream_t st, const double* H, int64_t ldh, const double
   const int la = m | 1;
   const bool vlds = (size_t)2 * la * m * sizeof(double) <= (size_t)150 * 1024;
   const size_t shmem = sizeof(double) * (size_t)la * m * (vlds ? 2 : 1);
+  // a Jacobi step has (m/2) * m element pairs per phase: four per thread
+  const int threads = std::min(EIG_THREADS, std::max(64, ((m * m / 8 + 63) / 64) * 64));
   if (vlds) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_eig_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
-    hipLaunchKernelGGL(small_eig_kernel<true>, dim3(1), dim3(EIG_THREADS), shmem, st, H, ldh, S, lds, m, gev ? 1 : 0, theta, Y, ldy, work, info);
+    hipLaunchKernelGGL(small_eig_kernel<true>, dim3(1), dim3(threads), shmem, st, H, ldh, S, lds, m, gev ? 1 : 0, theta, Y, ldy, work, info);
   } else {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_eig_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
-    hipLaunchKernelGGL(small_eig_kernel<false>, dim3(1), dim3(EIG_THREADS), shmem, st, H, ldh, S, lds, m, gev ? 1 : 0, theta, Y, ldy, work, info);
+    hipLaunchKernelGGL(small_eig_kernel<false>, dim3(1), dim3(threads), shmem, st, H, ldh, S, lds, m, gev ? 1 : 0, theta, Y, ldy, work, info);
   }
   return true;
 }
