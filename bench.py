@@ -320,6 +320,20 @@ def main():
                     "eigenvalues": [float(x) for x in lam_g[:3]],
                     "note": "sweeps_of_A x ms_per_sweep + the same number of generated-B sweeps is the device floor; the "
                             "remainder is host latency of the inner MINRES (dot-product round trips, small uploads)"}
+                # opt-in mixed-precision correction path: the inner sweeps of A read an fp32 copy of its tiles
+                try:
+                    g.set_inner_precision(32)
+                    g.solve("GJD", 1000, args.tol, want_vectors=False)    # warm-up: builds the fp32 copy (80 GB at N=200000)
+                    g.c.synchronize(); g.c.reset_stats()
+                    dt_m, it_m, lam_m = timed_solves(g, "GJD", 1, args.tol)
+                    sm_ = g.c.stats()
+                    extras["configs3_gjd"]["inner_fp32"] = {
+                        "seconds": round(dt_m, 4), "iters": it_m, "sweeps_of_A": int(sm_.applies),
+                        "ms_per_sweep_of_A_end_to_end": round(sm_.apply_ms / max(sm_.applies, 1), 3),
+                        "max_abs_eigenvalue_diff_vs_fp64_inner": float(np.abs(lam_m - lam_g).max()),
+                        "note": "engine_set_inner_precision(eng, 32): inner MINRES sweeps of A on fp32 tiles (fp64 accumulation); not the default"}
+                except Exception as exc:   # noqa: BLE001  (e.g. no room for the fp32 copy)
+                    extras["configs3_gjd"]["inner_fp32"] = {"error": repr(exc)[:300]}
                 g.close()
             except Exception as exc:       # noqa: BLE001
                 extras["configs3_gjd"] = {"error": repr(exc)[:300]}

@@ -100,6 +100,8 @@ struct OpDesc {
   double* e_table = nullptr; // device
   double* diag = nullptr;    // device, nloc_pad (local rows)
   int storage = 0;           // dense: 0 = full, 1 = symmetric-tiled (lower block triangle)
+  float* a32 = nullptr;      // fp32 copy of the symmetric tiles: operand of the mixed-precision inner sweeps (lazy)
+  bool a32_valid = false, a32_refused = false;
 };
 
 struct SmallBuf {            // device small matrix + pinned staging
@@ -140,6 +142,7 @@ struct dav_engine {
   double* sym_slab = nullptr;     // device: direct slabs (per item) followed by transposed slabs (per tile)
   size_t sym_slab_doubles = 0;    // grown on demand: what the largest launch so far needed (schedule x column groups)
   bool sym_no_pair = false;       // paired 32-column launches did not fit the memory: 16 columns per launch
+  int inner_bits = 64;            // 32: the sweeps INSIDE the GJD correction read an fp32 copy of the stored tiles (dav_set_inner_precision)
   // Several ranks: the lower block triangle is dealt out by groups of 4 block rows (what every schedule's super rows
   // nest in), boustrophedon over the ranks so that the long block rows spread evenly.  row_off[I] = first tile of
   // block row I in this rank's storage, -1 = another rank's.
@@ -421,6 +424,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   }
   for (int w = 0; w < 2; ++w) {
     hipFree(e->op[w].a);
+    hipFree(e->op[w].a32);
     hipFree(e->op[w].e_table);
     hipFree(e->op[w].diag);
   }
@@ -894,6 +898,8 @@ static int sym_ensure_slabs(E* e, size_t doubles) {
 
 static int alloc_dense(E* e, int which) {
   OpDesc& o = e->op[which];
+  o.a32_valid = false;       // new contents: the fp32 copy is rebuilt when the next inner sweep asks for it
+  o.a32_refused = false;
   if (o.a && o.storage != e->storage) { hipFree(o.a); o.a = nullptr; }
   o.storage = e->storage;
   if (!o.a) {
@@ -911,6 +917,18 @@ static int alloc_dense(E* e, int which) {
     }
   }
   if (o.storage == 1) CHK(sym_setup(e));
+  return 0;
+}
+
+// Mixed-precision correction path.  bits = 32: the block sweeps INSIDE the GJD correction solve
+// (src/davidson.f90:700-734: the solve only has to produce a good correction vector) read an fp32 copy of the stored
+// symmetric tiles - half the bytes per inner sweep; entries are widened to fp64 in registers, every product and sum
+// stays fp64.  Everything the answer is made of - the A*V sweep of the expansion, projections, residuals, the
+// convergence test - keeps reading the fp64 matrix.  bits = 64 (default): the reference's precision throughout.
+// Operators that are not stored symmetric tiles (row slabs, generated operators) are not affected.
+extern "C" int dav_set_inner_precision(dav_handle_t e, int bits) {
+  if (bits != 32 && bits != 64) return fail("dav_set_inner_precision: 32 or 64");
+  e->inner_bits = bits;
   return 0;
 }
 
@@ -1192,7 +1210,25 @@ extern "C" int dav_get_diagonal(dav_handle_t e, int which, double* out) {
 
 // ---- K1 -----------------------------------------------------------------------------------------
 // dst[:, 0:k] = Op(which) * src[:, 0:k] for device-resident column blocks with leading dimension ldp
-static int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed) {
+// fp32 copy of a stored symmetric-tiled operator, made when the first inner sweep wants it; false (and fp64 sweeps) when
+// the memory for it is not there
+static bool inner_f32_tiles(E* e, OpDesc& o) {
+  if (e->inner_bits != 32 || o.kind != DAV_KIND_DENSE || o.storage != 1 || o.a32_refused) return false;
+  if (o.a32_valid) return true;
+  const size_t count = (size_t)std::max<int64_t>(e->sym_ntiles_local, 1) * SYM_TB * SYM_TB;
+  if (!o.a32 && hipMalloc(&o.a32, sizeof(float) * count) != hipSuccess) {
+    (void)hipGetLastError();
+    o.a32 = nullptr;
+    o.a32_refused = true;
+    return false;
+  }
+  launch_tiles_to_f32(e->stream, o.a, o.a32, (int64_t)count);
+  o.a32_valid = true;
+  return true;
+}
+
+// inner = true: a sweep inside the GJD correction solve (may run on the fp32 copy, dav_set_inner_precision)
+static int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner = false) {
   OpDesc& o = e->op[which];
   if (o.kind == DAV_KIND_NONE) return fail("dav_apply: operator not set");
   if (o.kind == DAV_KIND_HOST) return fail("dav_apply: host operator - move blocks with dav_panel_get/put");
@@ -1215,7 +1251,9 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;
-      const int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, std::min(kk, 16));
+      const bool use32 = inner && inner_f32_tiles(e, o);
+      int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, std::min(kk, 16));
+      if (use32 && R == 1) R = 2;            // the fp32 tiles are read by the super-row kernels only
       const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
       const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)e->sym_nitems * 16 * SYM_TB;
       const int64_t tstride = R > 1 ? pl->zslots * 16 * SYM_TB : (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
@@ -1226,7 +1264,7 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
         CHK(sym_ensure_slabs(e, (size_t)(dstride + tstride) + 1));
       }
       int slot = -1, kslot = -1, cslot = -1;
-      const double stored = o.kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
+      const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
       double bytes = stored + 16.0 * (double)e->n * kk;
       // end to end: everything that turns the source columns into W - packing, (all-gather,) the sweep, the fixed-order sum(, reduce-scatter)
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
@@ -1246,7 +1284,8 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       const int nitems = R > 1 ? pl->nitems : e->sym_nitems;
       if (nitems > 0) {                      // a rank can be left without a block row (more ranks than groups of block rows)
         if (R > 1)
-          launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, o.a, e->sym_row_off, o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{},
+          launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
+                             o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{},
                              e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, e->xt, kk, e->sym_slab, slabT, npair,
                              e->xt_group_stride, dstride, tstride);
         else if (o.kind != DAV_KIND_DENSE)
@@ -1998,10 +2037,10 @@ extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const dou
       if (active[j] != 0.0) { c_lo = std::min(c_lo, j); c_hi = std::max(c_hi, j + 1); }
     c_lo = c_lo / 16 * 16;
     c_hi = std::min(m, (c_hi + 15) / 16 * 16);
-    CHK(apply_ptr(e, DAV_OP_A, v + (size_t)c_lo * e->ldp, c_hi - c_lo, ua + (size_t)c_lo * e->ldp, true));
+    CHK(apply_ptr(e, DAV_OP_A, v + (size_t)c_lo * e->ldp, c_hi - c_lo, ua + (size_t)c_lo * e->ldp, true, true));
     const double* ubp = v;
     if (gev) {
-      CHK(apply_ptr(e, DAV_OP_B, v + (size_t)c_lo * e->ldp, c_hi - c_lo, ub + (size_t)c_lo * e->ldp, true));
+      CHK(apply_ptr(e, DAV_OP_B, v + (size_t)c_lo * e->ldp, c_hi - c_lo, ub + (size_t)c_lo * e->ldp, true, true));
       ubp = ub;
     }
     if (getenv("DAV_GJD_TRACE")) {

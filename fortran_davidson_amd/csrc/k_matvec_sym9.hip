@@ -24,19 +24,25 @@
 // product and the transposed partial are multiplied by 0.
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 // row_off[I] = first tile of block row I in this rank's storage (k_matvec_sym.hip)
 __device__ __forceinline__ const double* sym9_tile(const double* tiles, const int64_t* __restrict__ row_off, int I, int J) {
   return tiles + (row_off[I] + J) * (int64_t)(SYM_TB * SYM_TB);
 }
 
-template <int R, bool GEN>
-__global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
+// F32: the tiles are an fp32 copy of the stored operator (mixed-precision inner sweeps of the GJD correction):
+// half the bytes per sweep, entries widened to fp64 in registers, products and sums in fp64 as before.
+template <int R, bool GEN, bool F32>
+__global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restrict__ tiles_v, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items,
                                                              const int* __restrict__ zslot_begin, const double* __restrict__ xt,
                                                              double* __restrict__ slabD, double* __restrict__ slabT, int kcols,
                                                              int npair, int64_t xt_gstride, int64_t slabD_gstride,
                                                              int64_t slabT_gstride, int nb, OpParams op, int64_t n) {
+  const double* tiles = static_cast<const double*>(tiles_v);
+  const float* tiles32 = static_cast<const float*>(tiles_v);
+  (void)tiles; (void)tiles32;
   constexpr int NCG = 4 / R;            // column groups of 16 tile columns per batch
   constexpr int NRS = 2 * R;            // 128-row slices
   constexpr int BW = 16 * NCG;          // tile columns per batch
@@ -107,12 +113,15 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __res
   const int nsteps = nunits * 4;
   double* tw = tr + wave * TRW;
 
-  f64x2 ra[4][4];
+  // register ring of the tile loads: raw fp32 pairs when the tiles are fp32 (widened where they are consumed, so that
+  // the loads stay three half-steps ahead), fp64 pairs otherwise
+  using RingT = std::conditional_t<F32, float2, f64x2>;
+  RingT ra[4][4];
   const uint64_t seedmix = op.seed * 0x9E3779B97F4A7C15ull;
   const double gscale = op.sparsity * (1.0 / 9007199254740992.0);
   // tile this wave works on in tile column J: its own if it is stored, else the (stored) tile of block row Imax
   auto tile_row = [&](int J) { return (I <= Imax && J <= I) ? I : Imax; };
-  auto load_hs = [&](int s, f64x2 (&a)[4]) {
+  auto load_hs = [&](int s, RingT (&a)[4]) {
     s = s < nsteps ? s : nsteps - 1;
     const int q = s >> 2, hs = s & 3;
     const int J = J0 + q / UPJ, col = (q % UPJ) * BW + w * 16;
@@ -138,6 +147,10 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __res
           a[u].y = (gi + 1 < n && cj < n) ? dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi + 1, cj) : 0.0;
         }
       }
+    } else if constexpr (F32) {
+      const float* ad = tiles32 + (row_off[Ie] + J) * (int64_t)(SYM_TB * SYM_TB) + (int64_t)(col + g) * SYM_TB + 128 * rhalf + 32 * hs + 2 * c;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float2*>(ad + (int64_t)(4 * u) * SYM_TB);
     } else {
       const double* ad = sym9_tile(tiles, row_off, Ie, J) + (int64_t)(col + g) * SYM_TB + 128 * rhalf + 32 * hs + 2 * c;
 #pragma unroll
@@ -183,7 +196,9 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __res
     for (int s4 = 0; s4 < 4; ++s4) zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs) {
-      f64x2 (&a)[4] = ra[hs];
+      f64x2 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)ra[hs][u].x, (double)ra[hs][u].y};
       load_hs(q * 4 + hs + DEPTH, ra[(hs + DEPTH) & 3]);
       f64x2 p[2][2], xb[2][2];
 #pragma unroll
@@ -256,17 +271,27 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const double* __res
   }
 }
 
-void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, const int64_t* row_off, OpParams op, int64_t n, int nb,
-                        const int* items_dev,
-                        int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int npair,
-                        int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
+void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool tiles_f32, const int64_t* row_off, OpParams op, int64_t n,
+                        int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
+                        double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   dim3 grid(nitems * npair), block(512);
-#define DAV_SYM9_LAUNCH(RR, GG)                                                                                              \
-  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
-                     npair, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
-  if (R == 4) { if (gen) DAV_SYM9_LAUNCH(4, true); else DAV_SYM9_LAUNCH(4, false); }
-  else        { if (gen) DAV_SYM9_LAUNCH(2, true); else DAV_SYM9_LAUNCH(2, false); }
+#define DAV_SYM9_LAUNCH(RR, GG, FF)                                                                                              \
+  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG, FF>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, \
+                     kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
+  if (R == 4) { if (gen) DAV_SYM9_LAUNCH(4, true, false); else if (tiles_f32) DAV_SYM9_LAUNCH(4, false, true); else DAV_SYM9_LAUNCH(4, false, false); }
+  else        { if (gen) DAV_SYM9_LAUNCH(2, true, false); else if (tiles_f32) DAV_SYM9_LAUNCH(2, false, true); else DAV_SYM9_LAUNCH(2, false, false); }
 #undef DAV_SYM9_LAUNCH
+}
+
+// fp32 copy of stored tiles (same layout): the operand of the mixed-precision inner sweeps
+__global__ __launch_bounds__(256) void tiles_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t count4) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count4; e += (int64_t)gridDim.x * 256) {
+    const f64x2 a = reinterpret_cast<const f64x2*>(src)[2 * e], b = reinterpret_cast<const f64x2*>(src)[2 * e + 1];
+    reinterpret_cast<float4*>(dst)[e] = float4{(float)a.x, (float)a.y, (float)b.x, (float)b.y};
+  }
+}
+void launch_tiles_to_f32(hipStream_t st, const double* src, float* dst, int64_t count) {
+  hipLaunchKernelGGL(tiles_to_f32_kernel, dim3(256 * 32), dim3(256), 0, st, src, dst, count / 4);
 }
 
 // W[J*256 + r, col] = sum over the items of super row J / R of slabD (block row J % R of the item)

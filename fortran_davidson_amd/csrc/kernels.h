@@ -102,9 +102,11 @@ bool matvec_sym_can_pair();
 void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, const int64_t* owned,
                        int nb, int64_t nloc, int k, double* dst, int64_t ldd, int64_t chunk_rows, int64_t total_rows);
 // super-row schedules (k_matvec_sym9.hip): R = 2 or 4 block rows per workgroup, transposed partials summed on chip
-void launch_matvec_sym9(hipStream_t st, int R, bool gen, const double* tiles, const int64_t* row_off, OpParams op, int64_t n, int nb,
-                        const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
+void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool tiles_f32, const int64_t* row_off, OpParams op, int64_t n,
+                        int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
                         double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
+// fp32 copy of `count` stored tile entries (count a multiple of 4)
+void launch_tiles_to_f32(hipStream_t st, const double* src, float* dst, int64_t count);
 void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,
                         const int* zslot_begin_dev, const int64_t* owned, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd,
                         int64_t chunk_rows, int64_t total_rows);

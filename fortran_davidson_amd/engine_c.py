@@ -234,6 +234,9 @@ class CEngine:
     def set_width(self, m):
         self._chk(self.lib.dav_set_width(self.h, C.c_int(m)))
 
+    def set_inner_precision(self, bits):
+        self._chk(self.lib.dav_set_inner_precision(self.h, C.c_int(bits)))
+
     def rr_enable(self, on=True):
         self._chk(self.lib.dav_rr_enable(self.h, C.c_int(1 if on else 0)))
 

@@ -20,7 +20,7 @@ module davidson_device
   use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_cholesky_inverse, lapack_matmul
   implicit none
   private
-  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, engine_set_device_rr, &
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, engine_set_device_rr, engine_set_inner_precision, &
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
@@ -108,9 +108,22 @@ contains
     call get_environment_variable("DAVIDSON_CORRECTION_POLICY", envbuf, envlen, envstat)
     eng%policy = POLICY_ALL
     if (envstat == 0 .and. envlen > 0) call engine_set_correction_policy(eng, envbuf(1:envlen))
+    call get_environment_variable("DAVIDSON_INNER_PRECISION", envbuf, envlen, envstat)
+    if (envstat == 0 .and. envlen >= 2) then
+       if (envbuf(1:2) == "32") call engine_set_inner_precision(eng, 32)
+    end if
     call get_environment_variable("DAVIDSON_DEVICE_RR", envbuf, envlen, envstat)
     eng%device_rr = (envstat == 0 .and. envlen > 0 .and. envbuf(1:1) == "1")
   end subroutine engine_create
+
+  !> Mixed-precision correction path (SURVEY 8f-4): bits = 32 lets the block sweeps inside the GJD correction solve
+  !> read an fp32 copy of the stored symmetric tiles (fp64 products and sums); residuals, projections and the
+  !> convergence test stay on the fp64 matrix.  bits = 64 (default) = the reference's precision throughout.
+  subroutine engine_set_inner_precision(eng, bits)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: bits
+    call check_dav(dav_set_inner_precision(eng%h, int(bits, c_int)), "dav_set_inner_precision")
+  end subroutine engine_set_inner_precision
 
   !> Device-side Rayleigh-Ritz (SURVEY 8f-1) on or off for the solves of this engine.  Off (default): the projected
   !> problem is solved by host LAPACK, as the reference does (src/lapack_wrapper.f90:14-91).  On: one-workgroup Jacobi

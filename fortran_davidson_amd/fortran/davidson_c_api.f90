@@ -143,6 +143,14 @@ contains
     end if
   end subroutine fd_engine_set_storage
 
+  subroutine fd_engine_set_inner_precision(p, bits) bind(C, name="fd_engine_set_inner_precision")
+    type(c_ptr), value :: p
+    integer(c_int), value :: bits
+    type(davidson_engine), pointer :: eng
+    call c_f_pointer(p, eng)
+    call engine_set_inner_precision(eng, int(bits))
+  end subroutine fd_engine_set_inner_precision
+
   subroutine fd_engine_set_device_rr(p, on) bind(C, name="fd_engine_set_device_rr")
     type(c_ptr), value :: p
     integer(c_int), value :: on

@@ -258,6 +258,12 @@ module davidson_hip_c
        integer(c_int), value :: m, kt
        integer(c_int) :: ierr
      end function
+     function dav_set_inner_precision(h, bits) bind(C, name="dav_set_inner_precision") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: bits
+       integer(c_int) :: ierr
+     end function
      !> device-resident Rayleigh-Ritz (opt-in): the projected matrices, Ritz values and vectors stay in HBM
      function dav_rr_enable(h, on) bind(C, name="dav_rr_enable") result(ierr)
        import :: c_ptr, c_int

@@ -114,6 +114,11 @@ class DavidsonEngine:
         that have not converged (Fortran: engine_set_correction_policy)."""
         self.lib.fd_engine_set_policy(self.p, C.c_int({"all": 0, "unconverged": 1}[policy]))
 
+    def set_inner_precision(self, bits):
+        """32: the sweeps inside the GJD correction read an fp32 copy of the stored symmetric tiles (Fortran:
+        engine_set_inner_precision); 64 (default): the reference's precision throughout."""
+        self.lib.fd_engine_set_inner_precision(self.p, C.c_int(bits))
+
     def set_device_rr(self, on=True):
         """Rayleigh-Ritz on the device (Fortran: engine_set_device_rr); default off = host LAPACK as the reference."""
         self.lib.fd_engine_set_device_rr(self.p, C.c_int(1 if on else 0))

@@ -210,6 +210,13 @@ int dav_expand(dav_handle_t h, int m, int kt);
 /* K5 - replaces V = V * Y(:, 1:keep) (src/davidson.f90:218): V, W and B*V are contracted with the
  * same keep columns of Yk (m x keep); sets m = keep. */
 int dav_restart(dav_handle_t h, int m, int keep, const double* Yk, int64_t ldy);
+/* Mixed-precision correction path (opt-in).  bits = 32: the block sweeps inside the GJD correction solve
+ * (replacing the dense projected solves of src/davidson.f90:700-734 + src/lapack_wrapper.f90:238-277) read an fp32 copy of
+ * the stored symmetric tiles (made on first use; half the bytes per inner sweep), widen to fp64 in registers and
+ * accumulate in fp64.  The expansion sweep, projections, residuals and the convergence test keep reading the fp64
+ * matrix, so eigenvalues and residual norms are unaffected; only the correction vectors carry fp32-rounded operator
+ * entries.  bits = 64 (default) is the reference's precision throughout. */
+int dav_set_inner_precision(dav_handle_t h, int bits);
 /* ---- device-resident Rayleigh-Ritz (opt-in) -------------------------------------------------------
  * Replaces lapack_generalized_eigensolver (src/lapack_wrapper.f90:14-91: DSYEV / DSYGV itype=1,'V','U', called at
  * src/davidson.f90:152-156 and :394) together with the transfers around it: after dav_rr_enable(h, 1) dav_project also
