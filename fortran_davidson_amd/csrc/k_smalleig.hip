@@ -202,8 +202,10 @@ bool launch_small_eig(hipStream_t st, const double* H, int64_t ldh, const double
   const int la = m | 1;
   const bool vlds = (size_t)2 * la * m * sizeof(double) <= (size_t)150 * 1024;
   const size_t shmem = sizeof(double) * (size_t)la * m * (vlds ? 2 : 1);
-  // a Jacobi step has (m/2) * m element pairs per phase: four per thread
-  const int threads = std::min(EIG_THREADS, std::max(64, ((m * m / 8 + 63) / 64) * 64));
+  // A Jacobi step has (m/2) * m element pairs per phase.  The phases are LDS-latency bound, not barrier bound: with four
+  // pairs per thread (512 threads at m = 64) a configs[1] solve took 4.25 ms against 3.54 ms with all 1024 threads
+  // (one or two pairs each), so the workgroup stays full down to m = 32
+  const int threads = m >= 32 ? EIG_THREADS : std::max(64, ((m * m / 2 + 63) / 64) * 64);
   if (vlds) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_eig_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
