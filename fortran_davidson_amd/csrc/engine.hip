@@ -854,10 +854,6 @@ static int sym_setup(E* e) {
     HIPCHK(hipMemcpy(pl.row_begin, prow.data(), sizeof(int) * prow.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pl.zslot_begin, zbeg.data(), sizeof(int) * zbeg.size(), hipMemcpyHostToDevice));
   }
-  if (e->nranks > 1) {
-    HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
-    HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
-  }
   return 0;
 }
 
@@ -1245,7 +1241,13 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
     // pairing shares the READS of stored tiles: nothing to share when the entries are generated
     int step = (pair_env && matvec_sym_can_pair() && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
-    const bool multi = e->nranks > 1;
+    // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
+    // reduce-scatter of this path through RCCL on a one-GPU box)
+    const bool multi = e->nranks > 1 || has_comm(e);
+    if (multi && !e->sym_wpart) {
+      HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
+      HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
+    }
     const int64_t* owned = multi ? e->sym_row_off : nullptr;
     const int64_t total_rows = (int64_t)e->nranks * e->nslab;
     for (int c = 0; c < k; c += step) {

@@ -197,14 +197,16 @@ def test_against_oracle_on_fresh_inputs():
         assert (residuals(A, None, lam, vec) < 1e-8).all()
 
 
-def test_sharded_code_path_through_rccl_single_rank(golden, monkeypatch):
+@pytest.mark.parametrize("storage", ["full", "symmetric"])
+def test_sharded_code_path_through_rccl_single_rank(golden, monkeypatch, storage):
     """DAVIDSON_FORCE_RCCL=1: a 1-rank RCCL communicator, so the all-gather of the packed basis block,
-    the all-reduces of Gram blocks / norms and the gathered panel download all run through RCCL."""
+    the all-reduces of Gram blocks / norms, the gathered panel download and - symmetric storage - the reduce-scatter
+    of the partial products all run through RCCL."""
     monkeypatch.setenv("DAVIDSON_FORCE_RCCL", "1")
     manifest, arrays = golden
     for name in ("n2000_std_dpr", "n1000_gev_restart_dpr"):
         case = manifest["dense"][name]
-        with fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=case["gev"]) as eng:
+        with fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=case["gev"], storage=storage) as eng:
             eng.comm_init(fd.CEngine.comm_unique_id())
             eng.c.set_timing(2)                                   # time the collectives too
             eng.generate_diagonal_dominant(1, case["sparsity"], seed=case["seed_a"])
