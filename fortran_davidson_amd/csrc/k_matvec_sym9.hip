@@ -33,7 +33,18 @@ __device__ __forceinline__ const double* sym9_tile(const double* tiles, const in
 
 // F32: the tiles are an fp32 copy of the stored operator (mixed-precision inner sweeps of the GJD correction):
 // half the bytes per sweep, entries widened to fp64 in registers, products and sums in fp64 as before.
-template <int R, bool GEN, bool F32>
+// M4 (k <= 8 only, i.e. R = 4): the products run on v_mfma_f64_4x4x4_4b_f64 - four independent 4x4x4 blocks per
+// instruction, 16.3 cycles (profiles/ubench/r02_mfma4x4.log) - instead of the 16-wide v_mfma_f64_16x16x4_f64, whose
+// block-column half 8..15 multiplies zeros at k <= 8: the same 64 matrix entries per instruction, half the pipe time,
+// half the accumulator registers.  Lane layout (measured): A lane = i + 4 blk + 16 k, B lane = j + 4 blk + 16 k,
+// D lane = j + 4 blk + 16 i; with lane = c + 16 g that is i / j = c & 3, blk = c >> 2, k (or D's i) = g - the natural
+// (direct) and the Gram (transposed) register layouts of this kernel fit as they are, the four blocks being four groups
+// of rows (direct) or of tile columns (transposed); the B operand is X restricted to block columns (c & 3) + 4 half,
+// the same for every blk.  Why it pays although the sweep is HBM-bound: on real data the matrix pipe's power sets the
+// clock - same box, N=200000, k=8, random X: 28.5 ms with every second MFMA removed 27.1 ms.
+__device__ __forceinline__ double mfma4_f64(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+template <int R, bool GEN, bool F32, bool M4>
 __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restrict__ tiles_v, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items,
                                                              const int* __restrict__ zslot_begin, const double* __restrict__ xt,
@@ -105,9 +116,14 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     for (int e = threadIdx.x; e < XT; e += 512) xsT[XROWS * XT + e] = 0.0;
   __syncthreads();
 
-  f64x4 acc[4][2];
+  static_assert(!M4 || R == 4, "the 4x4x4 path serves k <= 8, which is what R = 4 means");
+  f64x4 acc[4][2];                 // 16-wide MFMA: [half-step][row parity] x (4 row groups in the f64x4)
+  double acc4[4][2][2];            // 4x4x4 MFMA:  [half-step][row parity][block-column half]
 #pragma unroll
-  for (int hs = 0; hs < 4; ++hs) { acc[hs][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[hs][1] = f64x4{0.0, 0.0, 0.0, 0.0}; }
+  for (int hs = 0; hs < 4; ++hs) {
+    acc[hs][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[hs][1] = f64x4{0.0, 0.0, 0.0, 0.0};
+    acc4[hs][0][0] = acc4[hs][0][1] = acc4[hs][1][0] = acc4[hs][1][1] = 0.0;
+  }
 
   const int nunits = (J1 - J0) * UPJ;
   const int nsteps = nunits * 4;
@@ -158,13 +174,17 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     }
   };
   // B operand of the direct product for unit q (X_J rows of the unit's 16 tile columns), zero where this wave has no tile
-  auto load_b = [&](int q, double (&b)[4]) {
+  // b[u][0]: 16-wide MFMA, block column c.  b[u][0..1]: 4x4x4 MFMA, block columns (c & 3) and (c & 3) + 4.
+  auto load_b = [&](int q, double (&b)[4][2]) {
     q = q < nunits ? q : nunits - 1;
     const int J = J0 + q / UPJ, col = (q % UPJ) * BW + w * 16;
     const double dm = (I <= Imax && J <= I) ? 1.0 : 0.0;
-    const double* xj = xt + ((int64_t)J * SYM_TB + col + g) * 16 + c;
+    const double* xj = xt + ((int64_t)J * SYM_TB + col + g) * 16 + (M4 ? (c & 3) : c);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = xj[(4 * u) * 16] * dm;
+    for (int u = 0; u < 4; ++u) {
+      b[u][0] = xj[(4 * u) * 16] * dm;
+      if constexpr (M4) b[u][1] = xj[(4 * u) * 16 + 4] * dm;
+    }
   };
   // strip st of the run (64 tile columns; four per tile column): stage -> slabT slot (S, J) = [16 block columns][256 tile columns]
   const int64_t zbase = zslot_begin[S];
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     }
   };
 
-  double b[4], bn[4];
+  double b[4][2], bn[4][2];
   load_b(0, b);
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) load_hs(d, ra[d]);
@@ -188,19 +208,20 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     load_b(q + 1, bn);
     const int J = J0 + q / UPJ;
     const double zm = (I <= Imax && J < I) ? 1.0 : 0.0;
-    int xoff = (c < XROWS ? c : XROWS) * XT + 128 * hh + 4 * g;   // opaque: keeps the X_I reads inside the loop
+    int xoff = (M4 ? (c & 3) : (c < XROWS ? c : XROWS)) * XT + 128 * hh + 4 * g;   // opaque: keeps the X_I reads inside the loop
     asm volatile("" : "+v"(xoff));
     const double* xw = xsT + xoff;
     f64x4 zc[4];
+    double zc4[2][4];                 // [block-column half][row within the group of four]
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int s4 = 0; s4 < 4; ++s4) { zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0}; zc4[0][s4] = zc4[1][s4] = 0.0; }
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs) {
       f64x2 a[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)ra[hs][u].x, (double)ra[hs][u].y};
       load_hs(q * 4 + hs + DEPTH, ra[(hs + DEPTH) & 3]);
-      f64x2 p[2][2], xb[2][2];
+      f64x2 p[2][2], xb[2][2], xb1[2][2];
 #pragma unroll
       for (int u = 0; u < 4; ++u) *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c) = a[u];
 #pragma unroll
@@ -209,21 +230,55 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
         p[ib][1] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g + 2);
         xb[ib][0] = *reinterpret_cast<const f64x2*>(xw + 32 * hs + 16 * ib);
         xb[ib][1] = *reinterpret_cast<const f64x2*>(xw + 32 * hs + 16 * ib + 2);
+        if constexpr (M4) {           // block columns (c & 3) + 4
+          xb1[ib][0] = *reinterpret_cast<const f64x2*>(xw + 4 * XT + 32 * hs + 16 * ib);
+          xb1[ib][1] = *reinterpret_cast<const f64x2*>(xw + 4 * XT + 32 * hs + 16 * ib + 2);
+        }
       }
+      if constexpr (M4) {
+        // direct: D[row 2 (4 blk + i) + parity, block column j + 4 half] += sum_k A[row, tile column 4 u + k] X[.., ..]
+        // transposed: D[tile column 4 blk + i, block column j + 4 half] += sum_k P[row 16 ib + 4 k + r, tile column] X_I[row, ..]
+        // twelve independent accumulator chains, direct and transposed alternating
 #pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        acc[hs][0] = mfma_f64(a[2 * ib].x, b[2 * ib], acc[hs][0]);
-        zc[0] = mfma_f64(p[ib][0].x, xb[ib][0].x, zc[0]);
-        acc[hs][1] = mfma_f64(a[2 * ib].y, b[2 * ib], acc[hs][1]);
-        zc[1] = mfma_f64(p[ib][0].y, xb[ib][0].y, zc[1]);
-        acc[hs][0] = mfma_f64(a[2 * ib + 1].x, b[2 * ib + 1], acc[hs][0]);
-        zc[2] = mfma_f64(p[ib][1].x, xb[ib][1].x, zc[2]);
-        acc[hs][1] = mfma_f64(a[2 * ib + 1].y, b[2 * ib + 1], acc[hs][1]);
-        zc[3] = mfma_f64(p[ib][1].y, xb[ib][1].y, zc[3]);
+        for (int ib = 0; ib < 2; ++ib) {
+          acc4[hs][0][0] = mfma4_f64(a[2 * ib].x, b[2 * ib][0], acc4[hs][0][0]);
+          zc4[0][0] = mfma4_f64(p[ib][0].x, xb[ib][0].x, zc4[0][0]);
+          acc4[hs][0][1] = mfma4_f64(a[2 * ib].x, b[2 * ib][1], acc4[hs][0][1]);
+          zc4[1][0] = mfma4_f64(p[ib][0].x, xb1[ib][0].x, zc4[1][0]);
+          acc4[hs][1][0] = mfma4_f64(a[2 * ib].y, b[2 * ib][0], acc4[hs][1][0]);
+          zc4[0][1] = mfma4_f64(p[ib][0].y, xb[ib][0].y, zc4[0][1]);
+          acc4[hs][1][1] = mfma4_f64(a[2 * ib].y, b[2 * ib][1], acc4[hs][1][1]);
+          zc4[1][1] = mfma4_f64(p[ib][0].y, xb1[ib][0].y, zc4[1][1]);
+          acc4[hs][0][0] = mfma4_f64(a[2 * ib + 1].x, b[2 * ib + 1][0], acc4[hs][0][0]);
+          zc4[0][2] = mfma4_f64(p[ib][1].x, xb[ib][1].x, zc4[0][2]);
+          acc4[hs][0][1] = mfma4_f64(a[2 * ib + 1].x, b[2 * ib + 1][1], acc4[hs][0][1]);
+          zc4[1][2] = mfma4_f64(p[ib][1].x, xb1[ib][1].x, zc4[1][2]);
+          acc4[hs][1][0] = mfma4_f64(a[2 * ib + 1].y, b[2 * ib + 1][0], acc4[hs][1][0]);
+          zc4[0][3] = mfma4_f64(p[ib][1].y, xb[ib][1].y, zc4[0][3]);
+          acc4[hs][1][1] = mfma4_f64(a[2 * ib + 1].y, b[2 * ib + 1][1], acc4[hs][1][1]);
+          zc4[1][3] = mfma4_f64(p[ib][1].y, xb1[ib][1].y, zc4[1][3]);
+        }
+      } else {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          acc[hs][0] = mfma_f64(a[2 * ib].x, b[2 * ib][0], acc[hs][0]);
+          zc[0] = mfma_f64(p[ib][0].x, xb[ib][0].x, zc[0]);
+          acc[hs][1] = mfma_f64(a[2 * ib].y, b[2 * ib][0], acc[hs][1]);
+          zc[1] = mfma_f64(p[ib][0].y, xb[ib][0].y, zc[1]);
+          acc[hs][0] = mfma_f64(a[2 * ib + 1].x, b[2 * ib + 1][0], acc[hs][0]);
+          zc[2] = mfma_f64(p[ib][1].x, xb[ib][1].x, zc[2]);
+          acc[hs][1] = mfma_f64(a[2 * ib + 1].y, b[2 * ib + 1][0], acc[hs][1]);
+          zc[3] = mfma_f64(p[ib][1].y, xb[ib][1].y, zc[3]);
+        }
       }
     }
-    // z[reg]: tile column col + g + 4 reg, block column c, summed over this wave's 128 rows
-    {
+    if constexpr (M4) {
+      // z4[half]: tile column col + 4 (c >> 2) + g, block column (c & 3) + 4 half, summed over this wave's 128 rows
+      double* zr = &zred[q & 1][wave][0];
+      zr[lane] = ((zc4[0][0] + zc4[0][1]) + (zc4[0][2] + zc4[0][3])) * zm;
+      zr[64 + lane] = ((zc4[1][0] + zc4[1][1]) + (zc4[1][2] + zc4[1][3])) * zm;
+    } else {
+      // z[reg]: tile column col + g + 4 reg, block column c, summed over this wave's 128 rows
       const f64x4 z = ((zc[0] + zc[1]) + (zc[2] + zc[3])) * zm;
       double* zr = &zred[q & 1][wave][0];
       *reinterpret_cast<f64x2*>(zr + 2 * lane) = f64x2{z[0], z[1]};
@@ -233,17 +288,26 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     // this barrier also publishes the stage writes of unit q - 1: the previous strip is complete
     if (q % UPS == 0 && q > 0) flush_strip(q / UPS - 1);
     // the 2R waves of column group w sum disjoint parts of the 16 x 16 partial, slices in fixed order
-    for (int e = hh * EPW + lane; e < (hh + 1) * EPW; e += 64) {
+    constexpr int EPWU = M4 ? 128 / NRS : EPW;          // the 4x4x4 path exchanges 16 x 8 partials
+    for (int e = hh * EPWU + lane; e < (hh + 1) * EPWU; e += 64) {
       double s = zred[q & 1][w][e];
 #pragma unroll
       for (int sl = 1; sl < NRS; ++sl) s += zred[q & 1][sl * NCG + w][e];
-      const int half = e >> 7, ln = (e & 127) >> 1, j = e & 1;
-      const int cc = ln & 15, gg = ln >> 4, reg = 2 * half + j;
-      const int tcol = ((q % UPJ) * BW + w * 16 + gg + 4 * reg) & (ZW - 1);
-      zst[(q / UPS) & 1][cc * ZS + tcol] = s;
+      int bc, tcol;
+      if constexpr (M4) {
+        const int half = e >> 6, ln = e & 63, cc = ln & 15, gg = ln >> 4;
+        bc = (cc & 3) + 4 * half;
+        tcol = (q % UPJ) * BW + w * 16 + 4 * (cc >> 2) + gg;
+      } else {
+        const int half = e >> 7, ln = (e & 127) >> 1, j = e & 1;
+        const int gg = ln >> 4, reg = 2 * half + j;
+        bc = ln & 15;
+        tcol = (q % UPJ) * BW + w * 16 + gg + 4 * reg;
+      }
+      zst[(q / UPS) & 1][bc * ZS + (tcol & (ZW - 1))] = s;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = bn[u];
+    for (int u = 0; u < 4; ++u) { b[u][0] = bn[u][0]; b[u][1] = bn[u][1]; }
   }
   __syncthreads();
   flush_strip(nunits / UPS - 1);
@@ -254,9 +318,15 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
   for (int hs = 0; hs < 4; ++hs) {
     __syncthreads();
 #pragma unroll
-    for (int par = 0; par < 2; ++par)
+    for (int par = 0; par < 2; ++par) {
+      if constexpr (M4) {
+        tw[(c & 3) * RS + 2 * (4 * (c >> 2) + g) + par] = acc4[hs][par][0];
+        tw[((c & 3) + 4) * RS + 2 * (4 * (c >> 2) + g) + par] = acc4[hs][par][1];
+      } else {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) tw[c * RS + 2 * (g + 4 * reg) + par] = acc[hs][par][reg];
+        for (int reg = 0; reg < 4; ++reg) tw[c * RS + 2 * (g + 4 * reg) + par] = acc[hs][par][reg];
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < NRS; ++t) {
@@ -275,11 +345,21 @@ void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool
                         int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
                         double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   dim3 grid(nitems * npair), block(512);
-#define DAV_SYM9_LAUNCH(RR, GG, FF)                                                                                              \
-  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG, FF>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, \
+#define DAV_SYM9_LAUNCH(RR, GG, FF, MM)                                                                                          \
+  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG, FF, MM>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, \
                      kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
-  if (R == 4) { if (gen) DAV_SYM9_LAUNCH(4, true, false); else if (tiles_f32) DAV_SYM9_LAUNCH(4, false, true); else DAV_SYM9_LAUNCH(4, false, false); }
-  else        { if (gen) DAV_SYM9_LAUNCH(2, true, false); else if (tiles_f32) DAV_SYM9_LAUNCH(2, false, true); else DAV_SYM9_LAUNCH(2, false, false); }
+  // DAV_SYM_MFMA4=0: the k <= 8 sweep of a stored fp64 matrix on the 16-wide MFMA (A/B runs)
+  static const bool m4 = [] { const char* ev = getenv("DAV_SYM_MFMA4"); return !ev || atoi(ev) != 0; }();
+  if (R == 4) {
+    if (gen) DAV_SYM9_LAUNCH(4, true, false, true);
+    else if (tiles_f32) DAV_SYM9_LAUNCH(4, false, true, true);
+    else if (m4) DAV_SYM9_LAUNCH(4, false, false, true);
+    else DAV_SYM9_LAUNCH(4, false, false, false);
+  } else {
+    if (gen) DAV_SYM9_LAUNCH(2, true, false, false);
+    else if (tiles_f32) DAV_SYM9_LAUNCH(2, false, true, false);
+    else DAV_SYM9_LAUNCH(2, false, false, false);
+  }
 #undef DAV_SYM9_LAUNCH
 }
 
