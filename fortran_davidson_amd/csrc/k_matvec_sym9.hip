@@ -19,6 +19,11 @@
 // reproducible) into a 64-column stage that leaves the chip as 512-byte rows.  The direct partials need no
 // cross-wave sum over row slices at all (R = 4: none whatsoever; R = 2: two column groups, at the end of the run).
 //
+// Measured dead ends of this kernel (N=200000, random X, same box): without the per-unit barrier 28.9 against 28.3-28.6 ms
+// at k = 8 and no change at k = 16 / 32 - the barrier is not what the waves wait for; the LDS transposition of half-step
+// hs + 1 issued before the MFMAs of half-step hs (software pipeline, second set of Gram registers, 256 VGPRs) 54.0
+// against 50.7 ms at k = 32 and 32.5 against 30.1 ms at k = 16 - it costs a half-step of global-load lookahead.
+//
 // Tiles that do not exist for a wave (above the diagonal inside the R x R diagonal super block, or block rows past
 // the end of the matrix) are replaced by a stored tile of the same super row and masked: the B operand of the direct
 // product and the transposed partial are multiplied by 0.
