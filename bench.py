@@ -360,6 +360,18 @@ def main():
                     "sweeps": int(sf.applies), "launches": int(sf.apply_launches), "ms_per_launch": round(per_launch_ms, 2),
                     "entries_of_A_per_s_per_rank": round(entries / (per_launch_ms * 1e-3), 0) if per_launch_ms > 0 else None,
                     "eigenvalues": [float(x) for x in lam_f[:3]]}
+                # VALU roofline of the generator: one splitmix64 per generated entry = two 64-bit multiplies = 2 v_mad_u64_u32 +
+                # 4 v_mul_lo_u32 (quarter rate: 16 cycles per wave64 each) + ~28 full-rate integer / convert / fp64 instructions
+                # (4 cycles each) = ~208 cycles per 64 evaluations per SIMD
+                evals = entries * (0.5 if fstorage == "symmetric" else 1.0)
+                peak_evals = 1024 * 2.4e9 * 64 / 208.0
+                if per_launch_ms > 0:
+                    extras["configs4_free"]["roofline"] = {
+                        "bound": "valu-int", "unit": "hash evaluations/s", "achieved": round(evals / (per_launch_ms * 1e-3), 0),
+                        "peak": round(peak_evals, 0), "frac": round(evals / (per_launch_ms * 1e-3) / peak_evals, 4),
+                        "model": "1024 SIMDs x 2.4 GHz x 64 lanes / 208 cycles per wave-evaluation (6 quarter-rate 32-bit multiplies of the two "
+                                 "64-bit multiplies of splitmix64 = 96 cycles, ~28 full-rate instructions = 112 cycles); the MFMAs and the "
+                                 "LDS transposition of the sweep share the issue slots"}
                 f.close()
             except Exception as exc:       # noqa: BLE001
                 extras["configs4_free"] = {"error": repr(exc)[:300]}
