@@ -144,8 +144,8 @@ struct dav_engine {
   bool sym_no_pair = false;       // paired 32-column launches did not fit the memory: 16 columns per launch
   int inner_bits = 64;            // 32: the sweeps INSIDE the GJD correction read an fp32 copy of the stored tiles (dav_set_inner_precision)
   // Several ranks: the lower block triangle is dealt out by groups of 4 block rows (what every schedule's super rows
-  // nest in), boustrophedon over the ranks so that the long block rows spread evenly.  row_off[I] = first tile of
-  // block row I in this rank's storage, -1 = another rank's.
+  // nest in), longest group first to the least loaded rank (sym_group_owners).  row_off[I] = first tile of block row I
+  // in this rank's storage, -1 = another rank's.
   std::vector<int64_t> sym_row_off_h;
   int64_t* sym_row_off = nullptr; // device copy
   int64_t sym_ntiles_local = 0;
@@ -772,10 +772,24 @@ static int sym_schedule(const E* e, int kk) {
   return R;
 }
 
-// owner of the group of 4 block rows q: boustrophedon over the ranks (0 1 .. P-1 P-1 .. 1 0 0 1 ..)
-static int sym_group_owner(int q, int nranks) {
-  const int cyc = q / nranks, pos = q % nranks;
-  return (cyc & 1) ? nranks - 1 - pos : pos;
+// Owners of the groups of 4 block rows (what every schedule's super rows nest in): longest group first, each to the rank
+// that holds the fewest tiles so far (ties: lowest rank) - every rank computes the same table.  Cyclic or boustrophedon
+// dealing leaves the ranks 4-8 % apart at N=200000 on 8 ranks (the last, incomplete round hands out the longest block
+// rows); this stays within 0.5 %, and the sweep time of the slowest rank is what every rank waits for.
+static std::vector<int> sym_group_owners(int nb, int nranks) {
+  const int ng = (nb + 3) / 4;
+  std::vector<int> owner(ng, 0);
+  std::vector<int64_t> load(nranks, 0);
+  for (int q = ng - 1; q >= 0; --q) {
+    int64_t tiles = 0;
+    for (int I = 4 * q; I < std::min(nb, 4 * q + 4); ++I) tiles += I + 1;
+    int best = 0;
+    for (int r = 1; r < nranks; ++r)
+      if (load[r] < load[best]) best = r;
+    owner[q] = best;
+    load[best] += tiles;
+  }
+  return owner;
 }
 
 static int sym_setup(E* e) {
@@ -784,8 +798,9 @@ static int sym_setup(E* e) {
   const int nb = (int)(e->ncols_pad / SYM_TB);
   e->sym_row_off_h.assign(nb, -1);
   int64_t ntiles = 0;
+  const std::vector<int> gowner = sym_group_owners(nb, e->nranks);
   for (int I = 0; I < nb; ++I)
-    if (sym_group_owner(I / 4, e->nranks) == e->rank) { e->sym_row_off_h[I] = ntiles; ntiles += I + 1; }
+    if (gowner[I / 4] == e->rank) { e->sym_row_off_h[I] = ntiles; ntiles += I + 1; }
   e->sym_ntiles_local = ntiles;
   HIPCHK(hipMalloc(&e->sym_row_off, sizeof(int64_t) * nb));
   HIPCHK(hipMemcpy(e->sym_row_off, e->sym_row_off_h.data(), sizeof(int64_t) * nb, hipMemcpyHostToDevice));
@@ -1716,6 +1731,34 @@ extern "C" int dav_restart(dav_handle_t e, int m, int keep, const double* Yk, in
   if (keep <= 0 || keep > m) return fail("dav_restart: bad shape");
   CHK(dav_panel_transform(e, DAV_PANEL_V, 0, m, Yk, ldy, keep, DAV_PANEL_V, 0));
   e->m = keep;
+  return 0;
+}
+
+// Several ranks: every rank takes the driver's control decisions (converged? grow or restart? how many columns?) from
+// all-reduced small results, so they are identical by construction.  This makes that an enforced invariant instead of an
+// assumption: the words (iteration number, basis width, decisions) are all-reduced as max and as -min in one collective;
+// a rank that sees them differ returns an error - its process ends with a message, and the launcher tears the group down -
+// instead of walking into the next collective alone and hanging everybody.  One tiny all-reduce per outer iteration.
+extern "C" int dav_ranks_agree(dav_handle_t e, const double* words, int nwords) {
+  if (e->nranks <= 1 || !has_comm(e)) return 0;
+  CHK(bind(e));
+  if (nwords <= 0 || (size_t)(2 * nwords) > e->gram_doubles) return fail("dav_ranks_agree: bad word count");
+  // max(x) and max(-x) through the SUM all-reduce of the transports: encode every word of rank r in slot r of a
+  // nranks-wide row, so that the sum reproduces each rank's value
+  const size_t total = (size_t)nwords * e->nranks;
+  if (total > e->gram_doubles) return fail("dav_ranks_agree: too many words");
+  std::vector<double> buf(total, 0.0);
+  for (int i = 0; i < nwords; ++i) buf[(size_t)i * e->nranks + e->rank] = words[i];
+  HIPCHK(hipMemcpyAsync(e->gram_dev, buf.data(), sizeof(double) * total, hipMemcpyHostToDevice, e->stream));
+  CHK(coll_allreduce(e, e->gram_dev, total));
+  HIPCHK(hipMemcpyAsync(buf.data(), e->gram_dev, sizeof(double) * total, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < nwords; ++i)
+    for (int r = 0; r < e->nranks; ++r)
+      if (buf[(size_t)i * e->nranks + r] != words[i])
+        return fail("ranks disagree on a control decision of the driver loop (word " + std::to_string(i) + ": rank " + std::to_string(r) +
+                    " has " + std::to_string(buf[(size_t)i * e->nranks + r]) + ", rank " + std::to_string(e->rank) + " has " +
+                    std::to_string(words[i]) + "): inputs or environment differ between the ranks");
   return 0;
 }
 

@@ -234,6 +234,10 @@ class CEngine:
     def set_width(self, m):
         self._chk(self.lib.dav_set_width(self.h, C.c_int(m)))
 
+    def ranks_agree(self, words):
+        w = np.ascontiguousarray(words, dtype=np.float64)
+        self._chk(self.lib.dav_ranks_agree(self.h, _dp(w), C.c_int(w.size)))
+
     def set_inner_precision(self, bits):
         self._chk(self.lib.dav_set_inner_precision(self.h, C.c_int(bits)))
 

@@ -538,6 +538,10 @@ contains
        else
           done = all(errors < tolerance)
        end if
+       ! several ranks: the decisions of this iteration must be the same everywhere (they are, from all-reduced
+       ! results) - enforced, so that a diverged rank stops with a message instead of hanging its peers
+       call check_dav(dav_ranks_agree(h, [real(i, dp), real(m, dp), merge(1.0_dp, 0.0_dp, done), &
+            merge(1.0_dp, 0.0_dp, expand_now), real(ncorr, dp)], 5_c_int), "dav_ranks_agree")
        if (done) then
           iters = i
           exit outer_loop

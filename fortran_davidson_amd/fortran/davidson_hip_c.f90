@@ -258,6 +258,13 @@ module davidson_hip_c
        integer(c_int), value :: m, kt
        integer(c_int) :: ierr
      end function
+     function dav_ranks_agree(h, words, nwords) bind(C, name="dav_ranks_agree") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: words(*)
+       integer(c_int), value :: nwords
+       integer(c_int) :: ierr
+     end function
      function dav_set_inner_precision(h, bits) bind(C, name="dav_set_inner_precision") result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: h

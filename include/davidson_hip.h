@@ -210,6 +210,10 @@ int dav_expand(dav_handle_t h, int m, int kt);
 /* K5 - replaces V = V * Y(:, 1:keep) (src/davidson.f90:218): V, W and B*V are contracted with the
  * same keep columns of Yk (m x keep); sets m = keep. */
 int dav_restart(dav_handle_t h, int m, int keep, const double* Yk, int64_t ldy);
+/* Several ranks: returns an error if the ranks do not all pass the same `words` (the driver's control decisions of this
+ * iteration) - one small all-reduce; a no-op on a single rank.  Lets a diverged rank end with a message instead of
+ * leaving its peers in a collective. */
+int dav_ranks_agree(dav_handle_t h, const double* words, int nwords);
 /* Mixed-precision correction path (opt-in).  bits = 32: the block sweeps inside the GJD correction solve
  * (replacing the dense projected solves of src/davidson.f90:700-734 + src/lapack_wrapper.f90:238-277) read an fp32 copy of
  * the stored symmetric tiles (made on first use; half the bytes per inner sweep), widen to fp64 in registers and

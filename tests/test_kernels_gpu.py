@@ -439,3 +439,20 @@ def test_symmetric_sweep_over_several_ranks(nranks, sched, monkeypatch):
             assert relerr(res[2], G @ X) < 1e-12
             for a, b in zip(res, out[0]):
                 assert np.array_equal(a, b)              # every rank gathers the same bits
+
+
+def test_ranks_that_disagree_on_a_control_decision_stop_with_a_message():
+    """dav_ranks_agree: what the multi-rank driver loop calls once per iteration with its decisions; identical words pass,
+    different words are an error ON EVERY RANK (nobody is left alone in the next collective)."""
+    nranks = 3
+
+    def work(r, e):
+        e.ranks_agree([4.0, 32.0, 0.0, 1.0])
+        try:
+            e.ranks_agree([4.0, 32.0, 1.0 if r == 1 else 0.0, 1.0])
+        except fd.DavidsonHipError as exc:
+            return str(exc)
+        return "no error"
+
+    out = _run_ranks(nranks, lambda r: fd.CEngine(n=500, max_cols=16, rank=r, nranks=nranks), work)
+    assert all("ranks disagree" in o for o in out), out
