@@ -352,10 +352,10 @@ def test_hashed_operator_symmetric_generation_equals_the_dense_generator(n, k):
 
 @pytest.mark.parametrize("k", [8, 16, 40])
 def test_symmetric_super_row_schedules_at_a_size_that_selects_them(k):
-    """From 96 block rows on the sweep runs the super-row schedules (4 block rows per workgroup for k <= 8, else 2)
-    by itself: N=25000 (98 block rows, a ragged last super row), the same generated matrix in full storage
+    """From 200 block rows on the sweep runs the super-row schedules (4 block rows per workgroup for k <= 8, else 2)
+    by itself: N=51700 (202 block rows, a ragged last super row), the same generated matrix in full storage
     as the reference, stored tiles and the hashed operator generated in the sweep."""
-    n = 25000
+    n = 51700
     X = np.random.default_rng(k).standard_normal((n, k))
     with fd.CEngine(n=n, max_cols=48) as e:
         e.set_dense_generated(OP_A, 5, 1e-3)
