@@ -277,8 +277,8 @@ def main():
                     "ms_end_to_end": a8["ms_end_to_end"], "ms_kernel_only": a8["ms_kernel_only"],
                     "algorithmic_bytes_per_launch": a8["algorithmic_bytes"],
                     "traffic": pmc_traffic(n, storage, "matvec_sym9_kernel<4", 0) if (world == 1 and storage == "symmetric") else None,
-                    "note": "bytes = 8*S + 16*N*k, S = N(N+1)/2 (symmetric-tiled) or nloc*N (row slab); end to end = "
-                            "pack_xt + sweep kernel + fixed-order reduction of the partial sums (HIP events on the engine's stream)"}
+                    "note": "per rank: bytes = 8*S + 16*N*k, S = N(N+1)/2 / n_gpus (symmetric-tiled) or nloc*N (row slab); end to end = "
+                            "pack_xt (+ all-gather) + sweep kernel + fixed-order reduction of the partial sums (+ reduce-scatter); HIP events on the engine's stream"}
 
     extras = {}
     if not args.headline_only:

@@ -1936,9 +1936,10 @@ extern "C" int dav_bench_apply2(dav_handle_t e, int which, int k, int reps, doub
   *avg_ms = total / reps;
   *kernel_ms = ktotal / reps;
   const bool sym = e->op[which].storage == 1;
-  *bytes = (sym ? (e->op[which].kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) : 0.0)
+  // per rank: the stored bytes and the flops of the symmetric sweep are dealt out over the ranks like its tiles
+  *bytes = (sym ? (e->op[which].kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0)
                 : 8.0 * (double)e->nloc * (double)e->n) + 16.0 * (double)e->n * k;
-  *flops = 2.0 * (double)(sym ? e->n : e->nloc) * (double)e->n * k;
+  *flops = 2.0 * (sym ? (double)e->n / e->nranks : (double)e->nloc) * (double)e->n * k;
   e->st = saved;
   return 0;
 }
