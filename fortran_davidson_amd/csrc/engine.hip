@@ -151,6 +151,13 @@ struct dav_engine {
   int64_t sym_ntiles_local = 0;
   double* sym_wpart = nullptr;    // several ranks: this rank's partial of the whole product, [rank][column][row of its slab]
   double* sym_wrecv = nullptr;    // ... and the summed chunk the reduce-scatter hands back (nslab x 32)
+  // RCCL only: a second stream for the collectives of the symmetric sweep, so that the all-gather of the NEXT 32 columns
+  // and the reduce-scatter of the PREVIOUS ones run under the sweep of the current ones; buffers alternate by chunk parity
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ov_packed[2] = {nullptr, nullptr}, ov_gathered[2] = {nullptr, nullptr}, ov_reduced[2] = {nullptr, nullptr},
+             ov_scattered[2] = {nullptr, nullptr};
+  double* sym_wpart2[2] = {nullptr, nullptr};
+  double* sym_wrecv2[2] = {nullptr, nullptr};
   // super-row schedules (k_matvec_sym9.hip): plan p = 0 / 1 for R = 2 / 4 block rows per workgroup
   struct SymPlan {
     int R = 0, nitems = 0, nsuper = 0;
@@ -409,6 +416,15 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->sym_slab);
   hipFree(e->rr_H); hipFree(e->rr_S); hipFree(e->rr_Y); hipFree(e->rr_theta); hipFree(e->rr_work); hipFree(e->rr_info);
   hipFree(e->rr_Ypk); hipFree(e->rr_Y2pk); hipFree(e->rr_thpk);
+  for (int i = 0; i < 2; ++i) {
+    if (e->ov_packed[i]) hipEventDestroy(e->ov_packed[i]);
+    if (e->ov_gathered[i]) hipEventDestroy(e->ov_gathered[i]);
+    if (e->ov_reduced[i]) hipEventDestroy(e->ov_reduced[i]);
+    if (e->ov_scattered[i]) hipEventDestroy(e->ov_scattered[i]);
+    hipFree(e->sym_wpart2[i]);
+    hipFree(e->sym_wrecv2[i]);
+  }
+  if (e->comm_stream) hipStreamDestroy(e->comm_stream);
   hipFree(e->sym_row_off);
   hipFree(e->sym_wpart);
   hipFree(e->sym_wrecv);
@@ -1241,6 +1257,95 @@ static bool inner_f32_tiles(E* e, OpDesc& o) {
   return true;
 }
 
+// Symmetric sweep of k > 32 columns over several ranks with RCCL, chunks of 32 columns software-pipelined over two streams:
+//   comm stream:  gather(0)            gather(1)   scatter(0)   gather(2)   scatter(1) ...
+//   main stream:  pack(0) pack(1) | wait gather(0) sweep(0) reduce(0) | pack(2) wait gather(1) sweep(1) reduce(1) | to_panel(0) ...
+// i.e. the all-gather of chunk i + 1 and the reduce-scatter of chunk i - 1 run under the sweep of chunk i.  Xt column groups,
+// the partial-product buffer and the receive buffer alternate with the chunk parity.  Same kernels, same sums, same result as
+// the serial path (which the test transports and single-chunk applies keep using).
+static int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner) {
+  const int step = 32;
+  const int nchunks = (k + step - 1) / step;
+  if (!e->comm_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(hipEventCreateWithFlags(&e->ov_packed[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ov_gathered[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ov_reduced[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ov_scattered[i], hipEventDisableTiming));
+      HIPCHK(hipMalloc(&e->sym_wpart2[i], sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
+      HIPCHK(hipMalloc(&e->sym_wrecv2[i], sizeof(double) * (size_t)e->nslab * 32));
+    }
+  }
+  const int64_t total_rows = (int64_t)e->nranks * e->nslab;
+  const bool use32 = inner && inner_f32_tiles(e, o);
+  const int R = 2;                                     // 32-column chunks: the paired two-block-row schedule
+  const E::SymPlan* pl = &e->sym_plan[0];
+  const int64_t dstride = (int64_t)pl->nitems * R * 16 * SYM_TB, tstride = pl->zslots * 16 * SYM_TB;
+  CHK(sym_ensure_slabs(e, (size_t)2 * (size_t)(dstride + tstride) + 1));
+  int slot = -1;
+  const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
+  if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, stored * nchunks + 16.0 * (double)e->n * k, &slot));
+  auto cols = [&](int i) { return std::min(step, k - i * step); };
+  auto xt_of = [&](int i) { return e->xt + (size_t)(i & 1) * 2 * e->xt_group_stride; };
+  auto pack_and_gather = [&](int i) -> int {
+    const int p = i & 1, kk = cols(i), ng = (kk + 15) / 16;
+    launch_pack_xt(e->stream, src + (int64_t)i * step * e->ldp, e->ldp, e->nloc, e->nslab, kk, xt_of(i), e->xt_group_stride, e->row0);
+    HIPCHK(hipEventRecord(e->ov_packed[p], e->stream));
+    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_packed[p], 0));
+    NCCLCHK(g_rccl.GroupStart());
+    for (int g = 0; g < ng; ++g) {
+      double* base = xt_of(i) + (size_t)g * e->xt_group_stride;
+      NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, e->comm_stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipEventRecord(e->ov_gathered[p], e->comm_stream));
+    return 0;
+  };
+  auto to_panel = [&](int i) -> int {
+    const int p = i & 1, kk = cols(i), ng = (kk + 15) / 16;
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ov_scattered[p], 0));
+    for (int g = 0; g < ng; ++g)
+      launch_chunk_to_panel(e->stream, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad,
+                            std::min(16, kk - 16 * g), dst + (int64_t)(i * step + 16 * g) * e->ldp, e->ldp);
+    return 0;
+  };
+  CHK(pack_and_gather(0));
+  for (int i = 0; i < nchunks; ++i) {
+    const int p = i & 1, kk = cols(i), npair = (kk + 15) / 16;
+    if (i + 1 < nchunks) CHK(pack_and_gather(i + 1));         // Xt groups of the other parity: last read by the sweep of chunk i - 1
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ov_gathered[p], 0));
+    int kslot = -1;
+    if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
+    double* slabT = e->sym_slab + (int64_t)npair * dstride;
+    if (pl->nitems > 0)
+      launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
+                         o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin,
+                         xt_of(i), kk, e->sym_slab, slabT, npair, e->xt_group_stride, dstride, tstride);
+    CHK(timed_end(e, kslot));
+    // partial of the whole product of this chunk (the buffer of this parity was last read by the reduce-scatter of chunk
+    // i - 2, whose completion the main stream waited for when it finished chunk i - 2 below)
+    for (int g = 0; g < npair; ++g)
+      launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, e->sym_row_off, R,
+                         e->sym_nb, e->nloc, std::min(16, kk - 16 * g), e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->ldp,
+                         e->nslab, total_rows);
+    HIPCHK(hipEventRecord(e->ov_reduced[p], e->stream));
+    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_reduced[p], 0));
+    NCCLCHK(g_rccl.GroupStart());
+    for (int g = 0; g < npair; ++g)
+      NCCLCHK(g_rccl.ReduceScatter(e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16,
+                                   (size_t)e->nslab * std::min(16, kk - 16 * g), ncclDouble, ncclSum, e->comm, e->comm_stream));
+    NCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipEventRecord(e->ov_scattered[p], e->comm_stream));
+    if (i >= 1) CHK(to_panel(i - 1));                      // the previous chunk's rows of W, while this chunk's reduce-scatter runs
+    if (which == DAV_OP_A) { e->st.applies += 1; e->st.apply_cols += kk; }
+  }
+  CHK(to_panel(nchunks - 1));
+  CHK(timed_end(e, slot));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // inner = true: a sweep inside the GJD correction solve (may run on the fp32 copy, dav_set_inner_precision)
 static int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner = false) {
   OpDesc& o = e->op[which];
@@ -1268,6 +1373,11 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     }
     const int64_t* owned = multi ? e->sym_row_off : nullptr;
     const int64_t total_rows = (int64_t)e->nranks * e->nslab;
+    {
+      static const int overlap_env = [] { const char* ev = getenv("DAV_SYM_OVERLAP"); return ev ? atoi(ev) : 1; }();
+      if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 16) == 2)
+        return apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
+    }
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;

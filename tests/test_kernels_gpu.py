@@ -456,3 +456,31 @@ def test_ranks_that_disagree_on_a_control_decision_stop_with_a_message():
 
     out = _run_ranks(nranks, lambda r: fd.CEngine(n=500, max_cols=16, rank=r, nranks=nranks), work)
     assert all("ranks disagree" in o for o in out), out
+
+
+@pytest.mark.parametrize("n,k", [(1300, 40), (2500, 64), (2305, 33), (700, 48)])
+def test_symmetric_sweep_with_collectives_overlapped_on_a_second_stream(n, k, monkeypatch):
+    """RCCL path of the multi-rank symmetric sweep for blocks wider than 32 columns: the all-gather of the next 32 columns
+    and the reduce-scatter of the previous ones run on a second stream under the sweep of the current ones (Xt column
+    groups and partial-product buffers alternate).  Runs here through a 1-rank RCCL communicator (DAVIDSON_FORCE_RCCL=1)
+    with the two-block-row schedule forced (small orders would pick the one-block-row kernel)."""
+    monkeypatch.setenv("DAVIDSON_FORCE_RCCL", "1")
+    monkeypatch.setenv("DAV_SYM_R", "2")
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((n, n)); A = A + A.T
+    X = rng.standard_normal((n, k))
+    with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
+        e.comm_init(fd.CEngine.comm_unique_id())
+        e.set_storage(1)
+        e.set_dense_host(OP_A, A)
+        e.set_timing(2)
+        e.reset_stats()
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+        W = e.panel_get(PANEL_W, 0, k)
+        assert relerr(W, A @ X) < RTOL * n
+        e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
+        assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
+        st = e.stats()
+        assert st.applies == 2 * ((k + 31) // 32) and st.apply_cols == 2 * k
+        assert st.comm_ms == 0.0          # the serial path times its collectives on the main stream; this one has none there
