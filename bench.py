@@ -112,7 +112,7 @@ def cpu_baseline(path, lowest, tol):
 
 
 def pmc_traffic(n, storage, kernel, rank_by_grid):
-    """HBM bytes per launch of a roofline kernel from the rocprofv3 PMC summary under profiles/ - an OFFLINE figure
+    """(HBM bytes per launch, provenance) of a roofline kernel from the rocprofv3 PMC summary under profiles/ - an OFFLINE figure
     (counters cannot be read from inside the run): collected with `rocprofv3 --pmc` on this command at the commit the
     file names (profiles/summarize.py).  `kernel` = name prefix; launches of one kernel are grouped by grid size
     (column groups per launch) - rank_by_grid 0 = largest grid.  None when no summary matches the workload."""
@@ -122,11 +122,12 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
             doc = json.load(f)
         rows = sorted((k for k in doc["kernels"] if k["kernel"].startswith(kernel)), key=lambda k: -k["grid_size"])
         row = rows[rank_by_grid]
-        return {"bytes_per_launch": row["hbm_bytes_per_launch_corrected"], "kernel": row["kernel"], "grid_size": row["grid_size"],
-                "source": os.path.relpath(path, ROOT), "collected_at_commit": doc.get("commit"),
-                "note": "offline rocprofv3 --pmc pass (2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), not measured in this run"}
+        return row["hbm_bytes_per_launch_corrected"], {
+            "kernel": row["kernel"], "grid_size": row["grid_size"], "source": os.path.relpath(path, ROOT),
+            "collected_at_commit": doc.get("commit"),
+            "note": "offline rocprofv3 --pmc pass (2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), not measured in this run"}
     except Exception:      # noqa: BLE001
-        return None
+        return None, None
 
 
 def main():
@@ -252,12 +253,14 @@ def main():
     kernel_name = "matvec_sym9_kernel<R, false> (K1s: symmetric-tiled sweep, R block rows per workgroup: 2 in the solve, 4 at k <= 8)" if storage == "symmetric" else "matvec_dense_kernel<NT> (K1: row slab)"
     hbm_in_solve = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
     mfma_bound = cols_per_launch > 16
+    tr_solve = pmc_traffic(n, storage, "matvec_sym9_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", 0) if world == 1 else (None, None)
+    tr_k8 = pmc_traffic(n, storage, "matvec_sym9_kernel<4", 0) if (world == 1 and storage == "symmetric") else (None, None)
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kernel_name,
                 "achieved": round(tflops, 2) if mfma_bound else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9, 1),
                 "peak": FP64_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBPS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound
                         else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "traffic": pmc_traffic(n, storage, "matvec_sym9_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", 0) if world == 1 else None,
+                "traffic": tr_solve[0], "traffic_source": tr_solve[1],
                 "launches": launches, "avg_launch_ms": round(kms, 4), "columns_per_launch": round(cols_per_launch, 1),
                 "flops_per_launch": round(st.apply_flops / launches, 0),
                 "algorithmic_bytes_per_launch": round(st.apply_bytes / max(st.applies, 1) , 0),
@@ -276,7 +279,7 @@ def main():
                     "achieved_kernel_only": a8["GBps_kernel_only"], "frac_kernel_only": a8["frac_of_8TBps_kernel_only"],
                     "ms_end_to_end": a8["ms_end_to_end"], "ms_kernel_only": a8["ms_kernel_only"],
                     "algorithmic_bytes_per_launch": a8["algorithmic_bytes"],
-                    "traffic": pmc_traffic(n, storage, "matvec_sym9_kernel<4", 0) if (world == 1 and storage == "symmetric") else None,
+                    "traffic": tr_k8[0], "traffic_source": tr_k8[1],
                     "note": "per rank: bytes = 8*S + 16*N*k, S = N(N+1)/2 / n_gpus (symmetric-tiled) or nloc*N (row slab); end to end = "
                             "pack_xt (+ all-gather) + sweep kernel + fixed-order reduction of the partial sums (+ reduce-scatter); HIP events on the engine's stream"}
 
