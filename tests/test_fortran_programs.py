@@ -45,6 +45,12 @@ def build_ranks_program(tmp_path):
     return compile_link([os.path.join(SRC, "prog_ranks.f90")], os.path.join(bindir, "prog_ranks"), tmp_path)
 
 
+def build_options_program(tmp_path):
+    bindir = os.path.join(SRC, "_bin")
+    os.makedirs(bindir, exist_ok=True)
+    return compile_link([os.path.join(SRC, "prog_options.f90")], os.path.join(bindir, "prog_options"), tmp_path)
+
+
 def build_ingest_program(tmp_path):
     bindir = os.path.join(SRC, "_bin")
     os.makedirs(bindir, exist_ok=True)
@@ -59,6 +65,7 @@ def test_user_programs_compile_and_link(tmp_path):
     assert os.path.exists(dense) and os.path.exists(free)
     assert os.path.exists(build_ingest_program(tmp_path))
     assert os.path.exists(build_ranks_program(tmp_path))
+    assert os.path.exists(build_options_program(tmp_path))
 
 
 @needs_flang
@@ -149,3 +156,15 @@ def test_multi_rank_fortran_program(tmp_path, nranks):
         assert len(checks) == (6 if r == 0 else 4) and all(v == "T" for _, v in checks), out
         evals.append([float(x) for x in re.search(r"EVALS(.*)", out).group(1).split()])
     assert all(e == evals[0] for e in evals)            # same bits on every rank
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_options_program_runs_on_gpu(tmp_path):
+    """engine_set_storage / engine_set_inner_precision / engine_set_device_rr from a Fortran program, against the
+    drop-in calls on the same matrices."""
+    exe = build_options_program(tmp_path)
+    rc, out = _run(exe)
+    assert rc == 0, out
+    checks = re.findall(r"CHECK (\S+) ([TF])", out)
+    assert len(checks) == 14 and all(v == "T" for _, v in checks), out
