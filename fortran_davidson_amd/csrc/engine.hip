@@ -142,6 +142,7 @@ struct dav_engine {
   double* sym_slab = nullptr;     // device: direct slabs (per item) followed by transposed slabs (per tile)
   size_t sym_slab_doubles = 0;    // grown on demand: what the largest launch so far needed (schedule x column groups)
   bool sym_no_pair = false;       // paired 32-column launches did not fit the memory: 16 columns per launch
+  bool sym_no_quad = false;       // ... four column groups (64 columns) per launch did not
   int inner_bits = 64;            // 32: the sweeps INSIDE the GJD correction read an fp32 copy of the stored tiles (dav_set_inner_precision)
   // Several ranks: the lower block triangle is dealt out by groups of 4 block rows (what every schedule's super rows
   // nest in), longest group first to the least loaded rank (sym_group_owners).  row_off[I] = first tile of block row I
@@ -1364,6 +1365,11 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
     // pairing shares the READS of stored tiles: nothing to share when the entries are generated
     int step = (pair_env && matvec_sym_can_pair() && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
+    // 64 columns (the widest expansion of the doubling policy below a basis of 128) as FOUR column groups in one launch on
+    // the super-row kernels: the four workgroups of a work item share every tile read through their XCD's L2.  Same box,
+    // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  DAV_SYM_QUAD=0: off.
+    static const int quad_env = [] { const char* ev = getenv("DAV_SYM_QUAD"); return ev ? atoi(ev) : 1; }();
+    if (quad_env && step == 32 && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 16) == 2 && !has_comm(e)) step = 64;
     // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
     // reduce-scatter of this path through RCCL on a one-GPU box)
     const bool multi = e->nranks > 1 || has_comm(e);
@@ -1387,11 +1393,11 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
       const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)e->sym_nitems * 16 * SYM_TB;
       const int64_t tstride = R > 1 ? pl->zslots * 16 * SYM_TB : (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
-      if (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride) + 1) != 0) {
+      while (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride) + 1) != 0) {
+        // not enough memory for this many column groups per launch: fewer from here on (4 -> 2 -> 1)
         if (npair < 2) return 1;
-        e->sym_no_pair = true;               // not enough memory for two column groups per launch: one at a time from here on
-        step = 16; kk = 16; npair = 1;
-        CHK(sym_ensure_slabs(e, (size_t)(dstride + tstride) + 1));
+        if (npair > 2) { e->sym_no_quad = true; step = 32; kk = 32; npair = 2; }
+        else { e->sym_no_pair = true; step = 16; kk = 16; npair = 1; }
       }
       int slot = -1, kslot = -1, cslot = -1;
       const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;

@@ -76,16 +76,18 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
   __shared__ __attribute__((aligned(16))) double zst[2][16 * ZS];   // [strip parity][block column][tile column]
   static_assert(TRW >= 16 * RS, "the end-of-run exchange reuses the transposition scratch");
 
-  // two 16-column groups in one launch: see matvec_sym8_kernel (the members of a pair share an XCD and its L2)
+  // npair (2 or 4) 16-column groups in one launch: the workgroups of one work item are 8 apart in the grid - consecutive
+  // workgroups go to consecutive XCDs, so they share an XCD and its L2 - and stream the same tiles at the same pace
   int item, grp;
-  if (npair == 2) {
-    const int nfull = (int)(gridDim.x / 16) * 16;
+  if (npair > 1) {
+    const int span = 8 * npair;
+    const int nfull = (int)(gridDim.x / span) * span;
     if ((int)blockIdx.x < nfull) {
-      item = (blockIdx.x / 16) * 8 + (blockIdx.x % 8);
-      grp = (blockIdx.x / 8) % 2;
+      item = (blockIdx.x / span) * 8 + (blockIdx.x % 8);
+      grp = (blockIdx.x / 8) % npair;
     } else {
-      item = nfull / 2 + (blockIdx.x - nfull) / 2;
-      grp = (blockIdx.x - nfull) % 2;
+      item = nfull / npair + (blockIdx.x - nfull) / npair;
+      grp = (blockIdx.x - nfull) % npair;
     }
   } else {
     item = blockIdx.x;

@@ -276,7 +276,8 @@ def test_dense_matrix_from_device_memory(storage):
 
 @pytest.mark.parametrize("env", [{"DAV_SYM_V8": "0"}, {"DAV_SYM_PAIR": "0"}, {"DAV_SYM_RUN": "1"}, {"DAV_SYM_RUN": "7"},
                                  {"DAV_SYM_R": "2"}, {"DAV_SYM_R": "4"}, {"DAV_SYM_R": "4", "DAV_SYM_RUN9": "1"},
-                                 {"DAV_SYM_R": "2", "DAV_SYM_RUN9": "3"}, {"DAV_SYM_R": "2", "DAV_SYM_PAIR": "0"}])
+                                 {"DAV_SYM_R": "2", "DAV_SYM_RUN9": "3"}, {"DAV_SYM_R": "2", "DAV_SYM_PAIR": "0"},
+                                 {"DAV_SYM_R": "2", "DAV_SYM_QUAD": "0"}, {"DAV_SYM_R": "4", "DAV_SYM_MFMA4": "0"}])
 def test_symmetric_sweep_alternative_kernels_and_schedules(env):
     """The A/B knobs of the symmetric sweep (one-wave-per-SIMD kernel, unpaired 16-column launches, other run
     lengths, the super-row schedules with 2 / 4 block rows per workgroup that large matrices select by
@@ -350,20 +351,20 @@ def test_hashed_operator_symmetric_generation_equals_the_dense_generator(n, k):
         assert np.abs(e.panel_get(PANEL_W, 0, k) - A @ X).max() <= 1e-12 * np.abs(A @ X).max()
 
 
-@pytest.mark.parametrize("k", [8, 16, 40])
+@pytest.mark.parametrize("k", [8, 16, 40, 64])
 def test_symmetric_super_row_schedules_at_a_size_that_selects_them(k):
     """From 200 block rows on the sweep runs the super-row schedules (4 block rows per workgroup for k <= 8, else 2)
     by itself: N=51700 (202 block rows, a ragged last super row), the same generated matrix in full storage
     as the reference, stored tiles and the hashed operator generated in the sweep."""
     n = 51700
     X = np.random.default_rng(k).standard_normal((n, k))
-    with fd.CEngine(n=n, max_cols=48) as e:
+    with fd.CEngine(n=n, max_cols=64) as e:
         e.set_dense_generated(OP_A, 5, 1e-3)
         e.panel_put(PANEL_V, 0, X)
         e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
         ref = e.panel_get(PANEL_W, 0, k)
     for generated in (False, True):
-        with fd.CEngine(n=n, max_cols=48) as e:
+        with fd.CEngine(n=n, max_cols=64) as e:
             e.set_storage(1)
             if generated:
                 e.set_operator_hashed(OP_A, 5, 1e-3)
