@@ -23,6 +23,8 @@
 // at k = 8 and no change at k = 16 / 32 - the barrier is not what the waves wait for; the LDS transposition of half-step
 // hs + 1 issued before the MFMAs of half-step hs (software pipeline, second set of Gram registers, 256 VGPRs) 54.0
 // against 50.7 ms at k = 32 and 32.5 against 30.1 ms at k = 16 - it costs a half-step of global-load lookahead.
+// 32 columns as four groups of EIGHT on the R = 4 / 4x4x4 path (tile reads shared by four workgroups) 70.6 against 53.0 ms: every
+// group repeats the LDS transposition of the tile, and that, not the MFMA count, is what the extra groups multiply.
 //
 // Tiles that do not exist for a wave (above the diagonal inside the R x R diagonal super block, or block rows past
 // the end of the matrix) are replaced by a stored tile of the same super row and masked: the B operand of the direct
