@@ -416,6 +416,16 @@ def main():
                                       "note": "one-workgroup Jacobi eigensolver on the device instead of host DSYEV/DSYEVD; not the default"}
                 small["apply"] = apply_rooflines(s, (8, 16, 32), 20)
                 s.close()
+                # the same problem with only the lower block triangle resident (engine_set_storage(eng, "symmetric")): half the bytes per sweep
+                y = make_engine(sn, 8, None, "symmetric")
+                y.generate_diagonal_dominant(1, args.sparsity, seed=1)
+                for _ in range(5):
+                    y.solve("DPR", 1000, args.tol, want_vectors=False)
+                dt_y, it_y, lam_y = timed_solves(y, "DPR", 50, args.tol)
+                small["symmetric_storage"] = {"ms_per_solve": round(dt_y / 50 * 1e3, 4), "iterations_per_s": round(it_y / dt_y, 2),
+                                              "iters_per_solve": it_y // 50,
+                                              "max_abs_eigenvalue_diff_vs_full_storage": float(np.abs(lam_y - lam_s).max())}
+                y.close()
                 extras["small"] = small
             except Exception as exc:       # noqa: BLE001
                 extras["small"] = {"error": repr(exc)[:300]}
