@@ -447,3 +447,65 @@ def test_row_slabs_smaller_than_a_tile_and_empty_slabs(n, L, nranks, method, gev
         assert np.abs(np.abs(vec) - np.abs(vec1)).max() < 1e-10
     for e in engs:
         e.close()
+
+
+def _solve_on_ranks(nranks, make, prepare, method, max_it, tol):
+    """nranks DavidsonEngines as threads on one GPU (loopback transport); returns the (lam, vec, iters) of every rank"""
+    import ctypes as C
+    import threading
+    engs = [make(r) for r in range(nranks)]
+    handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+    assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            prepare(engs[r])
+            out[r] = engs[r].solve(method, max_it, tol)
+        except Exception as exc:      # noqa: BLE001
+            err[r] = exc
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in threads]
+    [t.join(timeout=300) for t in threads]
+    for e in engs:
+        e.close()
+    assert all(x is None for x in err), err
+    assert all(o is not None for o in out)
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_harness_operator_generated_in_the_symmetric_sweep_over_ranks(golden, nranks):
+    """the reference's test operator (transcendental entries) as a device operator, symmetric generation dealt out over
+    ranks: the golden values of the reference's matrix-free run"""
+    manifest, arrays = golden
+    case = manifest["free"]["free_n300"]
+
+    def prepare(eng):
+        eng.set_harness_operator(1)
+        eng.set_harness_operator(2)
+    out = _solve_on_ranks(nranks, lambda r: fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=True, rank=r, nranks=nranks,
+                                                              storage="symmetric"), prepare, "DPR", case["max_it"], case["tol"])
+    for lam, vec, iters in out:
+        assert np.abs(lam - arrays["free_n300__evals"]).max() < 1e-8
+        assert iters == case["iters"]
+        assert np.array_equal(lam, out[0][0])
+
+
+def test_fp32_inner_sweeps_over_ranks(golden):
+    """mixed-precision GJD with the symmetric tiles (and their fp32 copies) dealt out over 2 ranks"""
+    manifest, arrays = golden
+    name = "n400_gev_gjd"
+    case = manifest["dense"][name]
+    A, B = case_matrices(case, arrays)
+
+    def prepare(eng):
+        eng.set_dense(1, A)
+        eng.set_dense(2, B)
+        eng.set_inner_precision(32)
+    out = _solve_on_ranks(2, lambda r: fd.DavidsonEngine(case["n"], case["lowest"], case["max_dim"], gev=True, rank=r, nranks=2,
+                                                         storage="symmetric"), prepare, "GJD", case["max_it"], case["tol"])
+    for lam, vec, iters in out:
+        assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
+        assert iters == case["iters"]
+        assert (residuals(A, B, lam, vec) < case["tol"]).all()
