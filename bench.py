@@ -445,6 +445,18 @@ def main():
                                                 "over PCIe, solved, eigenvectors downloaded, everything released",
                                         "N": cn, "seconds": round(dt_d, 4), "iters": it_d, "iterations_per_s": round(it_d / dt_d, 2),
                                         "upload_GB": round(8.0 * cn * cn / 1e9, 3)}
+                    # the same call keeping only the lower block triangle (DAVIDSON_STORAGE=symmetric): half the PCIe bytes
+                    os.environ["DAVIDSON_STORAGE"] = "symmetric"
+                    try:
+                        fd.generalized_eigensolver(A_host, 8, "DPR", 1000, args.tol)
+                        t0 = time.perf_counter()
+                        lam_y, _, it_y = fd.generalized_eigensolver(A_host, 8, "DPR", 1000, args.tol)
+                        dt_y = time.perf_counter() - t0
+                        extras["dropin"]["symmetric_storage"] = {"seconds": round(dt_y, 4), "iters": it_y, "iterations_per_s": round(it_y / dt_y, 2),
+                                                                "upload_GB": round(4.0 * cn * cn / 1e9, 3),
+                                                                "max_abs_eigenvalue_diff": float(np.abs(lam_y - lam_d).max())}
+                    finally:
+                        del os.environ["DAVIDSON_STORAGE"]
                 except Exception as exc:       # noqa: BLE001
                     extras["dropin"] = {"error": repr(exc)[:300]}
             if not args.no_cpu_baseline:

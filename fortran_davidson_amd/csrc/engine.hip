@@ -977,19 +977,40 @@ static int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemc
   o.kind = DAV_KIND_DENSE;
   if (o.storage == 1) {
     // lower block triangle, tile by tile (edge tiles zero padded)
-    int nb = e->sym_nb;
-    HIPCHK(hipMemsetAsync(o.a, 0, sizeof(double) * (size_t)e->sym_ntiles_local * SYM_TB * SYM_TB, e->stream));
-    for (int I = 0; I < nb; ++I) {
-      if (e->sym_row_off_h[I] < 0) continue;             // block row of another rank
-      for (int J = 0; J <= I; ++J) {
-        int64_t r0 = (int64_t)I * SYM_TB, c0 = (int64_t)J * SYM_TB;
-        int64_t nr = std::min<int64_t>(SYM_TB, e->n - r0), nc = std::min<int64_t>(SYM_TB, e->n - c0);
-        if (nr <= 0 || nc <= 0) continue;
-        double* tile = o.a + (e->sym_row_off_h[I] + J) * (int64_t)(SYM_TB * SYM_TB);
-        HIPCHK(hipMemcpy2DAsync(tile, sizeof(double) * SYM_TB, a + r0 + c0 * lda, sizeof(double) * lda, sizeof(double) * nr,
-                                (size_t)nc, kind, e->stream));
+    // block column by block column: one long-row 2-D copy of the rows from the diagonal block down into a staging panel
+    // (two panels alternate, so the copy of column J + 1 is queued behind the cut of column J), then cut into tiles
+    const int nb = e->sym_nb;
+    const int64_t ldp_stage = (int64_t)nb * SYM_TB;
+    double* stage[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; ++b) {
+      hipError_t r = hipMalloc(&stage[b], sizeof(double) * (size_t)ldp_stage * SYM_TB);
+      if (r != hipSuccess) {
+        (void)hipGetLastError();
+        if (stage[0]) hipFree(stage[0]);
+        return fail("hipMalloc of the upload staging panel failed: " + std::string(hipGetErrorString(r)));
       }
     }
+    int rc = 0;
+    for (int J = 0; J < nb && rc == 0; ++J) {
+      const int64_t r0 = (int64_t)J * SYM_TB, nr = e->n - r0;
+      const int nc = (int)std::min<int64_t>(SYM_TB, e->n - r0);
+      if (nr <= 0) {                                    // block rows / columns wholly in the padding: zero tiles
+        launch_retile_panel(e->stream, stage[J & 1], ldp_stage, 0, 0, J, nb, e->sym_row_off, o.a);
+        continue;
+      }
+      if (hipMemcpy2DAsync(stage[J & 1], sizeof(double) * ldp_stage, a + r0 + r0 * lda, sizeof(double) * lda, sizeof(double) * nr,
+                           (size_t)nc, kind, e->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        rc = fail("dav_set_dense: copy of a block column failed");
+        break;
+      }
+      launch_retile_panel(e->stream, stage[J & 1], ldp_stage, nr, nc, J, nb, e->sym_row_off, o.a);
+    }
+    hipStreamSynchronize(e->stream);
+    hipFree(stage[0]);
+    hipFree(stage[1]);
+    if (rc != 0) return rc;
+    HIPCHK(hipGetLastError());
     CHK(sym_diag(e, o));
     CHK(refresh_diag_host(e, which));
     return 0;

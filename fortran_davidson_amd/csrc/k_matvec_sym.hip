@@ -571,3 +571,20 @@ void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_
   hipLaunchKernelGGL(gather_columns_sym_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, tiles, row_off, n,
                      nrows_pad, idx_dev, dst, ldd);
 }
+
+// Upload path of a host matrix into symmetric tiles: block column J arrives as ONE panel (rows J*256 .. n of its <= 256
+// columns, column-major with leading dimension ldp - a 2-D copy with long rows, which is what PCIe moves at full rate; a
+// tile-by-tile copy has 2 KB rows and runs at a third of it) and is cut into the tiles (I >= J, J) this rank stores.
+__global__ __launch_bounds__(256) void retile_panel_kernel(const double* __restrict__ panel, int64_t ldp, int64_t nrows, int ncols, int J,
+                                                           const int64_t* __restrict__ row_off, double* __restrict__ tiles) {
+  const int I = J + blockIdx.x;
+  if (row_off[I] < 0) return;                                  // block row of another rank
+  double* tile = tiles + (row_off[I] + J) * (int64_t)(SYM_TB * SYM_TB);
+  const int64_t r = (int64_t)blockIdx.x * SYM_TB + threadIdx.x;  // row inside the panel
+  for (int c = blockIdx.y * 16; c < blockIdx.y * 16 + 16; ++c)
+    tile[(int64_t)c * SYM_TB + threadIdx.x] = (r < nrows && c < ncols) ? panel[r + (int64_t)c * ldp] : 0.0;
+}
+void launch_retile_panel(hipStream_t st, const double* panel, int64_t ldp, int64_t nrows, int ncols, int J, int nb,
+                         const int64_t* row_off, double* tiles) {
+  hipLaunchKernelGGL(retile_panel_kernel, dim3((unsigned)(nb - J), SYM_TB / 16), dim3(SYM_TB), 0, st, panel, ldp, nrows, ncols, J, row_off, tiles);
+}

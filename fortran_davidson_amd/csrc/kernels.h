@@ -112,6 +112,8 @@ void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT
                         int64_t chunk_rows, int64_t total_rows);
 void launch_generate_sym_tiles(hipStream_t st, double* tiles, const int64_t* row_off_host, int nb, int64_t n, uint64_t seed,
                                double sparsity, int use_diag, double diag_val);
+void launch_retile_panel(hipStream_t st, const double* panel, int64_t ldp, int64_t nrows, int ncols, int J, int nb,
+                         const int64_t* row_off, double* tiles);
 void launch_diag_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows, double* diag);
 void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows_pad,
                                const int64_t* idx_dev, int k, double* dst, int64_t ldd);

@@ -20,7 +20,7 @@ module davidson_device
   use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_cholesky_inverse, lapack_matmul
   implicit none
   private
-  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, engine_set_device_rr, engine_set_inner_precision, &
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, env_storage_symmetric, engine_set_device_rr, engine_set_inner_precision, &
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
@@ -72,6 +72,16 @@ contains
     if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) dev
     if (stat /= 0) dev = 0
   end function env_device
+
+  !> DAVIDSON_STORAGE=symmetric selects symmetric-tiled storage for the dense front end (engines: engine_set_storage)
+  function env_storage_symmetric() result(sym)
+    logical :: sym
+    integer :: stat, length
+    character(len=16) :: buf
+    call get_environment_variable("DAVIDSON_STORAGE", buf, length, stat)
+    sym = (stat == 0 .and. length >= 3)
+    if (sym) sym = buf(1:3) == "sym"
+  end function env_storage_symmetric
 
   !> Widest basis the reference's policy can reach: m starts at 2*lowest and doubles while
   !> m <= max_dim (src/davidson.f90:195-213), so it may overshoot max_dim once.
@@ -892,6 +902,9 @@ contains
     max_dim = 10 * lowest
     if (present(max_dim_sub)) max_dim = max_dim_sub
     call engine_create(eng, size(matrix, 1), lowest, max_dim, present(second_matrix), env_device())
+    ! DAVIDSON_STORAGE=symmetric: upload and keep only the lower block triangle of the (symmetric, as the reference
+    ! assumes) input - half the PCIe bytes, half the HBM; default: the full matrix, as the reference's DGEMM reads it
+    if (env_storage_symmetric()) call engine_set_storage(eng, "symmetric")
     call engine_set_dense(eng, 1, matrix)
     if (present(second_matrix)) call engine_set_dense(eng, 2, second_matrix)
     call generalized_eigensolver_device(eng, eigenvalues, eigenvectors, lowest, method, max_iterations, &

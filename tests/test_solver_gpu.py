@@ -509,3 +509,17 @@ def test_fp32_inner_sweeps_over_ranks(golden):
         assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
         assert iters == case["iters"]
         assert (residuals(A, B, lam, vec) < case["tol"]).all()
+
+
+@pytest.mark.parametrize("name", ["matrix_txt_dpr", "c1_n50_gev_dpr", "n400_std_dpr", "n1000_gev_restart_dpr", "n400_gev_gjd"])
+def test_drop_in_call_with_symmetric_storage_from_the_environment(golden, name, monkeypatch):
+    """DAVIDSON_STORAGE=symmetric: the reference-signature dense call uploads and keeps only the lower block triangle of
+    its (symmetric) input - block-column panels over PCIe, cut into tiles on the device; golden values unchanged"""
+    monkeypatch.setenv("DAVIDSON_STORAGE", "symmetric")
+    manifest, arrays = golden
+    case = manifest["dense"][name]
+    A, B = case_matrices(case, arrays)
+    lam, vec, iters = fd.generalized_eigensolver(A, case["lowest"], case["method"], case["max_it"], case["tol"], case["max_dim"], B)
+    assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
+    assert (residuals(A, B, lam, vec) < case["tol"]).all()
+    assert iters == case["iters"]
