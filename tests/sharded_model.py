@@ -49,7 +49,7 @@ def orthonormalise(V, T):
 
 class SymmetricTiles:
     """The symmetric-tiled storage dealt out over the ranks: this rank keeps the tiles (I, J <= I) of the block rows
-    it owns (groups of 4, boustrophedon).  apply(): the exchange steps of the engine's multi-rank symmetric sweep -
+    it owns (groups of 4, longest first to the least loaded rank).  apply(): the exchange steps of the engine's multi-rank symmetric sweep -
     all-gather of the block, this rank's partial of the WHOLE product from its tiles (direct and transposed product of
     every off-diagonal tile), reduce-scatter of the partials (gloo has no reduce-scatter: all-reduce + own chunk is
     the same sum), rows of this rank's slab."""
