@@ -104,6 +104,14 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
 
   // ---- cyclic Jacobi ------------------------------------------------------------------------------------------------
   const int M = (m + 1) & ~1, half = M / 2;
+  // thread -> (pair slot, row or column) with power-of-two arithmetic: integer division by the run-time order and the
+  // modulo of the round-robin table cost more than the rotations themselves (a configs[1] solve with the device eigensolver: 3.54 -> 2.80 ms)
+  int lg = 0;
+  while ((1 << lg) < m) ++lg;
+  const int mp = 1 << lg;                      // rows / columns per pass, padded to a power of two
+  const int kstep = NT >> lg;                  // pairs handled per pass (NT >= mp: NT = 1024 or >= m*m/2 rounded to 64)
+  const int ti = tid & (mp - 1), tk = tid >> lg;
+  __shared__ int pair_p[64], pair_q[64];
   int sweeps = 0;
   for (; sweeps < 30; ++sweeps) {
     if (tid == 0) flag = 0;
@@ -127,34 +135,33 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
           }
         }
         rot_c[tid] = c; rot_s[tid] = sn;
+        pair_p[tid] = p; pair_q[tid] = q < m ? q : -1;
       }
       __syncthreads();
       // columns: A <- A J, V <- V J
-      for (int e = tid; e < half * m; e += NT) {
-        const int k = e / m, i = e % m;
-        int p, q;
-        tournament_pair(M, s, k, &p, &q);
-        const double c = rot_c[k], sn = rot_s[k];
-        if (q >= m || sn == 0.0) continue;
-        const double ap = As[i + p * la], aq = As[i + q * la];
-        As[i + p * la] = c * ap - sn * aq;
-        As[i + q * la] = sn * ap + c * aq;
-        const double vp = Vs[i + (size_t)p * lv], vq = Vs[i + (size_t)q * lv];
-        Vs[i + (size_t)p * lv] = c * vp - sn * vq;
-        Vs[i + (size_t)q * lv] = sn * vp + c * vq;
-      }
+      if (ti < m)
+        for (int k = tk; k < half; k += kstep) {
+          const int p = pair_p[k], q = pair_q[k];
+          const double c = rot_c[k], sn = rot_s[k];
+          if (q < 0 || sn == 0.0) continue;
+          const double ap = As[ti + p * la], aq = As[ti + q * la];
+          As[ti + p * la] = c * ap - sn * aq;
+          As[ti + q * la] = sn * ap + c * aq;
+          const double vp = Vs[ti + (size_t)p * lv], vq = Vs[ti + (size_t)q * lv];
+          Vs[ti + (size_t)p * lv] = c * vp - sn * vq;
+          Vs[ti + (size_t)q * lv] = sn * vp + c * vq;
+        }
       __syncthreads();
       // rows: A <- J^T A
-      for (int e = tid; e < half * m; e += NT) {
-        const int k = e / m, j = e % m;
-        int p, q;
-        tournament_pair(M, s, k, &p, &q);
-        const double c = rot_c[k], sn = rot_s[k];
-        if (q >= m || sn == 0.0) continue;
-        const double ap = As[p + j * la], aq = As[q + j * la];
-        As[p + j * la] = c * ap - sn * aq;
-        As[q + j * la] = sn * ap + c * aq;
-      }
+      if (ti < m)
+        for (int k = tk; k < half; k += kstep) {
+          const int p = pair_p[k], q = pair_q[k];
+          const double c = rot_c[k], sn = rot_s[k];
+          if (q < 0 || sn == 0.0) continue;
+          const double ap = As[p + ti * la], aq = As[q + ti * la];
+          As[p + ti * la] = c * ap - sn * aq;
+          As[q + ti * la] = sn * ap + c * aq;
+        }
       __syncthreads();
     }
     if (flag == 0) break;                            // a whole sweep without a rotation
@@ -202,10 +209,11 @@ bool launch_small_eig(hipStream_t st, const double* H, int64_t ldh, const double
   const int la = m | 1;
   const bool vlds = (size_t)2 * la * m * sizeof(double) <= (size_t)150 * 1024;
   const size_t shmem = sizeof(double) * (size_t)la * m * (vlds ? 2 : 1);
-  // A Jacobi step has (m/2) * m element pairs per phase.  The phases are LDS-latency bound, not barrier bound: with four
-  // pairs per thread (512 threads at m = 64) a configs[1] solve took 4.25 ms against 3.54 ms with all 1024 threads
-  // (one or two pairs each), so the workgroup stays full down to m = 32
-  const int threads = m >= 32 ? EIG_THREADS : std::max(64, ((m * m / 2 + 63) / 64) * 64);
+  // A Jacobi step has (m/2) * m element pairs per phase: one per thread up to the 1024 of a workgroup (with four pairs per
+  // thread - 512 threads at m = 64 - a configs[1] solve took 4.25 instead of 3.54 ms: the phases are LDS-latency bound)
+  int mp = 1;
+  while (mp < m) mp <<= 1;
+  const int threads = std::max(64, std::min(EIG_THREADS, mp * std::max(1, mp / 2)));   // one (pair, row) per thread up to 1024; a multiple of mp
   if (vlds) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_eig_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
