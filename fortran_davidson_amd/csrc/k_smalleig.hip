@@ -7,7 +7,8 @@
 //   standard:     H = Y Theta Y^T                                                                    (Y^T Y = I)
 //
 // Eigen-decomposition: cyclic two-sided Jacobi with the round-robin ("tournament") ordering - m/2 disjoint rotations
-// per step, m - 1 steps per sweep, until a whole sweep finds no |a_pq| > 1e-16 sqrt(|a_pp a_qq|); the projected matrices
+// per step (two barrier-separated phases: rotation angles, then every 2 x 2 block of A updated from both sides at once),
+// m - 1 steps per sweep, until a whole sweep finds no |a_pq| > 1e-16 sqrt(|a_pp a_qq|); the projected matrices
 // of a Davidson basis are close to diagonal (after a restart exactly diagonal), so 3-6 sweeps suffice.  The symmetric matrix lives in LDS (column-major, odd
 // stride); the accumulated rotations too when both fit (m <= 96), else in global memory (L2).  Eigenvalues leave
 // ascending (ties by index), eigenvectors in the matching order.  One workgroup: the order is at most 128, the sweeps
@@ -138,30 +139,38 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
         pair_p[tid] = p; pair_q[tid] = q < m ? q : -1;
       }
       __syncthreads();
-      // columns: A <- A J, V <- V J
-      if (ti < m)
-        for (int k = tk; k < half; k += kstep) {
-          const int p = pair_p[k], q = pair_q[k];
-          const double c = rot_c[k], sn = rot_s[k];
-          if (q < 0 || sn == 0.0) continue;
-          const double ap = As[ti + p * la], aq = As[ti + q * la];
-          As[ti + p * la] = c * ap - sn * aq;
-          As[ti + q * la] = sn * ap + c * aq;
-          const double vp = Vs[ti + (size_t)p * lv], vq = Vs[ti + (size_t)q * lv];
-          Vs[ti + (size_t)p * lv] = c * vp - sn * vq;
-          Vs[ti + (size_t)q * lv] = sn * vp + c * vq;
+      // A <- J^T A J in ONE phase: the 2 x 2 block of row pair ki and column pair kj only depends on itself, so a thread
+      // that owns a block applies the column rotation of pair kj and the row rotation of pair ki to its four entries
+      // with no barrier in between (two phases per step instead of three); V <- V J alongside (columns only)
+      {
+        const int hp = mp >> 1 ? mp >> 1 : 1;                   // pair slots padded to a power of two
+        const int lgh = lg > 0 ? lg - 1 : 0;
+        for (int e = tid; e < hp * hp; e += NT) {
+          const int ki = e >> lgh, kj = e & (hp - 1);
+          if (ki >= half || kj >= half) continue;
+          const int pi = pair_p[ki], qi = pair_q[ki], pj = pair_p[kj], qj = pair_q[kj];
+          const double ci = rot_c[ki], si = rot_s[ki], cj = rot_c[kj], sj = rot_s[kj];
+          if (si == 0.0 && sj == 0.0) continue;
+          // entries (pi|qi, pj|qj); a missing partner (odd order: q = -1) has the identity rotation and no entries
+          double app = As[pi + pj * la], apq = qj >= 0 ? As[pi + qj * la] : 0.0;
+          double aqp = qi >= 0 ? As[qi + pj * la] : 0.0, aqq = (qi >= 0 && qj >= 0) ? As[qi + qj * la] : 0.0;
+          const double tpp = cj * app - sj * apq, tpq = sj * app + cj * apq;      // columns
+          const double tqp = cj * aqp - sj * aqq, tqq = sj * aqp + cj * aqq;
+          As[pi + pj * la] = ci * tpp - si * tqp;                                 // rows
+          if (qj >= 0) As[pi + qj * la] = ci * tpq - si * tqq;
+          if (qi >= 0) As[qi + pj * la] = si * tpp + ci * tqp;
+          if (qi >= 0 && qj >= 0) As[qi + qj * la] = si * tpq + ci * tqq;
         }
-      __syncthreads();
-      // rows: A <- J^T A
-      if (ti < m)
-        for (int k = tk; k < half; k += kstep) {
-          const int p = pair_p[k], q = pair_q[k];
-          const double c = rot_c[k], sn = rot_s[k];
-          if (q < 0 || sn == 0.0) continue;
-          const double ap = As[p + ti * la], aq = As[q + ti * la];
-          As[p + ti * la] = c * ap - sn * aq;
-          As[q + ti * la] = sn * ap + c * aq;
-        }
+        if (ti < m)
+          for (int k = tk; k < half; k += kstep) {
+            const int p = pair_p[k], q = pair_q[k];
+            const double c = rot_c[k], sn = rot_s[k];
+            if (q < 0 || sn == 0.0) continue;
+            const double vp = Vs[ti + (size_t)p * lv], vq = Vs[ti + (size_t)q * lv];
+            Vs[ti + (size_t)p * lv] = c * vp - sn * vq;
+            Vs[ti + (size_t)q * lv] = sn * vp + c * vq;
+          }
+      }
       __syncthreads();
     }
     if (flag == 0) break;                            // a whole sweep without a rotation
