@@ -1401,7 +1401,10 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     const int64_t* owned = multi ? e->sym_row_off : nullptr;
     const int64_t total_rows = (int64_t)e->nranks * e->nslab;
     {
-      static const int overlap_env = [] { const char* ev = getenv("DAV_SYM_OVERLAP"); return ev ? atoi(ev) : 1; }();
+      // Opt-in (DAV_SYM_OVERLAP=1) until it has run on a multi-GPU node: the pipeline is exercised through a 1-rank RCCL
+      // communicator only, and a second stream on one communicator is exactly the kind of thing that must be seen on real
+      // links before it becomes the default of a run nobody can watch
+      static const int overlap_env = [] { const char* ev = getenv("DAV_SYM_OVERLAP"); return ev ? atoi(ev) : 0; }();
       if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 16) == 2)
         return apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
     }
