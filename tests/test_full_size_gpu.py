@@ -146,3 +146,17 @@ def test_config5_n1000000_matrix_free_four_ranks(storage):
     # the one-rank run of this problem (bench.py configs4_free leg, same seed): first three eigenvalues
     assert np.abs(out[0][0][:3] - np.array([0.9999946355480692, 1.9999955176766737, 2.9999964218285395])).max() < 1e-9
     assert out[0][1] == 4
+
+
+def test_config3_n200000_restart_forcing_variant():
+    """configs[2] with a denser coupling (sparsity 2e-2 instead of 1e-3): the basis passes max_dim_sub = 80 before the
+    pairs converge, so the solve goes through collapse restarts at full size (src/davidson.f90:215-220) - 32-, 64-column
+    and restart sweeps of the 160 GB triangle; properties of the answer as above."""
+    n, L, sp = 200000, 16, 2e-2
+    with fd.DavidsonEngine(n, L, 80, storage="symmetric") as eng:
+        eng.generate_diagonal_dominant(1, sp, seed=3)
+        lam, _, iters = eng.solve("DPR", 200, TOL, want_vectors=False)
+        assert 3 < iters <= 200
+        verify_on_device(eng, lam, False, n, sp)
+        st = eng.c.stats()
+        assert st.applies >= iters            # at least one sweep per iteration (restarts re-apply the kept block)
