@@ -124,3 +124,19 @@ def test_device_rr_with_restarts_policies_and_ranks(golden, storage, policy, nra
             assert (residuals(A, B, dev[0], dev[1]) < case["tol"]).all()
         for e in engs:
             e.close()
+
+
+@pytest.mark.parametrize("n,L,sp,md", [(17, 1, 1e-2, None), (33, 2, 1e-2, None), (64, 3, 1e-2, 4), (130, 5, 5e-2, 12),
+                                       (257, 1, 1e-1, 3), (500, 16, 1e-2, None)])
+def test_edge_shapes_with_device_rr_against_oracle(n, L, sp, md, monkeypatch):
+    """tiny and ragged orders, lowest = 1 (projected problems of order 2), restarts every iteration, a basis of 128 columns:
+    the device eigensolver drives the outer loop exactly like host LAPACK (and the oracle)"""
+    monkeypatch.setenv("DAVIDSON_DEVICE_RR", "1")
+    A = O.generate_diagonal_dominant(n, sp, seed=31)
+    tr = O.Trace()
+    lam_o, vec_o, it_o = O.generalized_eigensolver_dense(A, L, "DPR", 60, 1e-8, md, trace=tr)
+    lam, vec, it = fd.generalized_eigensolver(A, L, "DPR", 60, 1e-8, md)
+    assert it == it_o, (it, it_o, tr.widths)
+    assert np.abs(lam - lam_o).max() < EV_TOL
+    if tr.converged:
+        assert (residuals(A, None, lam, vec) < 1e-8).all()

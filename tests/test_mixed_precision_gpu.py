@@ -82,3 +82,19 @@ def test_fp32_inner_sweeps_at_a_size_with_super_row_schedules(monkeypatch):
     assert res["32"][1] == res["64"][1]
     assert np.abs(res["32"][0] - res["64"][0]).max() < 1e-9
     assert res["32"][2] < 0.8 * res["64"][2]            # the inner sweeps (most of them) moved half the bytes
+
+
+@pytest.mark.parametrize("n,L,sp,md,gev", [(200, 3, 5e-2, None, False), (300, 4, 1e-1, None, False),
+                                           (200, 3, 5e-2, 10, True), (400, 5, 2e-2, None, True), (150, 2, 3e-1, 8, False)])
+def test_fp32_inner_sweeps_on_harder_matrices_keep_the_oracle_iteration_counts(n, L, sp, md, gev, monkeypatch):
+    """strong off-diagonals, generalized problems and restarts, through the drop-in call with both knobs from the
+    environment (symmetric storage + fp32 inner sweeps): same outer iteration counts as the reference's dense DSYSV solves"""
+    monkeypatch.setenv("DAVIDSON_STORAGE", "symmetric")
+    monkeypatch.setenv("DAVIDSON_INNER_PRECISION", "32")
+    A = O.generate_diagonal_dominant(n, sp, seed=5)
+    B = O.generate_diagonal_dominant(n, sp * 0.1, 1.0, seed=6) if gev else None
+    lam_o, _, it_o = O.generalized_eigensolver_dense(A, L, "GJD", 40, 1e-8, md, B)
+    lam, vec, it = fd.generalized_eigensolver(A, L, "GJD", 40, 1e-8, md, B)
+    assert it == it_o
+    assert np.abs(lam - lam_o).max() < EV_TOL
+    assert (residuals(A, B, lam, vec) < 1e-8).all()
