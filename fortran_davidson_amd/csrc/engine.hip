@@ -1279,6 +1279,26 @@ static bool inner_f32_tiles(E* e, OpDesc& o) {
   return true;
 }
 
+// The super-row sweep of one launch: stored fp64 tiles, two block rows per workgroup and more than 8 columns run the
+// one-wave-per-SIMD kernel (k_matvec_symw.hip: 32 columns per workgroup, or 16 for a block of <= 16); generated operators,
+// the fp32 copy and the k <= 8 schedule (R = 4, 4x4x4 MFMA) stay on matvec_sym9_kernel.
+// DAV_SYM_WIDE = 0: never (A/B runs), 1: blocks wider than 16 columns only, 2 (default): from 9 columns on.  Read per call.
+static void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
+                       int npair, int64_t dstride, int64_t tstride) {
+  const char* ev = getenv("DAV_SYM_WIDE");
+  const int wide = ev ? atoi(ev) : 2;
+  if (R == 2 && o.kind == DAV_KIND_DENSE && !use32 && wide > 0 && (kk > 16 || wide > 1)) {
+    const int nbw = kk > 16 ? 2 : 1;
+    launch_matvec_symw(e->stream, nbw, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+                       (npair + nbw - 1) / nbw, e->xt_group_stride, dstride, tstride);
+    return;
+  }
+  launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
+                     o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk,
+                     slabD, slabT, npair, e->xt_group_stride, dstride, tstride);
+}
+
+
 // Symmetric sweep of k > 32 columns over several ranks with RCCL, chunks of 32 columns software-pipelined over two streams:
 //   comm stream:  gather(0)            gather(1)   scatter(0)   gather(2)   scatter(1) ...
 //   main stream:  pack(0) pack(1) | wait gather(0) sweep(0) reduce(0) | pack(2) wait gather(1) sweep(1) reduce(1) | to_panel(0) ...
@@ -1341,9 +1361,7 @@ static int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, i
     if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
     double* slabT = e->sym_slab + (int64_t)npair * dstride;
     if (pl->nitems > 0)
-      launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
-                         o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin,
-                         xt_of(i), kk, e->sym_slab, slabT, npair, e->xt_group_stride, dstride, tstride);
+      sym9_sweep(e, R, o, use32, pl, xt_of(i), kk, e->sym_slab, slabT, npair, dstride, tstride);
     CHK(timed_end(e, kslot));
     // partial of the whole product of this chunk (the buffer of this parity was last read by the reduce-scatter of chunk
     // i - 2, whose completion the main stream waited for when it finished chunk i - 2 below)
@@ -1444,10 +1462,7 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       const int nitems = R > 1 ? pl->nitems : e->sym_nitems;
       if (nitems > 0) {                      // a rank can be left without a block row (more ranks than groups of block rows)
         if (R > 1)
-          launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
-                             o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{},
-                             e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, e->xt, kk, e->sym_slab, slabT, npair,
-                             e->xt_group_stride, dstride, tstride);
+          sym9_sweep(e, R, o, use32, pl, e->xt, kk, e->sym_slab, slabT, npair, dstride, tstride);
         else if (o.kind != DAV_KIND_DENSE)
           launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
                                       e->xt_group_stride, dstride, tstride);
