@@ -11,42 +11,66 @@
 //   - the X_I operand of the transposed product for those rows (it never changes within an item: no LDS, no re-reads),
 // so one tile load and one LDS transposition feed 16 NB MFMAs per 32 x 16 sub-block instead of 16, the transposition of
 // half-step s + 1 is issued before the MFMAs of half-step s (its latency hides behind them - the registers for that are
-// what the two-wave kernel did not have), and addresses are a scalar base plus constant per-lane offsets.
+// what the two-wave kernel did not have), and addresses are a scalar descriptor plus constant per-lane offsets.
 // Same work items, slab layout, masking rules and fixed-order sums as matvec_sym9_kernel<2> (k_matvec_sym9.hip), so the
 // same reduction kernel follows; results are bitwise reproducible run to run.
 //
-// Registers.  The compiler splits the 512 registers of a wave into 256 VGPRs + 256 accumulation registers and, left to
-// itself, parks MFMA operands in the second half and copies them back before every use (160 v_accvgpr moves per unit).
-// The MFMAs are therefore inline assembly with the register file of every operand stated: direct partials and X_I in
-// accumulation registers (an MFMA reads A / B operands from either half), everything a VALU or DS instruction touches
-// in VGPRs.  What the compiler does not know about an asm MFMA is handled structurally: every MFMA operand is
-// produced by a load (never by a VALU instruction: the B operand of a tile that is not there is loaded from a page of
-// zeros instead of multiplied by zero; a chain starts with the literal-zero form; no branches around the MFMAs, whose
-// copies the compiler would put between them), and results are read by other instructions only behind
-// the 18 wait states a 16-pass MFMA needs (MFMA_DRAIN).  tests/test_isa_lint.py checks the emitted code for both rules.
+// Registers.  A wave's 512 registers are 256 VGPRs + 256 accumulation registers.  Measured (profiles/ubench/mfma_regfile.hip,
+// r03_mfma_regfile.log): v_mfma_f64_16x16x4_f64 issues every 64.0 cycles with its accumulator (C / D) in VGPRs - for any
+// distance between two MFMAs of one chain, back to back included - but only every 83.1 cycles with C / D in
+// accumulation registers; A and B operands cost nothing in either half.  So: accumulators (direct partials, transposed
+// partial) in VGPRs; what an MFMA only READS in accumulation registers - X_I (128), the load ring of tile entries (64),
+// the X_J operand (16 NB).  The compiler's allocator does not keep such values there reliably (it prefers VGPRs for a
+// value that may live in either half, runs out, and copies - a VALU write right in front of an MFMA it does not know to
+// be one), so the ring and X_J live in FIXED accumulation registers a[160:255] that only inline assembly names: buffer
+// loads straight into them, DS writes and MFMAs straight out of them, vmcnt counted by hand (every vector-memory load of
+// the loop is one of these; the compiler's own operations - prologue, strip stores - only make the counts conservative).
+// What the compiler does not know about an asm MFMA is handled structurally: every MFMA operand is produced by a
+// load, never by a VALU instruction (the B operand of a tile that is not there is loaded from a page of zeros instead
+// of multiplied by zero; a chain starts with the literal-zero form; no branches around MFMAs), and MFMA results are read
+// by other instructions only behind the 18 wait states a 16-pass MFMA needs (MFMA_DRAIN).  tests/test_isa_lint.py checks
+// the emitted code: no compiler instruction touches a[160:255], no VALU write within two instructions of an MFMA that reads it.
 #include "kernels.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #define MFMA_DRAIN "s_nop 15\n\ts_nop 3"
 
-// D (accumulation registers) += A (VGPR) B (VGPR)
-__device__ __forceinline__ void mfma_acc_vv(f64x4& d, double a, double b) {
-  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
-}
-// the same with D in VGPRs (what does not fit the accumulation half)
-__device__ __forceinline__ void mfma_v_vv(f64x4& d, double a, double b) {
-  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
-}
-// D (VGPRs) = or += A (VGPR) B (accumulation register)
-__device__ __forceinline__ void mfma_v_va_first(f64x4& d, double a, double b) {
-  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=v"(d) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma_v_va(f64x4& d, double a, double b) {
-  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
-}
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <class F, int... Is>
+__device__ __forceinline__ void symw_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void symw_static_for(F&& f) { symw_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// fixed accumulation registers: ring slot k (step mod NSLOT), load u: a[RING(k,u) .. +3] = rows 2c, 2c+1 of tile column 4u + g
+// (x = +0..1, y = +2..3), the ring ending at a223; X_J operand set s (unit parity), column quad u, group bcb: a[XJ(s,u,bcb) .. +1]
+#define SYMW_RING(k, u) (224 - 16 * NSLOT + 16 * (k) + 4 * (u))
+#define SYMW_XJ(s, u, bcb) (224 + 16 * (s) + 4 * (u) + 2 * (bcb))
+constexpr int symw_fixed_lo(int nb) { return nb == 1 ? 224 - 16 * 8 : 224 - 16 * 4; }   // first fixed register (tests/test_isa_lint.py)
 
 __device__ double symw_zero_page[16 * 16];     // B operand of a tile that is not there
+
+#ifdef DAV_SYMW_STAMPS
+// diagnostic build only (scratch/): shader cycles per wave summed over units - [0] unit start to the barrier (half-step 0),
+// [1] barrier wait, [2] LDS reads of the sum + half-step 1 + sum, [3] units, [4] / [5] shader clock / 100 MHz clock
+__device__ unsigned long long symw_stamp[12];
+#define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int dav_symw_stamps(unsigned long long* out) {
+  unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(symw_stamp), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(symw_stamp), z, sizeof(z)) != hipSuccess;
+}
+#else
+#define STAMP(t) do { } while (0)
+#endif
+
+// descriptor of a raw buffer (stride 0) at p: the hardware adds a per-lane and a scalar 32-bit offset
+__device__ __forceinline__ i32x4 symw_desc(const void* p, int bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), bytes, 0x00020000};
+}
 
 template <int NB>
 __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
@@ -58,10 +82,13 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   constexpr int NRS = 4;                // 128-row slices = waves
   constexpr unsigned UPJ = SYM_TB / 16; // units (16 tile columns) per tile column
   constexpr unsigned UPS = 4;           // units per 64-column strip of the stage
-  constexpr int DEPTH = 3;              // half-steps of load lookahead (ring of 4 slots)
-  constexpr int ACC_A = NB == 2 ? 3 : 4; // half-steps whose direct partials live in accumulation registers (X_I: all of it)
+  // ring of tile loads: 4 slots / 3 half-steps of lookahead next to 32 columns of operands; 8 / 7 for 16 columns, where the
+  // sweep is HBM-bound (k = 16: 636 cycles per unit in the vmcnt waits of the 4-slot ring) and the registers are there
+  constexpr int NSLOT = NB == 1 ? 8 : 4;
+  constexpr int DEPTH = NSLOT - 1;
   constexpr int TRS = 34, TRW = 16 * TRS, RS = 33;
   constexpr int ZW = 64, ZS = ZW + 2;   // stage strip: 64 tile columns, padded
+  constexpr int NBL = 4 * NB;           // X_J loads per unit
   __shared__ __attribute__((aligned(16))) double tr[NRS * TRW];
   __shared__ __attribute__((aligned(16))) double zred[2][NRS][NB * 256];   // [unit parity][wave][group][f64x4 per lane]
   __shared__ __attribute__((aligned(16))) double zst[2][NB * 16 * ZS];      // [strip parity][block column][tile column]
@@ -100,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 
   // X_I of this wave's 128 rows, in the lane layout of the transposed product's B operand: for half-step hs, 16-row block
   // ib, row pair j and parity xy the lane (k = g, column c) holds X[row 32 hs + 16 ib + 4 g + 2 j + xy, block column c].
-  // A wave without a block row never uses it (its MFMAs are skipped).
+  // A wave without a block row reads the rows of block row Imax; its partial is multiplied by zero.
   double xI[4][2][2][2][NB];
   {
     const double* xr = xt + ((int64_t)(have_row ? I : Imax) * SYM_TB + 128 * rhalf) * 16;
@@ -128,47 +155,125 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 
   const unsigned nunits = (unsigned)(J1 - J0) * UPJ;
   double* tw = tr + wave * TRW;
+  // LDS byte addresses (the low 32 bits of a generic pointer into LDS are the LDS offset)
+  unsigned long long st_vm = 0;      // (diagnostic build) cycles in the vmcnt waits of the transpositions
+  unsigned long long st_f[3] = {0, 0, 0};   // ... in the tile loads, in the transposition (wait included), in the 32 MFMAs of a half-step
+  (void)st_vm; (void)st_f;
+  const unsigned tw_wr = (unsigned)reinterpret_cast<uintptr_t>(tw + g * TRS + 2 * c);    // + 4 u rows of TRS: the direct layout
 
-  // tile loads: buffer loads - a scalar descriptor on the unit's 128 x 16 sub-block, constant per-lane offsets (rows 2c, 2c+1
-  // of column 4u + g), the half-step as an immediate: no vector address arithmetic in the loop
-  using u32x4 = unsigned __attribute__((ext_vector_type(4)));
-  using u32x2 = unsigned __attribute__((ext_vector_type(2)));
-  f64x2 ra[4][4];
+  // tile loads: a scalar descriptor on the unit's 128 x 16 sub-block, constant per-lane offsets (rows 2c, 2c+1 of column
+  // 4u + g), the half-step as a scalar offset: no vector address arithmetic in the loop
   unsigned voff[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) voff[u] = ((4 * u + g) * SYM_TB + 2 * c) * (unsigned)sizeof(double);
   // tile this wave works on in tile column J: its own if it is stored, else the (stored) tile of block row Imax
-  auto unit_rsrc = [&](unsigned q) {
+  // (the two block rows a wave can touch: their first tiles are read once - a scalar load per unit would expose its latency)
+  const double* const trow_own = tiles + row_off[have_row ? I : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf;
+  const double* const trow_max = tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf;
+  auto unit_desc = [&](unsigned q) {
     q = q < nunits ? q : nunits - 1;
     const int J = J0 + (int)(q / UPJ);
     const unsigned col = (q % UPJ) * 16;
-    const int Ie = (have_row && J <= I) ? I : Imax;
-    const double* ub = tiles + (row_off[Ie] + J) * (int64_t)(SYM_TB * SYM_TB) + col * SYM_TB + 128 * rhalf;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(ub), 0, 16 * SYM_TB * (int)sizeof(double), 0x00020000);
+    const double* ub = ((have_row && J <= I) ? trow_own : trow_max) + (int64_t)J * (SYM_TB * SYM_TB) + col * SYM_TB;
+    return symw_desc(ub, 16 * SYM_TB * (int)sizeof(double));
   };
-  auto load_hs = [&](__amdgpu_buffer_rsrc_t ur, int hs, f64x2 (&a)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      a[u] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(ur, voff[u] + hs * 32 * (unsigned)sizeof(double), 0, 0));
+  // 4 buffer loads of half-step hs of the unit behind `d` into ring slot SLOT
+  auto load_hs = [&](auto slot, const i32x4& d, int hs) {
+    constexpr int SLOT = decltype(slot)::value;
+    const int so = hs * 32 * (int)sizeof(double);
+    symw_static_for<4>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      const unsigned vo = voff[U];           // (operands of an asm statement inside a generic lambda are not captured by themselves)
+      const i32x4 dd = d;
+      const int soo = so;
+      asm volatile("buffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
+                   :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
+    });
   };
-  // B operand of the direct product for unit q: X_J rows of the unit's 16 tile columns - or, where this wave has no
-  // stored tile (above the diagonal inside the diagonal super block, block row past the end), a page of zeros
+  // B operand of the direct product for unit q -> set SET: X_J rows of the unit's 16 tile columns - or, where this wave
+  // has no stored tile (above the diagonal inside the diagonal super block, block row past the end), a page of zeros
   const unsigned boff = (g * 16 + c) * (unsigned)sizeof(double);
-  auto load_b = [&](unsigned q, double (&b)[4][NB]) {
+  auto load_b = [&](auto set, unsigned q) {
+    constexpr int SET = decltype(set)::value;
     q = q < nunits ? q : nunits - 1;
     const int J = J0 + (int)(q / UPJ);
     const bool stored = have_row && J <= I;
     const double* xj = stored ? xt + ((int64_t)J * SYM_TB + (q % UPJ) * 16) * 16 : symw_zero_page;
     const int gs = stored ? (int)(xt_gstride * (int64_t)sizeof(double)) : 0;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(xj), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int bcb = 0; bcb < NB; ++bcb)
-        b[u][bcb] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(xr, boff + (4 * u) * 16 * (unsigned)sizeof(double), bcb * gs, 0));
+    const i32x4 d = symw_desc(xj, 0x7fffffff);
+    symw_static_for<4>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      symw_static_for<NB>([&](auto bcb) {
+        constexpr int B = decltype(bcb)::value;
+        const int so = B * gs + (4 * U) * 16 * (int)sizeof(double);
+        const unsigned bo = boff;
+        const i32x4 dd = d;
+        asm volatile("buffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
+                     :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
+      });
+    });
   };
-  // strip st of the run (64 tile columns; four per tile column): stage -> slabT slot (S, J) = [16 block columns][256 tile columns]
+  // LDS transposition of the 32 x 16 sub-block in ring slot SLOT: direct layout (rows 2c, 2c+1 of column 4u + g) -> Gram
+  // layout (p[ib][j] = rows 16 ib + 4 g + 2 j, + 1 of column c); wave-private, DS operations of a wave execute in order:
+  // no barrier.  YOUNGER = vector-memory operations issued after the slot's loads: what may still be in flight.
+  auto transpose = [&](auto slot, auto younger, f64x2 (&p)[2][2], bool early = false) {
+    constexpr int SLOT = decltype(slot)::value;
+    // early (the first units of an item): fewer X_J loads have been issued than the steady-state count assumes
+    if (early) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
+#if DAV_SYMW_STAMPS > 1
+    unsigned long long w0, w1;
+    STAMP(w0);
+    asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(decltype(younger)::value) : "memory");
+    STAMP(w1);
+    st_vm += w1 - w0;
+#else
+    asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(decltype(younger)::value) : "memory");
+#endif
+    symw_static_for<4>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      const unsigned wa = tw_wr;
+      asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3"
+                   :: "v"(wa), "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "i"(4 * U * TRS * (int)sizeof(double)) : "memory");
+    });
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      p[ib][0] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g);
+      p[ib][1] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g + 2);
+    }
+  };
+
   const int64_t zbase = zslot_begin[S];
+  // The exchange of a unit's transposed partials is spread over the NEXT unit, so that what it waits for hides behind
+  // MFMAs: end of unit q: partial -> LDS (no wait); unit q + 1: after half-step 0 one workgroup barrier (the writes are
+  // 2000 cycles old; what is left is the skew between the four waves), the LDS reads of the cross-wave sum are issued,
+  // half-step 1 runs, then the sum is formed and staged.  zred alternates with the unit parity: a wave that runs ahead
+  // cannot overwrite what a slower one still sums, because to get there it has to pass the next barrier.
+  unsigned zoff[NB];                 // stage offsets of the entries this lane sums (constant; + 16 (q & 3) + strip parity)
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const unsigned e = wave * (NB * 64) + 64 * t + lane;
+    const unsigned bcb = e >> 8, half = (e >> 7) & 1, ln = (e & 127) >> 1, jj = e & 1;
+    zoff[t] = (16 * bcb + (ln & 15)) * ZS + (ln >> 4) + 4 * (2 * half + jj);
+  }
+  unsigned long long st_hs = 0, st_bar = 0, st_sum = 0, st_unit = 0;
+  (void)st_hs; (void)st_bar; (void)st_sum; (void)st_unit;
+#ifdef DAV_SYMW_STAMPS
+  unsigned long long tk0, tr0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0), "=s"(tr0) :: "memory");
+#endif
+  double sreg[NRS][NB];              // the slices of the entries this lane sums, on their way from LDS
+  auto sum_issue = [&](unsigned qp) {          // cross-wave sum of unit qp: LDS reads
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int sl = 0; sl < NRS; ++sl) sreg[sl][t] = zred[qp & 1][sl][wave * (NB * 64) + 64 * t + lane];
+  };
+  auto sum_finish = [&](unsigned qp) {         // slices in fixed order -> stage
+    double* zs = zst[(qp / UPS) & 1] + (qp & 3) * 16;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) zs[zoff[t]] = ((sreg[0][t] + sreg[1][t]) + sreg[2][t]) + sreg[3][t];
+  };
+  // strip st of the run (64 tile columns x 16 NB block columns = 512 NB f64x2 = 2 NB per thread): stage -> slabT
   auto flush_strip = [&](unsigned st) {
     const int J = J0 + (int)(st >> 2);
     if (J >= Imax) return;                           // no block row of the super row lies below tile column J
@@ -177,104 +282,157 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     for (int bcb = 0; bcb < NB; ++bcb) {
       const int kc = kcols - 16 * bcb < 16 ? kcols - 16 * bcb : 16;
       double* outT = slabT + bcb * slabT_gstride + (zbase + J) * 16 * SYM_TB + (st & 3) * ZW;
-      for (int e = threadIdx.x; e < kc * (ZW / 2); e += 256) {
-        const int bc = e >> 5, pr = e & 31;
-        *reinterpret_cast<f64x2*>(outT + bc * SYM_TB + 2 * pr) = *reinterpret_cast<const f64x2*>(zs + (16 * bcb + bc) * ZS + 2 * pr);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = threadIdx.x + 256 * h, bc = e >> 5, pr = e & 31;
+        if (bc < kc) *reinterpret_cast<f64x2*>(outT + bc * SYM_TB + 2 * pr) = *reinterpret_cast<const f64x2*>(zs + (16 * bcb + bc) * ZS + 2 * pr);
       }
     }
   };
-  // LDS transposition of a 32 x 16 sub-block: direct layout (rows 2c, 2c+1 of column 4u + g) -> Gram layout (p[ib][j] =
-  // rows 16 ib + 4 g + 2 j, + 1 of column c); wave-private, DS operations of a wave execute in order: no barrier
-  auto transpose = [&](const f64x2 (&a)[4], f64x2 (&p)[2][2]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c) = a[u];
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      p[ib][0] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g);
-      p[ib][1] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g + 2);
-    }
-  };
 
-  double b0[4][NB], b1[4][NB];       // B operands of the direct product: even / odd units
   f64x2 p[2][2][2];                 // [half-step parity]: Gram-layout operands of the current and of the next half-step
-  load_b(0, b0);
-  __amdgpu_buffer_rsrc_t ur = unit_rsrc(0);
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) load_hs(ur, d, ra[d]);
-  transpose(ra[0], p[0]);
+  // Vector-memory operations in program order from here on: X_J(0), L(0) .. L(DEPTH - 1); per unit q: X_J(q + 1), then per
+  // half-step hs the 4 loads of step s + DEPTH (s = 4 q + hs).  The transposition in half-step hs reads step s + 1: issued
+  // after it are DEPTH - 1 steps of loads plus the X_J loads of every unit boundary in between.  X_J(q) itself must have
+  // landed before the MFMAs of unit q: after it come the 16 loads of unit q - 1, X_J(q + 1) and the 4 loads of hs = 0.
+  constexpr auto younger = [](int hs) {
+    int nx = 0;
+    for (int d = 0; d <= DEPTH - 2; ++d) nx += ((hs - d) % 4 + 4) % 4 == 0;
+    const int y = 4 * (DEPTH - 1) + NBL * nx;
+    return hs == 0 && y > 20 + NBL ? 20 + NBL : y;
+  };
+  i32x4 ud[3] = {unit_desc(0), unit_desc(1), unit_desc(2)};     // descriptors of units q, q + 1, q + 2
+  load_b(std::integral_constant<int, 0>{}, 0);
+  symw_static_for<DEPTH>([&](auto sc) {
+    constexpr int st = decltype(sc)::value;
+    load_hs(std::integral_constant<int, st % NSLOT>{}, ud[st / 4], st % 4);
+  });
+  transpose(std::integral_constant<int, 0>{}, std::integral_constant<int, 4 * (DEPTH - 1)>{}, p[0]);
 
-  auto unit = [&](unsigned q, const double (&b)[4][NB], double (&bn)[4][NB]) {
-    load_b(q + 1, bn);
-    const __amdgpu_buffer_rsrc_t urn = unit_rsrc(q + 1);
+  auto unit = [&](unsigned q, auto set) {
+    constexpr int SET = decltype(set)::value;          // X_J operand set of this unit; the next unit's goes to the other
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    (void)t0; (void)t1; (void)t2; (void)t3;
+    STAMP(t0);
+    constexpr int S0 = NSLOT == 8 ? 4 * SET : 0;       // ring slot of this unit's half-step 0
+    load_b(std::integral_constant<int, 1 - SET>{}, q + 1);
+    const i32x4 udn = unit_desc(q + 3);
     const int J = J0 + (int)(q / UPJ);
     const double zm = (have_row && J < I) ? 1.0 : 0.0;   // the tile lies below the diagonal: it feeds the transposed product
-    f64x4 zc[NB][2];                           // transposed partials of the unit: [group][parity chain]
-#pragma unroll
-    for (int hs = 0; hs < 4; ++hs) {
+    const bool flush_due = (q & 3) == 1 && q >= 5;       // the sums of strip (q - 5) / 4 were staged during unit q - 1
+    f64x4 zc[NB];                              // transposed partials of the unit
+    symw_static_for<4>([&](auto hsc) {
+      constexpr int hs = decltype(hsc)::value;
+      if (hs == 1 && q > 0) {
+        STAMP(t1);
+        __syncthreads();
+        STAMP(t2);
+        if (flush_due) flush_strip((q - 5) / 4);       // once per four units: not worth registers across MFMAs
+        sum_issue(q - 1);
+      }
+      if (hs == 2 && q > 0) {
+        sum_finish(q - 1);
+        STAMP(t3);
+      }
+      // The compiler counts only its own LDS operations: a wait for this half-step's Gram operands (read one half-step
+      // ago) placed among the MFMAs would, with the transposition's asm DS writes queued behind them, turn into a wait
+      // for those writes.  Named here, the wait lands before the transposition is issued, where it costs nothing.
+      {
+        const f64x2(&pw)[2][2] = p[hs & 1];
+        asm volatile("" :: "v"(pw[0][0]), "v"(pw[0][1]), "v"(pw[1][0]), "v"(pw[1][1]));
+      }
       // the ring slot being refilled held half-step hs - 1, whose MFMAs have been issued
-      if (hs == 0) load_hs(ur, DEPTH, ra[DEPTH & 3]);
-      else load_hs(urn, hs - 1, ra[(hs + DEPTH) & 3]);
-      transpose(ra[(hs + 1) & 3], p[(hs + 1) & 1]);
-      const f64x2(&a)[4] = ra[hs];
+#if DAV_SYMW_STAMPS > 1
+      unsigned long long fa, fb, fc, fd;
+      STAMP(fa);
+#endif
+      load_hs(std::integral_constant<int, (S0 + hs + DEPTH) % NSLOT>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
+#if DAV_SYMW_STAMPS > 1
+      STAMP(fb);
+#endif
+      transpose(std::integral_constant<int, (S0 + hs + 1) % NSLOT>{}, std::integral_constant<int, younger(hs)>{}, p[(hs + 1) & 1], q < 2);
       const f64x2(&pc)[2][2] = p[hs & 1];
+#if DAV_SYMW_STAMPS > 1
+      STAMP(fc);
+#endif
       // direct: D[row 2 (g + 4 reg) + par, block column c] += sum_k A[row, tile column 4 u + k] X_J[tile column, c]
       // transposed: Z[tile column g + 4 reg, block column c] += sum_k P[row 16 ib + 4 k + 2 j + xy, tile column] X_I[row, c]
-      // alternating; every accumulator chain is touched once per 4 NB MFMAs
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int u = 2 * ib + j;
-#pragma unroll
-          for (int bcb = 0; bcb < NB; ++bcb) {
-            if (hs < ACC_A) mfma_acc_vv(acc[hs][0][bcb], a[u].x, b[u][bcb]);
-            else mfma_v_vv(acc[hs][0][bcb], a[u].x, b[u][bcb]);
-            if (hs == 0 && u == 0) mfma_v_va_first(zc[bcb][0], pc[ib][j].x, xI[hs][ib][j][0][bcb]);
-            else mfma_v_va(zc[bcb][0], pc[ib][j].x, xI[hs][ib][j][0][bcb]);
-            if (hs < ACC_A) mfma_acc_vv(acc[hs][1][bcb], a[u].y, b[u][bcb]);
-            else mfma_v_vv(acc[hs][1][bcb], a[u].y, b[u][bcb]);
-            if (hs == 0 && u == 0) mfma_v_va_first(zc[bcb][1], pc[ib][j].y, xI[hs][ib][j][1][bcb]);
-            else mfma_v_va(zc[bcb][1], pc[ib][j].y, xI[hs][ib][j][1][bcb]);
-          }
-        }
-    }
-    // z[reg]: tile column col + g + 4 reg, block column c of group bcb, summed over this wave's 128 rows
+      symw_static_for<4>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, ib = u >> 1, j = u & 1;
+        symw_static_for<NB>([&](auto bc) {
+          constexpr int bcb = decltype(bc)::value;
+          // (named here: operands of an asm statement inside a generic lambda are not captured by themselves)
+          f64x4 &d0 = acc[hs][0][bcb], &d1 = acc[hs][1][bcb], &zz = zc[bcb];
+          const double px = pc[ib][j].x, py = pc[ib][j].y, x0 = xI[hs][ib][j][0][bcb], x1 = xI[hs][ib][j][1][bcb];
+          // four MFMAs as ONE statement (the compiler pads every asm statement with an s_nop): direct (rows of parity 0),
+          // transposed (row pair's first row), direct (parity 1), transposed (second row)
+          if constexpr (hs == 0 && u == 0)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c7:%c8], a[%c11:%c12], %0\n\t"
+                         "v_mfma_f64_16x16x4_f64 %2, %3, %5, 0\n\t"
+                         "v_mfma_f64_16x16x4_f64 %1, a[%c9:%c10], a[%c11:%c12], %1\n\t"
+                         "v_mfma_f64_16x16x4_f64 %2, %4, %6, %2"
+                         : "+v"(d0), "+v"(d1), "=&v"(zz)
+                         : "v"(px), "v"(py), "a"(x0), "a"(x1), "i"(SYMW_RING(S0 + hs, u)), "i"(SYMW_RING(S0 + hs, u) + 1), "i"(SYMW_RING(S0 + hs, u) + 2),
+                           "i"(SYMW_RING(S0 + hs, u) + 3), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1));
+          else
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c7:%c8], a[%c11:%c12], %0\n\t"
+                         "v_mfma_f64_16x16x4_f64 %2, %3, %5, %2\n\t"
+                         "v_mfma_f64_16x16x4_f64 %1, a[%c9:%c10], a[%c11:%c12], %1\n\t"
+                         "v_mfma_f64_16x16x4_f64 %2, %4, %6, %2"
+                         : "+v"(d0), "+v"(d1), "+v"(zz)
+                         : "v"(px), "v"(py), "a"(x0), "a"(x1), "i"(SYMW_RING(S0 + hs, u)), "i"(SYMW_RING(S0 + hs, u) + 1), "i"(SYMW_RING(S0 + hs, u) + 2),
+                           "i"(SYMW_RING(S0 + hs, u) + 3), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1));
+        });
+      });
+#if DAV_SYMW_STAMPS > 1
+      STAMP(fd);
+      st_f[0] += fb - fa; st_f[1] += fc - fb; st_f[2] += fd - fc;
+#endif
+    });
+    // z[reg]: tile column col + g + 4 reg, block column c of group bcb, summed over this wave's 128 rows -> LDS
     {
       double* zr = &zred[q & 1][wave][0];
-      if constexpr (NB == 2) asm volatile(MFMA_DRAIN : "+v"(zc[0][0]), "+v"(zc[0][1]), "+v"(zc[1][0]), "+v"(zc[1][1]));
-      else asm volatile(MFMA_DRAIN : "+v"(zc[0][0]), "+v"(zc[0][1]));
+      if constexpr (NB == 2) asm volatile(MFMA_DRAIN : "+v"(zc[0]), "+v"(zc[1]));
+      else asm volatile(MFMA_DRAIN : "+v"(zc[0]));
 #pragma unroll
       for (int bcb = 0; bcb < NB; ++bcb) {
-        const f64x4 z = (zc[bcb][0] + zc[bcb][1]) * zm;
+        const f64x4 z = zc[bcb] * zm;
         *reinterpret_cast<f64x2*>(zr + 256 * bcb + 2 * lane) = f64x2{z[0], z[1]};
         *reinterpret_cast<f64x2*>(zr + 256 * bcb + 128 + 2 * lane) = f64x2{z[2], z[3]};
       }
     }
-    __syncthreads();
-    // this barrier also publishes the stage writes of unit q - 1: the previous strip is complete
-    if (q % UPS == 0 && q > 0) flush_strip(q / UPS - 1);
-    // the four waves sum disjoint parts of the 16 x 16 NB partial, slices in fixed order
-#pragma unroll
-    for (int t = 0; t < NB; ++t) {
-      const unsigned e = wave * (NB * 64) + 64 * t + lane;
-      double s = zred[q & 1][0][e];
-#pragma unroll
-      for (int sl = 1; sl < NRS; ++sl) s += zred[q & 1][sl][e];
-      const unsigned bcb = e >> 8, half = (e >> 7) & 1, ln = (e & 127) >> 1, jj = e & 1;
-      const unsigned gg = ln >> 4, reg = 2 * half + jj;
-      const unsigned bc = 16 * bcb + (ln & 15);
-      const unsigned tcol = (q % UPJ) * 16 + gg + 4 * reg;
-      zst[(q / UPS) & 1][bc * ZS + (tcol & (ZW - 1))] = s;
-    }
-    ur = urn;
+    ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn;
+#ifdef DAV_SYMW_STAMPS
+    unsigned long long t4;
+    STAMP(t4);
+    if (q > 0) { st_hs += t1 - t0; st_bar += t2 - t1; st_sum += t3 - t2; }
+    st_unit += t4 - t0;
+#endif
   };
-  // nunits is a multiple of 16: two units per trip, the B operand sets alternate (no register copies)
+  // nunits is a multiple of 16: two units per trip, the X_J operand sets alternate
   for (unsigned q = 0; q < nunits; q += 2) {
-    unit(q, b0, b1);
-    unit(q + 1, b1, b0);
+    unit(q, std::integral_constant<int, 0>{});
+    unit(q + 1, std::integral_constant<int, 1>{});
   }
+  // every load of the loop has landed before anything else (the compiler does not know about them)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the last unit's sum, then the last strip
+  __syncthreads();
+  sum_issue(nunits - 1);
+  sum_finish(nunits - 1);
   __syncthreads();
   flush_strip(nunits / UPS - 1);
+#ifdef DAV_SYMW_STAMPS
+  if (lane == 0) {
+    unsigned long long tk1, tr1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk1), "=s"(tr1) :: "memory");
+    atomicAdd(&symw_stamp[0], st_hs); atomicAdd(&symw_stamp[1], st_bar); atomicAdd(&symw_stamp[2], st_sum);
+    atomicAdd(&symw_stamp[3], (unsigned long long)nunits);
+    atomicAdd(&symw_stamp[4], tk1 - tk0); atomicAdd(&symw_stamp[5], tr1 - tr0); atomicAdd(&symw_stamp[6], st_vm);
+    atomicAdd(&symw_stamp[10], st_unit); atomicAdd(&symw_stamp[11], 1ull);
+    atomicAdd(&symw_stamp[7], st_f[0]); atomicAdd(&symw_stamp[8], st_f[1]); atomicAdd(&symw_stamp[9], st_f[2]);
+  }
+#endif
 
   // end of the run: the direct partials of every row slice (complete: one column group per workgroup), one 32-row
   // half-step and one group at a time through the transposition scratch so that they leave as 256-byte rows
@@ -284,8 +442,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     const int kc = kcols - 16 * bcb < 16 ? kcols - 16 * bcb : 16;
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs) {
-      if (hs < ACC_A) asm volatile(MFMA_DRAIN : "+a"(acc[hs][0][bcb]), "+a"(acc[hs][1][bcb]));
-      else asm volatile(MFMA_DRAIN : "+v"(acc[hs][0][bcb]), "+v"(acc[hs][1][bcb]));
+      asm volatile(MFMA_DRAIN : "+v"(acc[hs][0][bcb]), "+v"(acc[hs][1][bcb]));
 #pragma unroll
       for (int par = 0; par < 2; ++par)
 #pragma unroll
@@ -302,6 +459,8 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     }
   }
   // block rows of the super row past the end of the matrix: their slab rows are read by nobody
+  // the fixed registers belong to this kernel: the descriptor must allocate all 256 accumulation registers
+  asm volatile("" ::: "a160", "a255");
 }
 
 void launch_matvec_symw(hipStream_t st, int nbw, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,

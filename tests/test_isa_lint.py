@@ -1,0 +1,139 @@
+"""ISA lint of the hand-scheduled symmetric sweep (fortran_davidson_amd/csrc/k_matvec_symw.hip), no GPU needed.
+
+The kernel's MFMAs are inline assembly (the compiler does not know them as such, so it neither pads their hazards nor keeps
+out of the accumulation registers the kernel names literally).  The kernel header states the rules that make that safe; this
+test checks the EMITTED code for them:
+  1. no compiler-generated instruction (outside ;;#ASMSTART / ;;#ASMEND) names the kernel's fixed registers (a[160:255] with 32
+     columns per workgroup, a[96:255] with 16);
+  2. no VALU instruction writes a register that an MFMA reads within the next two instructions (2 wait states);
+  3. a register written by an MFMA is read by a non-MFMA instruction only after an `s_nop 15` (+ `s_nop 3`): 18+ wait states;
+  4. no register moves between the halves (v_accvgpr_*) and no scratch in the kernel at all.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "fortran_davidson_amd", "csrc", "k_matvec_symw.hip")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FIXED_LO = {1: 96, 2: 160}   # first fixed accumulation register by columns / 16 per workgroup (symw_fixed_lo in the kernel file)
+
+
+def _regs(tok):
+    """('v' | 'a', set of register numbers) named by an operand token such as v[10:13], a7, v3"""
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    if m:
+        return m.group(1), {int(m.group(2))}
+    return None, set()
+
+
+def _operands(line):
+    body = line.split(";")[0].strip()
+    parts = body.split(None, 1)
+    if len(parts) < 2:
+        return parts[0] if parts else "", []
+    return parts[0], [t.strip() for t in parts[1].replace(" offen", "").replace(" offset:", ",offset:").split(",")]
+
+
+def _kernels(asm):
+    out, cur, name = {}, None, None
+    for ln in asm.splitlines():
+        m = re.match(r"^(_Z\d+matvec_symw_kernel\w+):", ln)
+        if m:
+            name, cur = m.group(1), []
+            continue
+        if cur is not None:
+            cur.append(ln)
+            if "s_endpgm" in ln:
+                out[name] = cur
+                cur = None
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    out = tmp_path_factory.mktemp("isa") / "symw.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                    "-o", str(out), SRC], check=True, capture_output=True, timeout=300)
+    ks = _kernels(out.read_text())
+    assert len(ks) == 2, list(ks)
+    return ks
+
+
+def test_resources(kernels):
+    for name, lines in kernels.items():
+        text = "\n".join(lines)
+        assert "v_accvgpr" not in text, name
+        assert "scratch_" not in text, name
+
+
+def test_compiler_code_stays_out_of_the_fixed_registers(kernels):
+    for name, lines in kernels.items():
+        lo = FIXED_LO[int(re.search(r"kernelILi(\d)E", name).group(1))]
+        in_asm = False
+        for ln in lines:
+            if "#ASMSTART" in ln:
+                in_asm = True
+                continue
+            if "#ASMEND" in ln:
+                in_asm = False
+                continue
+            if in_asm or ln.strip().startswith((";", ".")):
+                continue
+            _, ops = _operands(ln)
+            for t in ops:
+                f, r = _regs(t)
+                assert not (f == "a" and r and max(r) >= lo), (name, ln)
+
+
+def test_mfma_hazards(kernels):
+    for name, lines in kernels.items():
+        code = [ln for ln in lines if ln.strip() and not ln.strip().startswith((";", ".")) and not ln.rstrip().endswith(":")]
+        recent = []                      # (is_valu, file, regs written) of the last instructions
+        mfma_written = {"v": {}, "a": {}}   # register -> index of the MFMA that wrote it, until drained
+        n_mfma = 0
+        for idx, ln in enumerate(code):
+            op, ops = _operands(ln)
+            if not op:
+                continue
+            if op.startswith("v_mfma"):
+                n_mfma += 1
+                dfile, dregs = _regs(ops[0])
+                reads = [_regs(t) for t in ops[1:]]
+                for wfile_w, wregs in [(f, r) for (isv, f, r) in recent[-2:] if isv]:
+                    for rf, rr in reads:
+                        assert not (rf == wfile_w and rr & wregs), (name, "VALU write -> MFMA read", ln)
+                # a chain (D = C) is forwarded by the hardware; anything else reading a pending result is checked below
+                for r in dregs:
+                    mfma_written[dfile][r] = idx
+                recent.append((False, dfile, dregs))
+                continue
+            if op == "s_nop":
+                if ops and ops[0] == "15":
+                    mfma_written = {"v": {}, "a": {}}
+                recent.append((False, None, set()))
+                continue
+            # non-MFMA instruction: must not read a register with an undrained MFMA result
+            is_store = op.startswith(("ds_write", "global_store", "buffer_store"))
+            srcs = ops if is_store else ops[1:]
+            for t in srcs:
+                f, r = _regs(t)
+                if f:
+                    pend = r & set(mfma_written[f])
+                    assert not pend, (name, "MFMA result read without drain", ln)
+            is_valu = op.startswith("v_") and not op.startswith("v_mfma")
+            dfile, dregs = _regs(ops[0]) if ops and not is_store else (None, set())
+            # a non-MFMA write of a register (load, VALU) ends its "pending MFMA result" state
+            if dfile:
+                for r in dregs:
+                    mfma_written[dfile].pop(r, None)
+            recent.append((is_valu, dfile, dregs))
+        assert n_mfma in (128, 256), (name, n_mfma)
