@@ -19,6 +19,8 @@ Objects in the JSON line besides the contract's fields:
   roofline_hbm   the north-star measurement: A*V at N=200000, k=8 on the same resident matrix, END TO END
                  (operand packing + sweep kernel + fixed-order reduction) and the sweep kernel alone
   apply          the same for k = 8, 16, 32
+  hbm_measured   device copy / triad rate of this box (what 8 TB/s amount to in practice); HBM fractions are quoted against both
+  configs2_restart  configs[2] with a denser coupling: the solve goes through collapse restarts at full size
   configs3_gjd   BASELINE configs[3]: N=200000 generalized (A, B), GJD correction, lowest=8
   configs4_free  BASELINE configs[4]: matrix-free hashed diagonal-dominant operator, lowest=8, DPR
   small          BASELINE configs[1]: N=20000 dense, lowest=8, DPR (full storage)
@@ -56,6 +58,7 @@ def parse():
     ap.add_argument("--sparsity", type=float, default=1e-3)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--storage", default="auto", help="auto = symmetric tiles (one GPU, or dealt out over the ranks); full = full row slabs")
+    ap.add_argument("--restart-sparsity", type=float, default=2e-2, help="coupling of the restart-forcing configs[2] leg (0 = skip)")
     ap.add_argument("--small-n", type=int, default=20000, help="order of the configs[1] leg (0 = skip)")
     ap.add_argument("--gjd-n", type=int, default=-1, help="order of the configs[3] leg (-1 = same as --order, 0 = skip)")
     ap.add_argument("--free-n", type=int, default=1000000, help="order of the configs[4] leg (0 = skip)")
@@ -87,6 +90,23 @@ if ref.available():
     # the second solve is the one reported: the first carries MKL's one-time initialisation (threads, code paths)
     t = time.perf_counter(); lam, vec, it = ref.dense_solve(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
     out.update(kind="reference", iters=int(it), seconds=dt, seconds_first_call=dt0, cores=threads, evals=[float(x) for x in lam])
+    # the primitive behind the reference's residual loop (lapack_matrix_vector -> DGEMV, src/lapack_wrapper.f90:330-364,
+    # called m times per iteration at src/davidson.f90:163-170): one sweep of A through MKL, all threads
+    try:
+        mkl = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so")
+        n = int(A.shape[0])
+        x = np.ones(n); y = np.zeros(n)
+        dp = ctypes.POINTER(ctypes.c_double)
+        def sweep():
+            mkl.cblas_dgemv(102, 111, n, n, ctypes.c_double(1.0), A.ctypes.data_as(dp), n, x.ctypes.data_as(dp), 1, ctypes.c_double(0.0),
+                            y.ctypes.data_as(dp), 1)
+        sweep()
+        t = time.perf_counter()
+        for _ in range(5):
+            sweep()
+        out["dgemv_sweep_GBps"] = 8.0 * n * n * 5 / (time.perf_counter() - t) / 1e9
+    except Exception as exc:
+        out["dgemv_sweep_error"] = repr(exc)[:200]
 else:
     t = time.perf_counter(); lam, vec, it = O.generalized_eigensolver_dense(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
     out.update(kind="port", iters=int(it), seconds=dt, cores=os.cpu_count(), evals=[float(x) for x in lam])
@@ -118,7 +138,7 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
     (counters cannot be read from inside the run): collected with `rocprofv3 --pmc` on this command at the commit the
     file names (profiles/summarize.py).  `kernel` = name prefix; launches of one kernel are grouped by grid size
     (column groups per launch) - rank_by_grid 0 = largest grid.  None when no summary matches the workload."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_n{n}_{storage}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_n{n}_{storage}.json")
     try:
         with open(path) as f:
             doc = json.load(f)
@@ -132,8 +152,26 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
         return None, None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run ... bench.py ...` as a CHILD process,
+    let rank 0's JSON line through and return the child's exit code.  This (parent) process never imports torch and never
+    touches the GPU - a process that has initialised the GPU must not be replaced by another program, and it is not."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    fwd = ["--order" if a == "--n" else ("--order=" + a[4:] if a.startswith("--n=") else a) for a in sys.argv[1:]]   # the launcher's parser rejects --n
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + fwd
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -142,8 +180,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU "
+                         "(python bench.py --gpus N starts torch.distributed.run by itself)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -223,9 +261,43 @@ def main():
                             "GBps_kernel_only": round(nbytes / (kms * 1e-3) / 1e9, 1),
                             "frac_of_8TBps_end_to_end": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                             "frac_of_8TBps_kernel_only": round(nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "frac_of_measured_stream_end_to_end": round(nbytes / (ms * 1e-3) / 1e9 / stream_gbps, 4) if stream_gbps > 0 else None,
                             "TFLOPs_kernel_only": round(flops / (kms * 1e-3) / 1e12, 2),
                             "algorithmic_bytes": nbytes}
         return out
+
+    def measured_stream():
+        """Achievable HBM rate on THIS box: device-to-device copy and a triad a = b + s*c of 2 GiB arrays (torch kernels, HIP events),
+        read + written bytes per second - what the 8 TB/s of the data sheet amount to in practice."""
+        try:
+            nel = 1 << 28                                  # 2 GiB of float64 per array
+            a = torch.empty(nel, dtype=torch.float64, device="cuda")
+            b = torch.ones(nel, dtype=torch.float64, device="cuda")
+            c = torch.ones(nel, dtype=torch.float64, device="cuda")
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            for _ in range(2):
+                a.copy_(b); torch.add(b, c, alpha=0.5, out=a)
+            torch.cuda.synchronize()
+            reps = 5
+            ev[0].record()
+            for _ in range(reps):
+                a.copy_(b)
+            ev[1].record(); ev[2].record()
+            for _ in range(reps):
+                torch.add(b, c, alpha=0.5, out=a)
+            ev[3].record()
+            torch.cuda.synchronize()
+            copy = 2 * 8.0 * nel * reps / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+            triad = 3 * 8.0 * nel * reps / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e9
+            del a, b, c
+            torch.cuda.empty_cache()
+            return {"copy_GBps": round(copy, 1), "triad_GBps": round(triad, 1), "bytes_per_array": 8 * nel,
+                    "note": "torch copy_ / add(alpha) on 2 GiB float64 arrays, read + written bytes, HIP events, this run"}
+        except Exception as exc:       # noqa: BLE001
+            return {"error": repr(exc)[:200]}
+
+    hbm_measured = measured_stream() if rank == 0 or world > 1 else None
+    stream_gbps = max(hbm_measured.get("copy_GBps", 0.0), hbm_measured.get("triad_GBps", 0.0)) if hbm_measured else 0.0
 
     storage = args.storage if args.storage != "auto" else "symmetric"
     storage_words = {"symmetric": "symmetric-tiled (lower block triangle, N(N+1)/2 entries" +
@@ -252,10 +324,11 @@ def main():
     kms = st.apply_kernel_ms / launches
     tflops = st.apply_flops / (st.apply_kernel_ms * 1e-3) / 1e12 if st.apply_kernel_ms > 0 else 0.0
     cols_per_launch = st.apply_cols / launches
-    kernel_name = "matvec_sym9_kernel<R, false> (K1s: symmetric-tiled sweep, R block rows per workgroup: 2 in the solve, 4 at k <= 8)" if storage == "symmetric" else "matvec_dense_kernel<NT> (K1: row slab)"
+    kernel_name = ("matvec_symw_kernel<NB> (K1s: symmetric-tiled sweep, one wave per SIMD, 16 NB columns per workgroup: 2 block rows, NB = 2 "
+                   "in the solve) / matvec_sym9_kernel<4> (4 block rows, 4x4x4 MFMA) at k <= 8") if storage == "symmetric" else "matvec_dense_kernel<NT> (K1: row slab)"
     hbm_in_solve = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
     mfma_bound = cols_per_launch > 16
-    tr_solve = pmc_traffic(n, storage, "matvec_sym9_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", 0) if world == 1 else (None, None)
+    tr_solve = pmc_traffic(n, storage, "matvec_symw_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", 0) if world == 1 else (None, None)
     tr_k8 = pmc_traffic(n, storage, "matvec_sym9_kernel<4", 0) if (world == 1 and storage == "symmetric") else (None, None)
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kernel_name,
                 "achieved": round(tflops, 2) if mfma_bound else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9, 1),
@@ -279,6 +352,7 @@ def main():
     roofline_hbm = {"bound": "hbm", "kernel": kernel_name, "N": n, "k": 8,
                     "achieved": a8["GBps_end_to_end"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a8["frac_of_8TBps_end_to_end"],
                     "achieved_kernel_only": a8["GBps_kernel_only"], "frac_kernel_only": a8["frac_of_8TBps_kernel_only"],
+                    "frac_of_measured_stream": a8["frac_of_measured_stream_end_to_end"], "measured_stream_GBps": stream_gbps or None,
                     "ms_end_to_end": a8["ms_end_to_end"], "ms_kernel_only": a8["ms_kernel_only"],
                     "algorithmic_bytes_per_launch": a8["algorithmic_bytes"],
                     "traffic": tr_k8[0], "traffic_source": tr_k8[1],
@@ -296,6 +370,32 @@ def main():
                                    "ms_per_solve": round(dt_pol / 2 * 1e3, 3), "iters_per_solve": it_pol // 2,
                                    "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_pol - lam).max())}
     eng.close()
+
+    if not args.headline_only and args.restart_sparsity > 0:
+        # ---- configs[2], restart-forcing variant: a denser coupling so that the basis passes max_dim_sub before the pairs
+        # converge and the solve goes through collapse restarts (src/davidson.f90:215-220) at full size ----------------------
+        try:
+            r = make_engine(n, lowest, max_dim, storage)
+            r.generate_diagonal_dominant(1, args.restart_sparsity, seed=3)
+            r.solve("DPR", 1000, args.tol, want_vectors=False)
+            r.c.synchronize(); r.c.reset_stats()
+            dt_r, it_r, lam_r = timed_solves(r, "DPR", 1, args.tol)
+            sr = r.c.stats()
+            extras["configs2_restart"] = {
+                "workload": f"N={n} dense fp64, lowest={lowest}, DPR, max_dim_sub={max_dim}, tol={args.tol}, "
+                            f"generate_diagonal_dominant(N,{args.restart_sparsity}) seed 3, storage: {storage}, {world} GPU(s)",
+                "iters": it_r, "restarts": int(sr.restarts), "seconds": round(dt_r, 4), "iterations_per_s": round(it_r / dt_r, 3),
+                "sweeps_of_A": int(sr.applies), "columns_swept": int(sr.apply_cols),
+                "columns_swept_per_restart_cycle": round(sr.apply_cols / (int(sr.restarts) + 1), 1),
+                "ms_in_sweeps_end_to_end": round(sr.apply_ms, 2), "ms_in_panel_products_incl_restart": round(sr.panel_ms, 2),
+                "ms_in_gram": round(sr.gram_ms, 2),
+                "TFLOPs_in_sweep_kernels": round(sr.apply_flops / (sr.apply_kernel_ms * 1e-3) / 1e12, 2) if sr.apply_kernel_ms > 0 else None,
+                "eigenvalues": [float(x) for x in lam_r[:3]],
+                "note": "a restart contracts V, W = A*V (and B*V) with the kept Ritz vectors: no sweep of A follows it "
+                        "(2 lowest + 4 lowest columns per cycle at restart width 80 = 96 at lowest=16; the reference re-applies A to the whole basis every iteration)"}
+            r.close()
+        except Exception as exc:       # noqa: BLE001
+            extras["configs2_restart"] = {"error": repr(exc)[:300]}
 
     if not args.headline_only:
         # ---- configs[3]: generalized (A, B), GJD correction, lowest=8 ---------------------------------------
@@ -480,6 +580,27 @@ def main():
                                   "by the reference built with flang+MKL (oracle/_ref), all host threads",
                         "max_abs_eigenvalue_diff_vs_gpu": float(np.abs(np.array(raw["evals"][:3]) - np.array(extras["small"]["eigenvalues"])).max())
                         if cn == args.small_n and "eigenvalues" in extras.get("small", {}) else None}
+                    # sweeps of A the reference makes and what they cost on these host cores; the timed N=200000
+                    # problem stated as (m+1) sweeps per iteration x 8 N^2 bytes / the measured CPU rate
+                    widths = [2 * 8 * 2 ** i for i in range(raw["iters"])]
+                    sweeps = sum(m + 1 for m in widths)
+                    cb = extras["cpu_baseline"]
+                    cb["sweeps_of_A_in_the_sample"] = {"basis_widths": widths, "sweeps": sweeps, "GB_swept": round(sweeps * 8.0 * cn * cn / 1e9, 1),
+                                                       "GBps_if_all_time_were_sweeps": round(sweeps * 8.0 * cn * cn / raw["seconds"] / 1e9, 1)}
+                    if "dgemv_sweep_GBps" in raw:
+                        bw = raw["dgemv_sweep_GBps"]
+                        w2 = [2 * lowest * 2 ** i for i in range(total_iters // args.steps)]
+                        s2 = sum(m + 1 for m in w2)
+                        est = s2 * 8.0 * float(n) * float(n) / (bw * 1e9)
+                        cb["dgemv_sweep_GBps"] = round(bw, 1)
+                        cb["extrapolation_to_timed_workload"] = {
+                            "N": n, "lowest": lowest, "basis_widths": w2, "sweeps_of_A": s2, "bytes_per_sweep": 8.0 * float(n) * float(n),
+                            "seconds_per_solve_at_measured_dgemv_rate": round(est, 1),
+                            "iterations_per_s": round((total_iters // args.steps) / est, 5),
+                            "gpu_speedup_vs_extrapolation": round(est / (elapsed / args.steps), 1),
+                            "assumption": "the reference's (m+1) sweeps of A per iteration (m DGEMVs for the residues + 1 DGEMM, src/davidson.f90:163-170,223) "
+                                          "at the DGEMV rate measured above on these cores, full storage (320 GB - would have to fit host memory); "
+                                          "QR and the small eigenproblem not counted"}
                 else:
                     extras["cpu_baseline"] = raw
 
@@ -494,7 +615,7 @@ def main():
                            "iters_per_solve": total_iters // args.steps, "parallelism": (f"block rows of the lower triangle over {world} GPUs, row slabs of the panels" if storage == "symmetric" else f"row-slab x{world}") if world > 1 else "single GPU",
                            "generate_seconds": round(t_gen, 2)},
                 "eigenvalues": [float(x) for x in lam[:3]],
-                "roofline": roofline, "roofline_hbm": roofline_hbm, "apply": apply_k}
+                "roofline": roofline, "roofline_hbm": roofline_hbm, "apply": apply_k, "hbm_measured": hbm_measured}
         line.update(extras)
         if "cpu_baseline" not in line:
             line["cpu_baseline"] = None

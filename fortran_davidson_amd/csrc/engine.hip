@@ -1884,12 +1884,34 @@ extern "C" int dav_panel_transform(dav_handle_t e, int src_panel, int s0, int p,
   return 0;
 }
 
+// V, W = A V and B V are contracted with the same keep columns (src/davidson.f90:218 contracts V and then re-applies the
+// operators to the whole basis, :223-226; W Y = A (V Y) holds to rounding, so no sweep of A or B follows a restart)
+static int restart_contract(E* e, int m, int keep, const double* Mdev, int64_t ldm) {
+  int slot;
+  CHK(timed_begin(e, 2, 0, &slot));
+  const int panels[3] = {DAV_PANEL_V, DAV_PANEL_W, DAV_PANEL_BV};
+  for (int i = 0; i < (e->gev ? 3 : 2); ++i) {
+    PanelGemmArgs a{};
+    a.P1 = panel_ptr(e, panels[i], 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = Mdev; a.ldm1 = ldm;
+    a.p2 = 0;
+    a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = keep; a.ldo = e->ldp;
+    a.out = panel_ptr(e, DAV_PANEL_S, 0);
+    launch_panel_gemm(e->stream, a);
+    launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, panels[i], 0), e->ldp, e->nloc_pad, keep);
+  }
+  CHK(timed_end(e, slot));
+  e->m = keep;
+  e->st.restarts += 1;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dav_restart(dav_handle_t e, int m, int keep, const double* Yk, int64_t ldy) {
   CHK(bind(e));
-  if (keep <= 0 || keep > m) return fail("dav_restart: bad shape");
-  CHK(dav_panel_transform(e, DAV_PANEL_V, 0, m, Yk, ldy, keep, DAV_PANEL_V, 0));
-  e->m = keep;
-  return 0;
+  if (keep <= 0 || keep > m || m > e->cols_alloc || ldy < m) return fail("dav_restart: bad shape");
+  int64_t ld_m;
+  CHK(small_upload(e, 3, Yk, ldy, m, keep, &ld_m));
+  return restart_contract(e, m, keep, e->sm[3].dev, ld_m);
 }
 
 // Several ranks: every rank takes the driver's control decisions (converged? grow or restart? how many columns?) from
@@ -1981,16 +2003,7 @@ extern "C" int dav_rr_restart(dav_handle_t e, int m, int keep) {
   if (!e->rr_on || keep <= 0 || keep > m || m > e->rr_ld) return fail("dav_rr_restart: bad shape");
   launch_rr_pack(e->stream, e->rr_Y, e->rr_ld, e->rr_theta, m, keep, (int)roundup(m, 4), (int)roundup(keep, 64), e->rr_Ypk, e->rr_Y2pk,
                  e->rr_thpk, e->rr_info, nullptr);
-  PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = e->rr_Ypk; a.ldm1 = roundup(m, 4);
-  a.p2 = 0;
-  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = keep; a.ldo = e->ldp;
-  a.out = panel_ptr(e, DAV_PANEL_S, 0);
-  launch_panel_gemm(e->stream, a);
-  launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, e->nloc_pad, keep);
-  e->m = keep;
-  HIPCHK(hipGetLastError());
-  return 0;
+  return restart_contract(e, m, keep, e->rr_Ypk, roundup(m, 4));
 }
 
 // the device-resident eigenvectors (m x ncols) and Ritz values, for tests and for callers that want them on the host

@@ -23,7 +23,7 @@ class Stats(C.Structure):
                 ("apply_ms", C.c_double), ("apply_bytes", C.c_double), ("last_apply_ms", C.c_double),
                 ("last_apply_bytes", C.c_double), ("gram_ms", C.c_double), ("panel_ms", C.c_double),
                 ("comm_ms", C.c_double), ("apply_kernel_ms", C.c_double), ("apply_flops", C.c_double),
-                ("apply_launches", C.c_int64)]
+                ("apply_launches", C.c_int64), ("restarts", C.c_int64)]
 
 
 def _dp(a):

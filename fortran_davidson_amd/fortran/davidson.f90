@@ -625,20 +625,23 @@ contains
           call lap(6)
           m = m + kt
        else
-          ! collapse restart: V <- V*Y(:, 1:2L)   (src/davidson.f90:218)
+          ! collapse restart: V <- V*Y(:, 1:2L) (src/davidson.f90:218).  The reference then re-applies A (and B) to the
+          ! whole basis (:223-226); here W = A*V and B*V are contracted with the same columns instead - W*Y = A*(V*Y)
+          ! to rounding - so a restart costs three panel products and no sweep of the operators.
           kt = initial_dimension
-          if (drr) then
+          if (drr .and. .not. gev) then
              call check_dav(dav_rr_restart(h, int(m, c_int), int(kt, c_int)), "dav_rr_restart")
           else
+             if (drr) call check_dav(dav_rr_get(h, int(m, c_int), int(m, c_int), theta, y, int(m, c_int64_t)), "dav_rr_get")
+             if (gev) then
+                ! Y is S-orthonormal in the generalized case: V*Y(:, 1:kt) has the Gram matrix G = Y^T Y (V itself is
+                ! Euclidean-orthonormal), so Y*M with M^T G M = I makes the restarted basis orthonormal again - what the
+                ! reference gets from its next QR of the whole basis - and carries W and B*V along
+                call restart_transform(y(1:m, 1:kt), m, kt)
+             end if
              call check_dav(dav_restart(h, int(m, c_int), int(kt, c_int), y, int(m, c_int64_t)), "dav_restart")
           end if
-          ! Y is S-orthonormal in the generalized case: make V Euclidean-orthonormal again (the
-          ! reference gets this from its next QR of the whole basis)
-          if (gev) call block_orthonormalise(h, n, 0, kt)
           call lap(7)
-          call check_dav(dav_expand(h, 0_c_int, int(kt, c_int)), "dav_expand")
-          if (host_ops) call apply_host_block(h, n, 0, kt, fun_a, fun_b)
-          call lap(5)
           hm = 0.0_dp
           sm = 0.0_dp
           if (drr) then
@@ -850,6 +853,56 @@ contains
        print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
     end if
   end subroutine block_orthonormalise
+
+  !> yk (m x kt) <- yk * M with M = G^(-1/2)-like (Cholesky R^-1, or the eigen-decomposition route with an eigenvalue
+  !> floor when the factor is ill-conditioned), G = yk^T yk: the columns of the result are Euclidean-orthonormal.
+  subroutine restart_transform(yk, m, kt)
+    integer, intent(in) :: m, kt
+    real(dp), intent(inout) :: yk(m, kt)
+    real(dp), allocatable :: g(:, :), u(:, :), w(:), mm(:, :), d(:)
+    integer :: j, l, info, pass
+    real(dp) :: wmin, wmax
+    allocate(g(kt, kt), u(kt, kt), w(kt), mm(kt, kt), d(kt))
+    do pass = 1, 2                      ! the second pass sees G = I + O(eps cond): it removes what the first left
+       g = lapack_matmul("T", "N", yk, yk)
+       do j = 1, kt
+          d(j) = 1.0_dp / sqrt(g(j, j))
+       end do
+       do j = 1, kt
+          do l = 1, kt
+             g(l, j) = g(l, j) * d(l) * d(j)
+          end do
+       end do
+       call lapack_cholesky_inverse(g, u, info)
+       wmin = huge(1.0_dp)
+       wmax = 0.0_dp
+       if (info == 0) then
+          do j = 1, kt
+             wmin = min(wmin, abs(u(j, j)))
+             wmax = max(wmax, abs(u(j, j)))
+          end do
+       end if
+       if (info == 0 .and. wmax < 1.0e4_dp * wmin) then
+          do j = 1, kt
+             do l = 1, kt
+                mm(l, j) = d(l) * u(l, j)
+             end do
+          end do
+       else
+          call lapack_rayleigh_ritz(g, w, u, kt)
+          wmax = maxval(w)
+          do j = 1, kt
+             w(j) = max(w(j), 1.0e-14_dp * wmax)
+          end do
+          do j = 1, kt
+             do l = 1, kt
+                mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
+             end do
+          end do
+       end if
+       yk = lapack_matmul("N", "N", yk, mm)
+    end do
+  end subroutine restart_transform
 
   !> Deterministic filler direction (xorshift), entries in (-0.5, 0.5).
   subroutine pseudo_random_vector(vec, salt)

@@ -17,6 +17,7 @@ module davidson_hip_c
      real(c_double) :: apply_ms, apply_bytes, last_apply_ms, last_apply_bytes, gram_ms, panel_ms, comm_ms
      real(c_double) :: apply_kernel_ms, apply_flops
      integer(c_int64_t) :: apply_launches
+     integer(c_int64_t) :: restarts
   end type dav_stats
 
   interface
@@ -299,6 +300,14 @@ module davidson_hip_c
        import :: c_ptr, c_int
        type(c_ptr), value :: h
        integer(c_int), value :: m, keep
+       integer(c_int) :: ierr
+     end function
+     function dav_rr_get(h, m, ncols, theta, y, ldy) bind(C, name="dav_rr_get") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, ncols
+       integer(c_int64_t), value :: ldy
+       real(c_double), intent(out) :: theta(*), y(ldy, *)
        integer(c_int) :: ierr
      end function
      function dav_restart(h, m, keep, yk, ldy) bind(C, name="dav_restart") result(ierr)

@@ -63,6 +63,7 @@ typedef struct dav_stats {
                            /* is used twice)                                                         */
   int64_t apply_launches;  /* launches of the block-matvec kernel (an apply of > 32 / 64 columns is  */
                            /* several launches)                                                      */
+  int64_t restarts;        /* collapse restarts (dav_restart / dav_rr_restart) so far                */
 } dav_stats;
 
 const char* dav_last_error(void);
@@ -207,8 +208,11 @@ int dav_ortho_apply(dav_handle_t h, int m, int kt, const double* C, int64_t ldc,
 /* Commit T as basis columns m..m+kt-1 and apply the operators to them (device operators only):
  * W[:, m:m+kt] = A*T (one block sweep of A - the only one per iteration), BV likewise. */
 int dav_expand(dav_handle_t h, int m, int kt);
-/* K5 - replaces V = V * Y(:, 1:keep) (src/davidson.f90:218): V, W and B*V are contracted with the
- * same keep columns of Yk (m x keep); sets m = keep. */
+/* K5 - replaces V = V * Y(:, 1:keep) (src/davidson.f90:218) AND the re-application of the operators to the whole
+ * basis that follows it in the reference (:223-226): V, W = A*V and (generalized problems) B*V are all contracted
+ * with the same keep columns of Yk (m x keep), W*Yk = A*(V*Yk) to rounding, so no sweep of A or B follows a
+ * restart; sets m = keep.  Generalized problems: pass Yk already multiplied by the k x k transform that makes V*Yk
+ * Euclidean-orthonormal (Yk^T Yk = I), as the Fortran driver does, so that all three panels carry it. */
 int dav_restart(dav_handle_t h, int m, int keep, const double* Yk, int64_t ldy);
 /* Several ranks: returns an error if the ranks do not all pass the same `words` (the driver's control decisions of this
  * iteration) - one small all-reduce; a no-op on a single rank.  Lets a diverged rank end with a message instead of
@@ -235,7 +239,8 @@ int dav_rr_enable(dav_handle_t h, int on);
 int dav_project_dev(dav_handle_t h, int c0, int k);
 int dav_rr_ritz(dav_handle_t h, int m, int ncorr, int lowest, int method, double* theta_out, double* resnorm, double* C,
                 int64_t ldc, double* G, int64_t ldg, int* sweeps_out);
-/* collapse restart with the device-resident eigenvectors: V = V * Y(:, 1:keep) (src/davidson.f90:218) */
+/* collapse restart with the device-resident eigenvectors (standard problems): V, W <- V, W * Y(:, 1:keep)
+ * (src/davidson.f90:218, :223) */
 int dav_rr_restart(dav_handle_t h, int m, int keep);
 /* the device-resident Ritz values / eigenvectors (m x ncols) on the host (either pointer may be NULL) */
 int dav_rr_get(dav_handle_t h, int m, int ncols, double* theta, double* Y, int64_t ldy);

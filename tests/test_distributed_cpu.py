@@ -112,3 +112,22 @@ def test_bench_launch_plumbing_world_size_2():
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["control_plane"] == "ok" and out["world"] == 2 and out["rows_rank0"] == [0, 100000]     # default order 200000 (configs[2]) over 2 ranks
+
+
+def test_bench_starts_its_own_launcher_for_several_gpus():
+    """`python bench.py --gpus 2` WITHOUT an outer launcher: the parent starts torch.distributed.run as a child process
+    (it never touches a GPU itself), rank 0's JSON line comes through and the exit code is the child's; --n is
+    forwarded as --order (the launcher's parser rejects --n)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--control-plane-only", "--n", "1000"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["control_plane"] == "ok" and out["world"] == 2 and out["rows_rank0"] == [0, 512]
+    # a failing child propagates its exit code
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--control-plane-only", "--no-such-flag"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert bad.returncode != 0

@@ -206,7 +206,35 @@ def test_init_basis_expand_project_restart():
         assert np.allclose(e.panel_get(PANEL_W, 0, 16), A @ V, atol=1e-12)
         Y = np.linalg.qr(np.random.default_rng(2).standard_normal((16, 16)))[0]
         e.restart(16, 8, Y)
-        assert np.allclose(e.panel_get(PANEL_V, 0, 8), V @ Y[:, :8], atol=1e-13)
+        Vn = e.panel_get(PANEL_V, 0, 8)
+        assert np.allclose(Vn, V @ Y[:, :8], atol=1e-13)
+        # W = A V is contracted with the same columns: no sweep of A follows a restart (src/davidson.f90:218, :223)
+        assert np.allclose(e.panel_get(PANEL_W, 0, 8), A @ Vn, atol=1e-11)
+        st = e.stats()
+        assert st.restarts == 1 and st.m == 8 and st.applies == 1       # the one block sweep of the expansion above
+        e.project(0, 8, H)
+        assert np.allclose(H[:8, :8], Vn.T @ A @ Vn, atol=1e-11)
+
+
+def test_restart_contracts_the_second_operator_panel_too():
+    """Generalized problem: V, W = A V and B V all carry the restart transform (the Fortran driver passes the kept Ritz
+    vectors times the k x k matrix that makes V Y Euclidean-orthonormal)."""
+    n = 400
+    A = O.generate_diagonal_dominant(n, 1e-2, seed=6)
+    B = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=7)
+    rng = np.random.default_rng(3)
+    V = np.linalg.qr(rng.standard_normal((n, 12)))[0]
+    with fd.CEngine(n=n, max_cols=32, gev=True) as e:
+        e.set_dense_host(OP_A, A)
+        e.set_dense_host(OP_B, B)
+        e.panel_put(PANEL_V, 0, V)
+        e.expand(0, 12)
+        M = rng.standard_normal((12, 6))
+        e.restart(12, 6, M)
+        Vn = e.panel_get(PANEL_V, 0, 6)
+        assert np.allclose(Vn, V @ M, atol=1e-12)
+        assert np.allclose(e.panel_get(PANEL_W, 0, 6), A @ Vn, atol=1e-10)
+        assert np.allclose(e.panel_get(PANEL_BV, 0, 6), B @ Vn, atol=1e-11)
 
 
 def test_row_partition_matches_engine():
@@ -275,13 +303,16 @@ def test_dense_matrix_from_device_memory(storage):
 
 
 @pytest.mark.parametrize("env", [{"DAV_SYM_V8": "0"}, {"DAV_SYM_PAIR": "0"}, {"DAV_SYM_RUN": "1"}, {"DAV_SYM_RUN": "7"},
-                                 {"DAV_SYM_R": "2"}, {"DAV_SYM_R": "4"}, {"DAV_SYM_R": "4", "DAV_SYM_RUN9": "1"},
+                                 {"DAV_SYM_R": "2"}, {"DAV_SYM_R": "2", "DAV_SYM_WIDE": "0"}, {"DAV_SYM_R": "2", "DAV_SYM_WIDE": "1"},
+                                 {"DAV_SYM_R": "2", "DAV_SYM_WIDE": "2", "DAV_SYM_RUN9": "1"}, {"DAV_SYM_R": "4"}, {"DAV_SYM_R": "4", "DAV_SYM_RUN9": "1"},
                                  {"DAV_SYM_R": "2", "DAV_SYM_RUN9": "3"}, {"DAV_SYM_R": "2", "DAV_SYM_PAIR": "0"},
                                  {"DAV_SYM_R": "2", "DAV_SYM_QUAD": "0"}, {"DAV_SYM_R": "4", "DAV_SYM_MFMA4": "0"}])
 def test_symmetric_sweep_alternative_kernels_and_schedules(env):
     """The A/B knobs of the symmetric sweep (one-wave-per-SIMD kernel, unpaired 16-column launches, other run
     lengths, the super-row schedules with 2 / 4 block rows per workgroup that large matrices select by
-    themselves) are read once per process, so each runs in a child process; same product, bit-reproducible.
+    themselves - with 2 block rows: the wide one-wave-per-SIMD kernel of k_matvec_symw.hip for more than 8 columns
+    (DAV_SYM_WIDE = 2, default), for more than 16 only (1) or never (0: matvec_sym9_kernel<2>)) are read once per
+    process, so each runs in a child process; same product, bit-reproducible.
     Orders cover 1..10 block rows: ragged super rows, diagonal super blocks, a single block row."""
     import os
     import subprocess
