@@ -13,6 +13,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <ctime>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -114,6 +118,7 @@ struct SmallBuf {            // device small matrix + pinned staging
 constexpr int N_SMALL = 4;
 constexpr int N_EVPAIRS = 64;
 
+struct Watchdog;
 struct dav_engine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -154,7 +159,11 @@ struct dav_engine {
   double* sym_wrecv = nullptr;    // ... and the summed chunk the reduce-scatter hands back (nslab x 32)
   // RCCL only: a second stream for the collectives of the symmetric sweep, so that the all-gather of the NEXT 32 columns
   // and the reduce-scatter of the PREVIOUS ones run under the sweep of the current ones; buffers alternate by chunk parity
+  Watchdog* wd = nullptr;         // watches the RCCL collectives of this engine (dav_comm_init)
+  int group_depth = 0;            // inside ncclGroupStart / ncclGroupEnd: the group is marked once, at its end
+  long iter_hint = -1;            // outer iteration the driver is in (dav_ranks_agree), for the watchdog's message
   hipStream_t comm_stream = nullptr;
+  bool ov_ready = false;          // stream, events and buffers of apply_sym_overlapped all exist
   hipEvent_t ov_packed[2] = {nullptr, nullptr}, ov_gathered[2] = {nullptr, nullptr}, ov_reduced[2] = {nullptr, nullptr},
              ov_scattered[2] = {nullptr, nullptr};
   double* sym_wpart2[2] = {nullptr, nullptr};
@@ -192,10 +201,57 @@ struct dav_engine {
   hipEvent_t ev[N_EVPAIRS][2];
   double ev_bytes[N_EVPAIRS];
   int ev_kind[N_EVPAIRS];
+  bool ev_done[N_EVPAIRS];        // end event recorded (a call that fails between begin and end leaves a pair without one)
   int ev_used = 0, ev_open = 0;
   int timing_level = 1;           // 0 = nothing, 1 = block matvec only, 2 = every phase
 };
 typedef dav_engine E;
+
+// ---- collective watchdog (failure detection: the reference's convention is print + stop,
+// src/lapack_wrapper.f90:395-408) ------------------------------------------------------------------------------------
+// A rank whose peer died inside RCCL would wait for ever: the collectives are asynchronous stream operations, the host
+// only notices at its next synchronisation, which never returns.  Every RCCL collective (or group of them) is therefore
+// followed by an event, and one thread per engine checks that events complete: one that has not after
+// DAVIDSON_COLLECTIVE_TIMEOUT seconds (default 600; 0 = no watchdog) prints rank / collective / outer iteration and ends
+// the process with exit code 124 - the launcher then tears the group down.  No re-exec, nothing is retried.
+struct Watchdog {
+  static constexpr int NW = 32;
+  struct Item { hipEvent_t ev = nullptr; const char* what = ""; uint64_t seq = 0; double t0 = 0.0; long iter = -1; bool active = false; };
+  Item it[NW];
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool stop = false;
+  uint64_t seq = 0;
+  double timeout_s = 0.0;
+  int device = 0, rank = 0, nranks = 1;
+};
+static double wall_seconds() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void watchdog_loop(Watchdog* w) {
+  (void)hipSetDevice(w->device);
+  std::unique_lock<std::mutex> lk(w->mu);
+  while (!w->stop) {
+    w->cv.wait_for(lk, std::chrono::milliseconds(200));
+    const double now = wall_seconds();
+    for (Watchdog::Item& x : w->it) {
+      if (!x.active) continue;
+      const hipError_t q = hipEventQuery(x.ev);
+      if (q == hipSuccess) { x.active = false; continue; }
+      (void)hipGetLastError();
+      if (q == hipErrorNotReady && now - x.t0 > w->timeout_s) {
+        std::fprintf(stderr, "davidson engine: rank %d of %d: collective \"%s\" (number %llu, outer iteration %ld) has not completed after %.0f s "
+                             "- a peer is gone or stuck; ending this process (DAVIDSON_COLLECTIVE_TIMEOUT sets the bound)\n",
+                     w->rank, w->nranks, x.what, (unsigned long long)x.seq, x.iter, now - x.t0);
+        std::fflush(stderr);
+        _exit(124);
+      }
+    }
+  }
+}
 static void ingest_release(E* e);
 static void shm_release(E* e);
 
@@ -203,8 +259,13 @@ static inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m
 
 static int bind(E* e) { HIPCHK(hipSetDevice(e->device)); return 0; }
 
+// Called only where no pair can legitimately be open (API entry points, or timed_begin with ev_open == 0): a pair left
+// without its end event by a failed call is dropped here, and the open count starts from zero again - a failure does
+// not switch the timing off for the rest of the engine's life.
 static int collect_events(E* e) {
+  e->ev_open = 0;
   for (int i = 0; i < e->ev_used; ++i) {
+    if (!e->ev_done[i]) continue;
     HIPCHK(hipEventSynchronize(e->ev[i][1]));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e->ev[i][0], e->ev[i][1]));
@@ -235,10 +296,11 @@ static int timed_begin(E* e, int kind, double bytes, int* slot) {
   // dav_set_timing(h, 2) adds the Gram / panel / collective phases
   if (e->timing_level < 1 || (kind != 0 && kind != 4 && e->timing_level < 2)) { *slot = -1; return 0; }
   // pairs nest (kernel inside apply): collect only while no pair is open, and leave room for the inner ones
-  if (e->ev_open == 0 && e->ev_used > N_EVPAIRS - 4) CHK(collect_events(e));
+  if (e->ev_open == 0 && e->ev_used > N_EVPAIRS - 12) CHK(collect_events(e));   // room for the inner pairs of one apply (<= 8 chunks + collectives)
   if (e->ev_used == N_EVPAIRS) { *slot = -1; return 0; }
   ++e->ev_open;
   *slot = e->ev_used++;
+  e->ev_done[*slot] = false;
   e->ev_kind[*slot] = kind;
   e->ev_bytes[*slot] = bytes;
   HIPCHK(hipEventRecord(e->ev[*slot][0], e->stream));
@@ -246,8 +308,9 @@ static int timed_begin(E* e, int kind, double bytes, int* slot) {
 }
 static int timed_end(E* e, int slot) {
   if (slot < 0) return 0;
-  --e->ev_open;
+  if (e->ev_open > 0) --e->ev_open;
   HIPCHK(hipEventRecord(e->ev[slot][1], e->stream));
+  e->ev_done[slot] = true;
   return 0;
 }
 
@@ -426,6 +489,14 @@ extern "C" int dav_destroy(dav_handle_t e) {
     hipFree(e->sym_wrecv2[i]);
   }
   if (e->comm_stream) hipStreamDestroy(e->comm_stream);
+  if (e->wd) {
+    { std::lock_guard<std::mutex> lk(e->wd->mu); e->wd->stop = true; }
+    e->wd->cv.notify_all();
+    e->wd->th.join();
+    for (Watchdog::Item& x : e->wd->it) if (x.ev) hipEventDestroy(x.ev);
+    delete e->wd;
+    e->wd = nullptr;
+  }
   hipFree(e->sym_row_off);
   hipFree(e->sym_wpart);
   hipFree(e->sym_wrecv);
@@ -471,6 +542,21 @@ extern "C" int dav_comm_init(dav_handle_t e, const void* id128) {
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   NCCLCHK(g_rccl.CommInitRank(&e->comm, e->nranks, id, e->rank));
+  // the watchdog of this communicator's collectives (DAVIDSON_COLLECTIVE_TIMEOUT seconds; default 600, 0 = none)
+  double timeout = 600.0;
+  if (const char* ev = getenv("DAVIDSON_COLLECTIVE_TIMEOUT")) timeout = atof(ev);
+  if (timeout > 0.0 && !e->wd) {
+    Watchdog* w = new Watchdog;
+    w->timeout_s = timeout; w->device = e->device; w->rank = e->rank; w->nranks = e->nranks;
+    for (Watchdog::Item& x : w->it)
+      if (hipEventCreateWithFlags(&x.ev, hipEventDisableTiming) != hipSuccess) {
+        for (Watchdog::Item& y : w->it) if (y.ev) (void)hipEventDestroy(y.ev);
+        delete w;
+        return fail("dav_comm_init: could not create the watchdog's events");
+      }
+    w->th = std::thread(watchdog_loop, w);
+    e->wd = w;
+  }
   return 0;
 }
 
@@ -518,10 +604,10 @@ static int need_comm(E* e) {
   return 0;
 }
 
-// ---- test transports (build flag DAV_TEST_TRANSPORTS, on in this repository's Makefile because the GPU tests run on a
-// one-GPU box; `make DAV_TEST_TRANSPORTS=0` builds the library without them) ---------------------------------------
+// ---- test transports (build flag DAV_TEST_TRANSPORTS: off in the product lib/libdavidson_hip.so, on in lib/test/libdavidson_hip.so,
+// the build pytest loads because the GPU tests run on a one-GPU box - csrc/Makefile) -------------------------------------
 #ifndef DAV_TEST_TRANSPORTS
-#define DAV_TEST_TRANSPORTS 1
+#define DAV_TEST_TRANSPORTS 0
 #endif
 #if DAV_TEST_TRANSPORTS
 // ---- loopback transport: several ranks of one problem as threads of ONE process on ONE GPU ----------
@@ -738,24 +824,56 @@ extern "C" int dav_local_group_join(dav_handle_t*, int) { return fail("dav_local
 #endif
 
 // recv[p*count .. (p+1)*count) = send of rank p, for every rank (send may alias recv + rank*count)
+#if DAV_TEST_TRANSPORTS
+// test hook (DAV_TEST_STALL_MS): a finite single-thread kernel that holds the stream for that long in front of a
+// collective's event, so that the watchdog can be seen to fire on a one-GPU box
+__global__ void watchdog_stall_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+#endif
+// an event behind the collective(s) just enqueued on `stream`, handed to the watchdog
+static int watch_mark(E* e, const char* what, hipStream_t stream) {
+  Watchdog* w = e->wd;
+  if (!w || e->group_depth > 0) return 0;
+#if DAV_TEST_TRANSPORTS
+  if (const char* ev = getenv("DAV_TEST_STALL_MS"))
+    hipLaunchKernelGGL(watchdog_stall_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long)atoll(ev) * 100000ull);   // 100 MHz counter
+#endif
+  std::lock_guard<std::mutex> lk(w->mu);
+  Watchdog::Item& x = w->it[w->seq % Watchdog::NW];
+  if (x.active) return 0;                       // the ring is full of unfinished collectives: the oldest of them is being watched
+  HIPCHK(hipEventRecord(x.ev, stream));
+  x.what = what; x.seq = w->seq++; x.t0 = wall_seconds(); x.iter = e->iter_hint; x.active = true;
+  return 0;
+}
+static int coll_group_begin(E* e) {
+  if (e->comm) { NCCLCHK(g_rccl.GroupStart()); ++e->group_depth; }
+  return 0;
+}
+static int coll_group_end(E* e, const char* what, hipStream_t stream) {
+  if (e->comm) { NCCLCHK(g_rccl.GroupEnd()); --e->group_depth; CHK(watch_mark(e, what, stream)); }
+  return 0;
+}
+
 static int coll_allgather(E* e, const double* send, double* recv, size_t count) {
   if (has_test_transport(e)) return test_allgather(e, send, recv, count);
   NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
-  return 0;
+  return watch_mark(e, "all-gather", e->stream);
 }
 
 // buf <- sum over ranks of buf (same bits on every rank)
 static int coll_allreduce(E* e, double* buf, size_t count) {
   if (has_test_transport(e)) return test_allreduce(e, buf, count);
   NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
-  return 0;
+  return watch_mark(e, "all-reduce", e->stream);
 }
 
 // recv[0 .. count) = sum over ranks p of send_p[rank*count .. (rank+1)*count)  (send holds nranks chunks)
 static int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
   if (has_test_transport(e)) return test_reduce_scatter(e, send, recv, count);
   NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
-  return 0;
+  return watch_mark(e, "reduce-scatter", e->stream);
 }
 
 static int refresh_diag_host(E* e, int which) {
@@ -1308,23 +1426,41 @@ static void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPla
 static int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner) {
   const int step = 32;
   const int nchunks = (k + step - 1) / step;
-  if (!e->comm_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-      HIPCHK(hipEventCreateWithFlags(&e->ov_packed[i], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&e->ov_gathered[i], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&e->ov_reduced[i], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&e->ov_scattered[i], hipEventDisableTiming));
-      HIPCHK(hipMalloc(&e->sym_wpart2[i], sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
-      HIPCHK(hipMalloc(&e->sym_wrecv2[i], sizeof(double) * (size_t)e->nslab * 32));
+  if (!e->ov_ready) {
+    // everything into locals first: a failure half-way must not leave a stream without its events or buffers behind
+    // (later calls would skip this block and launch on null handles); committed to the engine only when complete
+    hipStream_t cs = nullptr;
+    hipEvent_t evs[8] = {};
+    double* bufs[4] = {};
+    auto undo = [&]() {
+      for (hipEvent_t v : evs) if (v) (void)hipEventDestroy(v);
+      for (double* b : bufs) if (b) (void)hipFree(b);
+      if (cs) (void)hipStreamDestroy(cs);
+    };
+    bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < 2; ++i) {
+      ok = hipMalloc(&bufs[i], sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32) == hipSuccess &&
+           hipMalloc(&bufs[2 + i], sizeof(double) * (size_t)e->nslab * 32) == hipSuccess;
     }
+    if (!ok) {
+      (void)hipGetLastError();
+      undo();
+      return 2;                                        // the caller runs the serial path
+    }
+    e->comm_stream = cs;
+    for (int i = 0; i < 2; ++i) {
+      e->ov_packed[i] = evs[4 * i]; e->ov_gathered[i] = evs[4 * i + 1]; e->ov_reduced[i] = evs[4 * i + 2]; e->ov_scattered[i] = evs[4 * i + 3];
+      e->sym_wpart2[i] = bufs[i]; e->sym_wrecv2[i] = bufs[2 + i];
+    }
+    e->ov_ready = true;
   }
   const int64_t total_rows = (int64_t)e->nranks * e->nslab;
   const bool use32 = inner && inner_f32_tiles(e, o);
   const int R = 2;                                     // 32-column chunks: the paired two-block-row schedule
   const E::SymPlan* pl = &e->sym_plan[0];
   const int64_t dstride = (int64_t)pl->nitems * R * 16 * SYM_TB, tstride = pl->zslots * 16 * SYM_TB;
-  CHK(sym_ensure_slabs(e, (size_t)2 * (size_t)(dstride + tstride) + 1));
+  if (sym_ensure_slabs(e, (size_t)2 * (size_t)(dstride + tstride) + 1) != 0) return 2;   // serial path: it degrades 4 -> 2 -> 1 column groups
   int slot = -1;
   const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
   if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, stored * nchunks + 16.0 * (double)e->n * k, &slot));
@@ -1335,12 +1471,12 @@ static int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, i
     launch_pack_xt(e->stream, src + (int64_t)i * step * e->ldp, e->ldp, e->nloc, e->nslab, kk, xt_of(i), e->xt_group_stride, e->row0);
     HIPCHK(hipEventRecord(e->ov_packed[p], e->stream));
     HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_packed[p], 0));
-    NCCLCHK(g_rccl.GroupStart());
+    CHK(coll_group_begin(e));
     for (int g = 0; g < ng; ++g) {
       double* base = xt_of(i) + (size_t)g * e->xt_group_stride;
       NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, e->comm_stream));
     }
-    NCCLCHK(g_rccl.GroupEnd());
+    CHK(coll_group_end(e, "all-gather of a column chunk (second stream)", e->comm_stream));
     HIPCHK(hipEventRecord(e->ov_gathered[p], e->comm_stream));
     return 0;
   };
@@ -1371,11 +1507,11 @@ static int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, i
                          e->nslab, total_rows);
     HIPCHK(hipEventRecord(e->ov_reduced[p], e->stream));
     HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_reduced[p], 0));
-    NCCLCHK(g_rccl.GroupStart());
+    CHK(coll_group_begin(e));
     for (int g = 0; g < npair; ++g)
       NCCLCHK(g_rccl.ReduceScatter(e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16,
                                    (size_t)e->nslab * std::min(16, kk - 16 * g), ncclDouble, ncclSum, e->comm, e->comm_stream));
-    NCCLCHK(g_rccl.GroupEnd());
+    CHK(coll_group_end(e, "reduce-scatter of a column chunk (second stream)", e->comm_stream));
     HIPCHK(hipEventRecord(e->ov_scattered[p], e->comm_stream));
     if (i >= 1) CHK(to_panel(i - 1));                      // the previous chunk's rows of W, while this chunk's reduce-scatter runs
     if (which == DAV_OP_A) { e->st.applies += 1; e->st.apply_cols += kk; }
@@ -1423,8 +1559,10 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       // communicator only, and a second stream on one communicator is exactly the kind of thing that must be seen on real
       // links before it becomes the default of a run nobody can watch
       static const int overlap_env = [] { const char* ev = getenv("DAV_SYM_OVERLAP"); return ev ? atoi(ev) : 0; }();
-      if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 16) == 2)
-        return apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
+      if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 16) == 2) {
+        const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
+        if (rc != 2) return rc;                        // 2: its streams / buffers / slabs could not be set up - serial path below
+      }
     }
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
@@ -1449,12 +1587,12 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
       if (multi) {
         CHK(timed_begin(e, 3, 0, &cslot));
-        if (e->comm) NCCLCHK(g_rccl.GroupStart());
+        CHK(coll_group_begin(e));
         for (int g = 0; g < npair; ++g) {
           double* base = e->xt + g * e->xt_group_stride;
           CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
         }
-        if (e->comm) NCCLCHK(g_rccl.GroupEnd());
+        CHK(coll_group_end(e, "all-gather of the new block", e->stream));
         CHK(timed_end(e, cslot));
       }
       if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
@@ -1483,13 +1621,13 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
       }
       if (multi) {
         CHK(timed_begin(e, 3, 0, &cslot));
-        if (e->comm) NCCLCHK(g_rccl.GroupStart());
+        CHK(coll_group_begin(e));
         for (int g = 0; g < npair; ++g) {
           const int kg = std::min(16, kk - 16 * g);
           CHK(coll_reduce_scatter(e, e->sym_wpart + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16,
                                   (size_t)e->nslab * kg));
         }
-        if (e->comm) NCCLCHK(g_rccl.GroupEnd());
+        CHK(coll_group_end(e, "reduce-scatter of the partial products", e->stream));
         CHK(timed_end(e, cslot));
         for (int g = 0; g < npair; ++g)
           launch_chunk_to_panel(e->stream, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad,
@@ -1515,12 +1653,12 @@ static int apply_ptr(E* e, int which, const double* src, int k, double* dst, boo
     if (has_comm(e)) {
       int cslot;
       CHK(timed_begin(e, 3, 0, &cslot));
-      if (e->comm) NCCLCHK(g_rccl.GroupStart());
+      CHK(coll_group_begin(e));
       for (int g = 0; g < groups; ++g) {
         double* base = e->xt + g * e->xt_group_stride;
         CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
       }
-      if (e->comm) NCCLCHK(g_rccl.GroupEnd());
+      CHK(coll_group_end(e, "all-gather of the new block", e->stream));
       CHK(timed_end(e, cslot));
     }
     int nsplit, jc;
@@ -1764,7 +1902,7 @@ static int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_
   if (dev) {
     // the Ritz values (and the eigensolver's status word) ride on the same fetch, behind the all-reduced part
     const size_t toff = (count + 7) / 8 * 8;
-    if (toff + (size_t)m + 1 > e->gram_doubles) return fail("gram result exceeds engine capacity");
+    if (toff + (size_t)roundup(m + 1, 2) > e->gram_doubles) return fail("gram result exceeds engine capacity");   // the tail copy moves whole pairs
     if (has_comm(e)) CHK(coll_allreduce(e, e->gram_dev, count));
     launch_copy_columns(e->stream, e->rr_thpk + roundup(ncorr, 64), 2 * (int64_t)roundup(m + 1, 2), result_target(e) + toff,
                         2 * (int64_t)roundup(m + 1, 2), roundup(m + 1, 2), 1);
@@ -1920,6 +2058,7 @@ extern "C" int dav_restart(dav_handle_t e, int m, int keep, const double* Yk, in
 // a rank that sees them differ returns an error - its process ends with a message, and the launcher tears the group down -
 // instead of walking into the next collective alone and hanging everybody.  One tiny all-reduce per outer iteration.
 extern "C" int dav_ranks_agree(dav_handle_t e, const double* words, int nwords) {
+  if (nwords > 0) e->iter_hint = (long)words[0];       // the driver's first word is its iteration number (the watchdog's message)
   if (e->nranks <= 1 || !has_comm(e)) return 0;
   CHK(bind(e));
   if (nwords <= 0 || (size_t)(2 * nwords) > e->gram_doubles) return fail("dav_ranks_agree: bad word count");
@@ -1946,9 +2085,10 @@ extern "C" int dav_ranks_agree(dav_handle_t e, const double* words, int nwords) 
 extern "C" int dav_rr_enable(dav_handle_t e, int on) {
   CHK(bind(e));
   if (on && !e->rr_H) {
-    if (e->cols_alloc > 144) return fail("dav_rr_enable: the device eigensolver handles projected problems of order <= 128");
-    e->rr_ld = e->cols_alloc;
-    const size_t sq = (size_t)e->rr_ld * e->rr_ld, pk = (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
+    // the device eigensolver handles projected problems of order <= 128 (+ one expansion block on top); an engine created
+    // for a wider basis can still run narrower solves with it: the device-resident matrices are sized to what it can use
+    e->rr_ld = std::min<int64_t>(e->cols_alloc, 160);
+    const size_t sq = (size_t)e->rr_ld * e->rr_ld, pk = (size_t)roundup(e->rr_ld, 4) * roundup(e->rr_ld, 64);
     HIPCHK(hipMalloc(&e->rr_H, sizeof(double) * sq));
     HIPCHK(hipMalloc(&e->rr_S, sizeof(double) * sq));
     HIPCHK(hipMalloc(&e->rr_Y, sizeof(double) * sq));
@@ -1957,7 +2097,7 @@ extern "C" int dav_rr_enable(dav_handle_t e, int on) {
     HIPCHK(hipMalloc(&e->rr_info, sizeof(double) * 8));
     HIPCHK(hipMalloc(&e->rr_Ypk, sizeof(double) * pk));
     HIPCHK(hipMalloc(&e->rr_Y2pk, sizeof(double) * pk));
-    HIPCHK(hipMalloc(&e->rr_thpk, sizeof(double) * (roundup(e->cols_alloc, 64) + e->rr_ld + 8)));
+    HIPCHK(hipMalloc(&e->rr_thpk, sizeof(double) * (roundup(e->rr_ld, 64) + e->rr_ld + 8)));
     HIPCHK(hipMemsetAsync(e->rr_H, 0, sizeof(double) * sq, e->stream));
     HIPCHK(hipMemsetAsync(e->rr_S, 0, sizeof(double) * sq, e->stream));
   }
@@ -1981,6 +2121,8 @@ extern "C" int dav_rr_ritz(dav_handle_t e, int m, int ncorr, int lowest, int met
   CHK(bind(e));
   if (!e->rr_on) return fail("dav_rr_ritz: call dav_rr_enable first");
   if (m <= 0 || m > 128 || m > e->rr_ld || !theta_out || !resnorm) return fail("dav_rr_ritz: bad arguments (order <= 128)");
+  // checked BEFORE the eigensolver and the operand packing are launched: they index the device-resident arrays with these
+  if (lowest <= 0 || lowest > m || ncorr < 0 || ncorr > m) return fail("dav_rr_ritz: bad shape (0 < lowest <= m, 0 <= ncorr <= m)");
   if (C && (!G || ldc < m || ldg < ncorr)) return fail("dav_rr_ritz: bad shape");
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));

@@ -173,7 +173,12 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
       }
       __syncthreads();
     }
-    if (flag == 0) break;                            // a whole sweep without a rotation
+    // a whole sweep without a rotation ends the iteration.  The decision is latched in a register BEFORE the barrier
+    // that lets thread 0 reset the flag for the next sweep: read after it, a slower wave could see the reset value,
+    // leave the loop alone and strand the workgroup at different barriers.
+    const int rotated = flag;
+    __syncthreads();
+    if (rotated == 0) break;
   }
 
   // ---- ascending order (ties by index), Y ---------------------------------------------------------------------------

@@ -59,8 +59,8 @@ typedef struct dav_stats {
   double last_apply_bytes;
   double gram_ms, panel_ms, comm_ms;
   double apply_kernel_ms;  /* the block-matvec kernel alone inside apply_ms (same launches)          */
-  double apply_flops;      /* 2*nloc*N*k per apply (N*N*k with symmetric tiles: every stored entry   */
-                           /* is used twice)                                                         */
+  double apply_flops;      /* 2*nloc*N*k per apply and rank (2*N*N*k / nranks with symmetric tiles:  */
+                           /* every stored entry is used twice)                                      */
   int64_t apply_launches;  /* launches of the block-matvec kernel (an apply of > 32 / 64 columns is  */
                            /* several launches)                                                      */
   int64_t restarts;        /* collapse restarts (dav_restart / dav_rr_restart) so far                */
@@ -98,10 +98,12 @@ int dav_set_timing(dav_handle_t h, int level);
 int dav_local_rows(dav_handle_t h, int64_t* row0, int64_t* nloc);
 
 /* ---- operators (replace `matrix` / `second_matrix` / fun_matrix_gemv) ------------------------- */
-/* Storage of dense operators set AFTER this call: 0 = full (default; required for nranks > 1),
- * 1 = symmetric-tiled: only the lower block triangle (256 x 256 tiles) is kept in HBM - N(N+1)/2
- * entries, e.g. 160 GB instead of 320 GB at N = 200000 - and the block matvec uses every
- * off-diagonal tile twice (A is assumed symmetric, as the reference assumes). */
+/* Storage of dense operators set AFTER this call: 0 = full row slabs (default), 1 = symmetric-tiled: only
+ * the lower block triangle (256 x 256 tiles) is kept in HBM - N(N+1)/2 entries, e.g. 160 GB instead of
+ * 320 GB at N = 200000 - and the block matvec uses every off-diagonal tile twice (A is assumed symmetric,
+ * as the reference assumes).  Both work with any number of ranks: full = rank r keeps its rows of
+ * A (all-gather of the new block per sweep); symmetric = the block rows of the triangle are dealt out over
+ * the ranks, N*N/2P entries each (all-gather + reduce-scatter per sweep). */
 int dav_set_storage(dav_handle_t h, int mode);
 /* Dense matrix from host memory, full storage a(lda, n), the caller's array as passed to
  * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and

@@ -11,6 +11,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# pytest runs against the TEST build of the engine (fortran_davidson_amd/lib/test/libdavidson_hip.so: the product's sources plus
+# the loopback / shared-memory transports that let several ranks share the one GPU of the test box); the product library
+# (lib/libdavidson_hip.so) is built without them.  Same soname: the Fortran host library binds to the copy already loaded, and
+# the Fortran test programs (linked with a RUNPATH to lib/) find the test copy first through LD_LIBRARY_PATH.
+_TEST_LIB_DIR = os.path.join(ROOT, "fortran_davidson_amd", "lib", "test")
+if os.path.exists(os.path.join(_TEST_LIB_DIR, "libdavidson_hip.so")):
+    os.environ.setdefault("DAVIDSON_HIP_LIB", os.path.join(_TEST_LIB_DIR, "libdavidson_hip.so"))
+    os.environ["LD_LIBRARY_PATH"] = _TEST_LIB_DIR + (":" + os.environ["LD_LIBRARY_PATH"] if os.environ.get("LD_LIBRARY_PATH") else "")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

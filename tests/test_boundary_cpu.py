@@ -100,3 +100,25 @@ def test_rayleigh_ritz_solver_all_routes_against_scipy(n, nvec, gev):
     SY = Y if S is None else S @ Y
     assert np.abs(H @ Y - SY * w[None, :]).max() < 1e-9
     assert np.abs(Y.T @ SY - np.eye(nvec)).max() < 1e-10
+
+
+def test_product_library_is_built_without_the_test_transports():
+    """lib/libdavidson_hip.so (what a user links) carries no loopback / shared-memory transport: its two entry points are
+    stubs that fail; lib/test/libdavidson_hip.so (same sources, -DDAV_TEST_TRANSPORTS=1, same soname) is what pytest loads."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prod = os.path.join(root, "fortran_davidson_amd", "lib", "libdavidson_hip.so")
+    test = os.path.join(root, "fortran_davidson_amd", "lib", "test", "libdavidson_hip.so")
+    for path in (prod, test):
+        assert os.path.exists(path), path
+        dyn = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+        assert "soname: [libdavidson_hip.so]" in dyn
+    stub_msg = b"built without DAV_TEST_TRANSPORTS"
+    assert stub_msg in open(prod, "rb").read()
+    assert stub_msg not in open(test, "rb").read()
+    assert os.environ.get("DAVIDSON_HIP_LIB") == test          # conftest.py
+    # the stubs fail without touching a GPU
+    lib = C.CDLL(prod, mode=C.RTLD_LOCAL)
+    lib.dav_last_error.restype = C.c_char_p
+    assert lib.dav_local_group_join(None, 0) != 0 and stub_msg in lib.dav_last_error()
