@@ -1,0 +1,362 @@
+// Engine, K1 scheduling: W = A X (or B X) for a block of columns - which kernel, how many columns per launch, packing,
+// collectives around the sweep, the fixed-order reductions; the apply microbenchmark entry points.
+#include "engine_internal.h"
+
+// ---- K1 -----------------------------------------------------------------------------------------
+// dst[:, 0:k] = Op(which) * src[:, 0:k] for device-resident column blocks with leading dimension ldp
+// fp32 copy of a stored symmetric-tiled operator, made when the first inner sweep wants it; false (and fp64 sweeps) when
+// the memory for it is not there
+bool inner_f32_tiles(E* e, OpDesc& o) {
+  if (e->inner_bits != 32 || o.kind != DAV_KIND_DENSE || o.storage != 1 || o.a32_refused) return false;
+  if (o.a32_valid) return true;
+  const size_t count = (size_t)std::max<int64_t>(e->sym_ntiles_local, 1) * SYM_TB * SYM_TB;
+  if (!o.a32 && hipMalloc(&o.a32, sizeof(float) * count) != hipSuccess) {
+    (void)hipGetLastError();
+    o.a32 = nullptr;
+    o.a32_refused = true;
+    return false;
+  }
+  launch_tiles_to_f32(e->stream, o.a, o.a32, (int64_t)count);
+  o.a32_valid = true;
+  return true;
+}
+
+// The super-row sweep of one launch: stored fp64 tiles, two block rows per workgroup and more than 8 columns run the
+// one-wave-per-SIMD kernel (k_matvec_symw.hip: 32 columns per workgroup, or 16 for a block of <= 16); generated operators,
+// the fp32 copy and the k <= 8 schedule (R = 4, 4x4x4 MFMA) stay on matvec_sym9_kernel.
+// DAV_SYM_WIDE = 0: never (A/B runs), 1: blocks wider than 16 columns only, 2 (default): from 9 columns on.  Read per call.
+void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
+                       int npair, int64_t dstride, int64_t tstride) {
+  const char* ev = getenv("DAV_SYM_WIDE");
+  const int wide = ev ? atoi(ev) : 2;
+  if (R == 2 && o.kind == DAV_KIND_DENSE && !use32 && wide > 0 && (kk > 16 || wide > 1)) {
+    const int nbw = kk > 16 ? 2 : 1;
+    launch_matvec_symw(e->stream, nbw, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+                       (npair + nbw - 1) / nbw, e->xt_group_stride, dstride, tstride);
+    return;
+  }
+  launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
+                     o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk,
+                     slabD, slabT, npair, e->xt_group_stride, dstride, tstride);
+}
+
+
+// Symmetric sweep of k > 32 columns over several ranks with RCCL, chunks of 32 columns software-pipelined over two streams:
+//   comm stream:  gather(0)            gather(1)   scatter(0)   gather(2)   scatter(1) ...
+//   main stream:  pack(0) pack(1) | wait gather(0) sweep(0) reduce(0) | pack(2) wait gather(1) sweep(1) reduce(1) | to_panel(0) ...
+// i.e. the all-gather of chunk i + 1 and the reduce-scatter of chunk i - 1 run under the sweep of chunk i.  Xt column groups,
+// the partial-product buffer and the receive buffer alternate with the chunk parity.  Same kernels, same sums, same result as
+// the serial path (which the test transports and single-chunk applies keep using).
+int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner) {
+  const int step = 32;
+  const int nchunks = (k + step - 1) / step;
+  if (!e->ov_ready) {
+    // everything into locals first: a failure half-way must not leave a stream without its events or buffers behind
+    // (later calls would skip this block and launch on null handles); committed to the engine only when complete
+    hipStream_t cs = nullptr;
+    hipEvent_t evs[8] = {};
+    double* bufs[4] = {};
+    auto undo = [&]() {
+      for (hipEvent_t v : evs) if (v) (void)hipEventDestroy(v);
+      for (double* b : bufs) if (b) (void)hipFree(b);
+      if (cs) (void)hipStreamDestroy(cs);
+    };
+    bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < 2; ++i) {
+      ok = hipMalloc(&bufs[i], sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32) == hipSuccess &&
+           hipMalloc(&bufs[2 + i], sizeof(double) * (size_t)e->nslab * 32) == hipSuccess;
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      undo();
+      return 2;                                        // the caller runs the serial path
+    }
+    e->comm_stream = cs;
+    for (int i = 0; i < 2; ++i) {
+      e->ov_packed[i] = evs[4 * i]; e->ov_gathered[i] = evs[4 * i + 1]; e->ov_reduced[i] = evs[4 * i + 2]; e->ov_scattered[i] = evs[4 * i + 3];
+      e->sym_wpart2[i] = bufs[i]; e->sym_wrecv2[i] = bufs[2 + i];
+    }
+    e->ov_ready = true;
+  }
+  const int64_t total_rows = (int64_t)e->nranks * e->nslab;
+  const bool use32 = inner && inner_f32_tiles(e, o);
+  const int R = 2;                                     // 32-column chunks: the paired two-block-row schedule
+  const E::SymPlan* pl = &e->sym_plan[0];
+  const int64_t dstride = (int64_t)pl->nitems * R * 16 * SYM_TB, tstride = pl->zslots * 16 * SYM_TB;
+  if (sym_ensure_slabs(e, (size_t)2 * (size_t)(dstride + tstride) + 1) != 0) return 2;   // serial path: it degrades 4 -> 2 -> 1 column groups
+  int slot = -1;
+  const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
+  if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, stored * nchunks + 16.0 * (double)e->n * k, &slot));
+  auto cols = [&](int i) { return std::min(step, k - i * step); };
+  auto xt_of = [&](int i) { return e->xt + (size_t)(i & 1) * 2 * e->xt_group_stride; };
+  auto pack_and_gather = [&](int i) -> int {
+    const int p = i & 1, kk = cols(i), ng = (kk + 15) / 16;
+    launch_pack_xt(e->stream, src + (int64_t)i * step * e->ldp, e->ldp, e->nloc, e->nslab, kk, xt_of(i), e->xt_group_stride, e->row0);
+    HIPCHK(hipEventRecord(e->ov_packed[p], e->stream));
+    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_packed[p], 0));
+    CHK(coll_group_begin(e));
+    for (int g = 0; g < ng; ++g) {
+      double* base = xt_of(i) + (size_t)g * e->xt_group_stride;
+      NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, e->comm_stream));
+    }
+    CHK(coll_group_end(e, "all-gather of a column chunk (second stream)", e->comm_stream));
+    HIPCHK(hipEventRecord(e->ov_gathered[p], e->comm_stream));
+    return 0;
+  };
+  auto to_panel = [&](int i) -> int {
+    const int p = i & 1, kk = cols(i), ng = (kk + 15) / 16;
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ov_scattered[p], 0));
+    for (int g = 0; g < ng; ++g)
+      launch_chunk_to_panel(e->stream, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad,
+                            std::min(16, kk - 16 * g), dst + (int64_t)(i * step + 16 * g) * e->ldp, e->ldp);
+    return 0;
+  };
+  CHK(pack_and_gather(0));
+  for (int i = 0; i < nchunks; ++i) {
+    const int p = i & 1, kk = cols(i), npair = (kk + 15) / 16;
+    if (i + 1 < nchunks) CHK(pack_and_gather(i + 1));         // Xt groups of the other parity: last read by the sweep of chunk i - 1
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ov_gathered[p], 0));
+    int kslot = -1;
+    if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
+    double* slabT = e->sym_slab + (int64_t)npair * dstride;
+    if (pl->nitems > 0)
+      sym9_sweep(e, R, o, use32, pl, xt_of(i), kk, e->sym_slab, slabT, npair, dstride, tstride);
+    CHK(timed_end(e, kslot));
+    // partial of the whole product of this chunk (the buffer of this parity was last read by the reduce-scatter of chunk
+    // i - 2, whose completion the main stream waited for when it finished chunk i - 2 below)
+    for (int g = 0; g < npair; ++g)
+      launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, e->sym_row_off, R,
+                         e->sym_nb, e->nloc, std::min(16, kk - 16 * g), e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->ldp,
+                         e->nslab, total_rows);
+    HIPCHK(hipEventRecord(e->ov_reduced[p], e->stream));
+    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_reduced[p], 0));
+    CHK(coll_group_begin(e));
+    for (int g = 0; g < npair; ++g)
+      NCCLCHK(g_rccl.ReduceScatter(e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16,
+                                   (size_t)e->nslab * std::min(16, kk - 16 * g), ncclDouble, ncclSum, e->comm, e->comm_stream));
+    CHK(coll_group_end(e, "reduce-scatter of a column chunk (second stream)", e->comm_stream));
+    HIPCHK(hipEventRecord(e->ov_scattered[p], e->comm_stream));
+    if (i >= 1) CHK(to_panel(i - 1));                      // the previous chunk's rows of W, while this chunk's reduce-scatter runs
+    if (which == DAV_OP_A) { e->st.applies += 1; e->st.apply_cols += kk; }
+  }
+  CHK(to_panel(nchunks - 1));
+  CHK(timed_end(e, slot));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// inner = true: a sweep inside the GJD correction solve (may run on the fp32 copy, dav_set_inner_precision)
+int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner) {
+  OpDesc& o = e->op[which];
+  if (o.kind == DAV_KIND_NONE) return fail("dav_apply: operator not set");
+  if (o.kind == DAV_KIND_HOST) return fail("dav_apply: host operator - move blocks with dav_panel_get/put");
+  if (o.kind == DAV_KIND_IDENTITY) {
+    launch_copy_columns(e->stream, src, e->ldp, dst, e->ldp, e->nloc_pad, k);
+    return 0;
+  }
+  CHK(need_comm(e));
+  if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS) && o.storage == 1) {
+    // symmetric-tiled sweep: every off-diagonal tile read (or generated) once, used twice.  16 columns per workgroup; 32
+    // columns per launch as paired workgroups that share their tile reads through the memory-side cache.
+    // Several ranks: each sweeps the block rows it stores against the all-gathered block and holds a partial of the
+    // WHOLE product; one reduce-scatter per 16 columns sums the partials and leaves every rank its row slab.
+    static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
+    // pairing shares the READS of stored tiles: nothing to share when the entries are generated
+    int step = (pair_env && matvec_sym_can_pair() && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
+    // 64 columns (the widest expansion of the doubling policy below a basis of 128) as FOUR column groups in one launch on
+    // the super-row kernels: the four workgroups of a work item share every tile read through their XCD's L2.  Same box,
+    // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  DAV_SYM_QUAD=0: off.
+    static const int quad_env = [] { const char* ev = getenv("DAV_SYM_QUAD"); return ev ? atoi(ev) : 1; }();
+    if (quad_env && step == 32 && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 16) == 2 && !has_comm(e)) step = 64;
+    // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
+    // reduce-scatter of this path through RCCL on a one-GPU box)
+    const bool multi = e->nranks > 1 || has_comm(e);
+    if (multi && !e->sym_wpart) {
+      HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
+      HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
+    }
+    const int64_t* owned = multi ? e->sym_row_off : nullptr;
+    const int64_t total_rows = (int64_t)e->nranks * e->nslab;
+    {
+      // Opt-in (DAV_SYM_OVERLAP=1) until it has run on a multi-GPU node: the pipeline is exercised through a 1-rank RCCL
+      // communicator only, and a second stream on one communicator is exactly the kind of thing that must be seen on real
+      // links before it becomes the default of a run nobody can watch
+      static const int overlap_env = [] { const char* ev = getenv("DAV_SYM_OVERLAP"); return ev ? atoi(ev) : 0; }();
+      if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 16) == 2) {
+        const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
+        if (rc != 2) return rc;                        // 2: its streams / buffers / slabs could not be set up - serial path below
+      }
+    }
+    for (int c = 0; c < k; c += step) {
+      int kk = std::min(step, k - c);
+      int npair = (kk + 15) / 16;
+      const bool use32 = inner && inner_f32_tiles(e, o);
+      int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, std::min(kk, 16));
+      if (use32 && R == 1) R = 2;            // the fp32 tiles are read by the super-row kernels only
+      const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
+      const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)e->sym_nitems * 16 * SYM_TB;
+      const int64_t tstride = R > 1 ? pl->zslots * 16 * SYM_TB : (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
+      while (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride) + 1) != 0) {
+        // not enough memory for this many column groups per launch: fewer from here on (4 -> 2 -> 1)
+        if (npair < 2) return 1;
+        if (npair > 2) { e->sym_no_quad = true; step = 32; kk = 32; npair = 2; }
+        else { e->sym_no_pair = true; step = 16; kk = 16; npair = 1; }
+      }
+      int slot = -1, kslot = -1, cslot = -1;
+      const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
+      double bytes = stored + 16.0 * (double)e->n * kk;
+      // end to end: everything that turns the source columns into W - packing, (all-gather,) the sweep, the fixed-order sum(, reduce-scatter)
+      if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
+      launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
+      if (multi) {
+        CHK(timed_begin(e, 3, 0, &cslot));
+        CHK(coll_group_begin(e));
+        for (int g = 0; g < npair; ++g) {
+          double* base = e->xt + g * e->xt_group_stride;
+          CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
+        }
+        CHK(coll_group_end(e, "all-gather of the new block", e->stream));
+        CHK(timed_end(e, cslot));
+      }
+      if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
+      double* slabT = e->sym_slab + (int64_t)npair * dstride;
+      const int nitems = R > 1 ? pl->nitems : e->sym_nitems;
+      if (nitems > 0) {                      // a rank can be left without a block row (more ranks than groups of block rows)
+        if (R > 1)
+          sym9_sweep(e, R, o, use32, pl, e->xt, kk, e->sym_slab, slabT, npair, dstride, tstride);
+        else if (o.kind != DAV_KIND_DENSE)
+          launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
+                                      e->xt_group_stride, dstride, tstride);
+        else
+          launch_matvec_sym(e->stream, o.a, e->sym_row_off, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
+                            e->xt_group_stride, dstride, tstride);
+      }
+      CHK(timed_end(e, kslot));
+      for (int g = 0; g < npair; ++g) {
+        const int kg = std::min(16, kk - 16 * g);
+        double* out = multi ? e->sym_wpart + (size_t)g * (size_t)total_rows * 16 : dst + (int64_t)(c + 16 * g) * e->ldp;
+        if (R > 1)
+          launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, owned, R, e->sym_nb,
+                             e->nloc, kg, out, e->ldp, multi ? e->nslab : 0, total_rows);
+        else
+          launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, owned, e->sym_nb, e->nloc, kg,
+                            out, e->ldp, multi ? e->nslab : 0, total_rows);
+      }
+      if (multi) {
+        CHK(timed_begin(e, 3, 0, &cslot));
+        CHK(coll_group_begin(e));
+        for (int g = 0; g < npair; ++g) {
+          const int kg = std::min(16, kk - 16 * g);
+          CHK(coll_reduce_scatter(e, e->sym_wpart + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16,
+                                  (size_t)e->nslab * kg));
+        }
+        CHK(coll_group_end(e, "reduce-scatter of the partial products", e->stream));
+        CHK(timed_end(e, cslot));
+        for (int g = 0; g < npair; ++g)
+          launch_chunk_to_panel(e->stream, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad,
+                                std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+      }
+      CHK(timed_end(e, slot));
+      if (which == DAV_OP_A) {
+        e->st.applies += 1;
+        e->st.apply_cols += kk;
+      }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  for (int c = 0; c < k; c += 64) {
+    int kk = std::min(64, k - c);
+    int groups = (kk + 15) / 16;
+    int ngroups = groups == 3 ? 4 : groups;
+    int slot = -1, kslot = -1;
+    double bytes = 8.0 * (double)e->nloc * (double)e->n + 16.0 * (double)e->n * kk;
+    if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
+    launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
+    if (has_comm(e)) {
+      int cslot;
+      CHK(timed_begin(e, 3, 0, &cslot));
+      CHK(coll_group_begin(e));
+      for (int g = 0; g < groups; ++g) {
+        double* base = e->xt + g * e->xt_group_stride;
+        CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
+      }
+      CHK(coll_group_end(e, "all-gather of the new block", e->stream));
+      CHK(timed_end(e, cslot));
+    }
+    int nsplit, jc;
+    matvec_plan(e->nloc_pad, e->ncols_pad, ngroups, &nsplit, &jc);
+    if (matvec_slab_doubles(e->nloc_pad, ngroups, nsplit) > e->scratch_doubles) return fail("matvec scratch too small");
+    if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->nloc * (double)e->n * kk, &kslot));
+    if (o.kind == DAV_KIND_DENSE)
+      launch_matvec_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->xt, e->xt_group_stride, ngroups,
+                          e->scratch, nsplit, jc);
+    else
+      launch_matvec_free(e->stream, op_params(o), e->row0, e->nloc, e->n, e->nloc_pad, e->ncols_pad, e->xt,
+                         e->xt_group_stride, ngroups, e->scratch, nsplit, jc);
+    CHK(timed_end(e, kslot));               // inner pair: the block-matvec kernel alone
+    launch_slab_reduce(e->stream, e->scratch, nsplit, e->nloc_pad, ngroups, e->nloc, kk, dst + (int64_t)c * e->ldp, e->ldp);
+    CHK(timed_end(e, slot));                // outer pair: pack + all-gather + kernel + reduction
+    if (which == DAV_OP_A) {
+      e->st.applies += 1;
+      e->st.apply_cols += kk;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int apply_impl(E* e, int which, int src_panel, int c0, int k, int dst_panel, int d0, bool timed) {
+  CHK(check_panel(e, src_panel, c0, k));
+  CHK(check_panel(e, dst_panel, d0, k));
+  return apply_ptr(e, which, panel_ptr(e, src_panel, c0), k, panel_ptr(e, dst_panel, d0), timed);
+}
+
+extern "C" int dav_apply(dav_handle_t e, int which, int src_panel, int c0, int k, int dst_panel, int d0) {
+  if (which < 0 || which > 1) return fail("dav_apply: bad operator id");
+  CHK(bind(e));
+  return apply_impl(e, which, src_panel, c0, k, dst_panel, d0, true);
+}
+
+// ---- measurement --------------------------------------------------------------------------------
+extern "C" int dav_bench_apply(dav_handle_t e, int which, int k, int reps, double* avg_ms, double* bytes) {
+  double kernel_ms, flops;
+  return dav_bench_apply2(e, which, k, reps, avg_ms, &kernel_ms, bytes, &flops);
+}
+
+extern "C" int dav_bench_apply2(dav_handle_t e, int which, int k, int reps, double* avg_ms, double* kernel_ms, double* bytes,
+                                double* flops) {
+  CHK(bind(e));
+  if (which != DAV_OP_A) return fail("dav_bench_apply: only operator A is timed");
+  if (k <= 0 || k > 64 || reps <= 0) return fail("dav_bench_apply: k must be in 1..64");
+  CHK(collect_events(e));
+  dav_stats saved = e->st;
+  // warm up once, then time whole applies (pack + kernel + reduction; operands resident in HBM)
+  const int saved_level = e->timing_level;
+  e->timing_level = 1;
+  CHK(apply_impl(e, which, DAV_PANEL_V, 0, k, DAV_PANEL_S, 0, false));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  double total = 0, ktotal = 0;
+  int done = 0;
+  while (done < reps) {
+    int batch = std::min(reps - done, N_EVPAIRS / 8);
+    e->st.apply_ms = 0;
+    e->st.apply_kernel_ms = 0;
+    for (int i = 0; i < batch; ++i) CHK(apply_impl(e, which, DAV_PANEL_V, 0, k, DAV_PANEL_S, 0, true));
+    CHK(collect_events(e));
+    total += e->st.apply_ms;
+    ktotal += e->st.apply_kernel_ms;
+    done += batch;
+  }
+  e->timing_level = saved_level;
+  *avg_ms = total / reps;
+  *kernel_ms = ktotal / reps;
+  const bool sym = e->op[which].storage == 1;
+  // per rank: the stored bytes and the flops of the symmetric sweep are dealt out over the ranks like its tiles
+  *bytes = (sym ? (e->op[which].kind == DAV_KIND_DENSE ? 8.0 * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0)
+                : 8.0 * (double)e->nloc * (double)e->n) + 16.0 * (double)e->n * k;
+  *flops = 2.0 * (sym ? (double)e->n / e->nranks : (double)e->nloc) * (double)e->n * k;
+  e->st = saved;
+  return 0;
+}

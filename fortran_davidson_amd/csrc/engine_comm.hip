@@ -1,0 +1,397 @@
+// Engine, communication: RCCL (loaded lazily), communicator set-up, the collective watchdog, the collectives the other parts
+// call (all-gather / all-reduce / reduce-scatter, grouped or not), the agreement check of the driver's control decisions - and,
+// in the TEST build only (-DDAV_TEST_TRANSPORTS=1, csrc/Makefile), the loopback / shared-memory transports.
+#include "engine_internal.h"
+
+Rccl g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return fail(std::string("cannot load librccl.so: ") + dlerror());
+#define SYM(field, name)                                              \
+  *(void**)(&g_rccl.field) = dlsym(lib, name);                        \
+  if (!g_rccl.field) return fail(std::string("librccl.so lacks ") + name);
+  SYM(GetUniqueId, "ncclGetUniqueId")
+  SYM(CommInitRank, "ncclCommInitRank")
+  SYM(CommDestroy, "ncclCommDestroy")
+  SYM(AllGather, "ncclAllGather")
+  SYM(AllReduce, "ncclAllReduce")
+  SYM(Broadcast, "ncclBroadcast")
+  SYM(ReduceScatter, "ncclReduceScatter")
+  SYM(GroupStart, "ncclGroupStart")
+  SYM(GroupEnd, "ncclGroupEnd")
+  SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  g_rccl.lib = lib;
+  return 0;
+}
+
+double wall_seconds() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void watchdog_loop(Watchdog* w) {
+  (void)hipSetDevice(w->device);
+  std::unique_lock<std::mutex> lk(w->mu);
+  while (!w->stop) {
+    w->cv.wait_for(lk, std::chrono::milliseconds(200));
+    const double now = wall_seconds();
+    for (Watchdog::Item& x : w->it) {
+      if (!x.active) continue;
+      const hipError_t q = hipEventQuery(x.ev);
+      if (q == hipSuccess) { x.active = false; continue; }
+      (void)hipGetLastError();
+      if (q == hipErrorNotReady && now - x.t0 > w->timeout_s) {
+        std::fprintf(stderr, "davidson engine: rank %d of %d: collective \"%s\" (number %llu, outer iteration %ld) has not completed after %.0f s "
+                             "- a peer is gone or stuck; ending this process (DAVIDSON_COLLECTIVE_TIMEOUT sets the bound)\n",
+                     w->rank, w->nranks, x.what, (unsigned long long)x.seq, x.iter, now - x.t0);
+        std::fflush(stderr);
+        _exit(124);
+      }
+    }
+  }
+}
+
+extern "C" int dav_comm_unique_id(void* id128) {
+  CHK(rccl_load());
+  ncclUniqueId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int dav_comm_init(dav_handle_t e, const void* id128) {
+  // A single rank needs no communicator.  DAVIDSON_FORCE_RCCL=1 builds a 1-rank communicator anyway so
+  // that every collective of the sharded path (all-gather of the packed block, all-reduce of the Gram
+  // blocks and norms) runs through RCCL on a single-GPU box - used by the GPU tests.
+  if (e->nranks == 1) {
+    const char* force = getenv("DAVIDSON_FORCE_RCCL");
+    if (!force || force[0] != '1') return 0;
+  }
+  CHK(rccl_load());
+  CHK(bind(e));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  NCCLCHK(g_rccl.CommInitRank(&e->comm, e->nranks, id, e->rank));
+  // the watchdog of this communicator's collectives (DAVIDSON_COLLECTIVE_TIMEOUT seconds; default 600, 0 = none)
+  double timeout = 600.0;
+  if (const char* ev = getenv("DAVIDSON_COLLECTIVE_TIMEOUT")) timeout = atof(ev);
+  if (timeout > 0.0 && !e->wd) {
+    Watchdog* w = new Watchdog;
+    w->timeout_s = timeout; w->device = e->device; w->rank = e->rank; w->nranks = e->nranks;
+    for (Watchdog::Item& x : w->it)
+      if (hipEventCreateWithFlags(&x.ev, hipEventDisableTiming) != hipSuccess) {
+        for (Watchdog::Item& y : w->it) if (y.ev) (void)hipEventDestroy(y.ev);
+        delete w;
+        return fail("dav_comm_init: could not create the watchdog's events");
+      }
+    w->th = std::thread(watchdog_loop, w);
+    e->wd = w;
+  }
+  return 0;
+}
+
+// ---- operators ---------------------------------------------------------------------------------
+bool has_comm(E* e) { return e->comm != nullptr || e->lg != nullptr || e->shm != nullptr; }
+int need_comm(E* e) {
+  if (e->nranks > 1 && !has_comm(e)) return fail("multi-rank engine used before dav_comm_init");
+  return 0;
+}
+
+// ---- test transports (build flag DAV_TEST_TRANSPORTS: off in the product lib/libdavidson_hip.so, on in lib/test/libdavidson_hip.so,
+// the build pytest loads because the GPU tests run on a one-GPU box - csrc/Makefile) -------------------------------------
+#ifndef DAV_TEST_TRANSPORTS
+#define DAV_TEST_TRANSPORTS 0
+#endif
+#if DAV_TEST_TRANSPORTS
+// ---- loopback transport: several ranks of one problem as threads of ONE process on ONE GPU ----------
+// Same collective semantics as the RCCL path (in-place all-gather of equal slabs, sum all-reduce with
+// a rank-ordered, hence identical, result on every rank).  It exists so that the row-slab logic of a
+// multi-rank engine (offsets, padding, gathered indices) can be verified on a single-GPU box; the
+// multi-GPU data path is RCCL.
+struct LocalGroup {
+  int n = 0;
+  pthread_barrier_t bar;
+  const double* send[16] = {nullptr};
+};
+
+// ---- shared-memory transport: several ranks of one problem as PROCESSES that share one GPU ---------------
+// Same collective semantics again, through a POSIX shared-memory segment (staging via the host).  It lets
+// the complete multi-process launch flow (torch.distributed.run, id broadcast, one engine per process,
+// barriers) run on a single-GPU box; the multi-GPU data path is RCCL.
+struct ShmHeader {
+  pthread_barrier_t bar;
+  int nranks;
+  size_t slot_doubles;
+};
+struct ShmGroup {
+  ShmHeader* hdr = nullptr;
+  double* slots = nullptr;      // nranks x slot_doubles
+  size_t bytes = 0;
+  std::string name;
+  bool owner = false;
+};
+
+bool has_test_transport(const E* e) { return e->lg != nullptr || e->shm != nullptr; }
+size_t test_transport_max_message(const E* e) { return e->shm ? e->shm->hdr->slot_doubles : (size_t)-1; }
+
+int test_allgather(E* e, const double* send, double* recv, size_t count) {
+  if (e->lg) {
+    LocalGroup* g = e->lg;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    g->send[e->rank] = send;
+    pthread_barrier_wait(&g->bar);
+    for (int p = 0; p < g->n; ++p)
+      if (recv + (size_t)p * count != g->send[p])
+        HIPCHK(hipMemcpyAsync(recv + (size_t)p * count, g->send[p], sizeof(double) * count, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->bar);
+    return 0;
+  }
+  if (e->shm) {
+    ShmGroup* g = e->shm;
+    if (count > g->hdr->slot_doubles) return fail("shared-memory transport: message larger than a slot");
+    HIPCHK(hipMemcpyAsync(g->slots + (size_t)e->rank * g->hdr->slot_doubles, send, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
+    for (int p = 0; p < e->nranks; ++p)
+      if (p != e->rank || recv + (size_t)p * count != send)
+        HIPCHK(hipMemcpyAsync(recv + (size_t)p * count, g->slots + (size_t)p * g->hdr->slot_doubles, sizeof(double) * count,
+                              hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
+    return 0;
+  }
+  return fail("no test transport");
+}
+
+int test_allreduce(E* e, double* buf, size_t count) {
+  if (e->lg) {
+    LocalGroup* g = e->lg;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    g->send[e->rank] = buf;
+    pthread_barrier_wait(&g->bar);
+    std::vector<double> sum(count, 0.0), tmp(count);
+    for (int p = 0; p < g->n; ++p) {
+      HIPCHK(hipMemcpy(tmp.data(), g->send[p], sizeof(double) * count, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < count; ++i) sum[i] += tmp[i];
+    }
+    pthread_barrier_wait(&g->bar);            // everyone has read every buffer
+    HIPCHK(hipMemcpy(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
+  if (e->shm) {
+    ShmGroup* g = e->shm;
+    if (count > g->hdr->slot_doubles) return fail("shared-memory transport: message larger than a slot");
+    HIPCHK(hipMemcpyAsync(g->slots + (size_t)e->rank * g->hdr->slot_doubles, buf, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
+    std::vector<double> sum(count, 0.0);
+    for (int p = 0; p < e->nranks; ++p) {          // rank order: the same bits on every rank
+      const double* src = g->slots + (size_t)p * g->hdr->slot_doubles;
+      for (size_t i = 0; i < count; ++i) sum[i] += src[i];
+    }
+    pthread_barrier_wait(&g->hdr->bar);
+    HIPCHK(hipMemcpy(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
+  return fail("no test transport");
+}
+
+int test_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
+  if (e->lg) {
+    LocalGroup* g = e->lg;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    g->send[e->rank] = send;
+    pthread_barrier_wait(&g->bar);
+    std::vector<double> sum(count, 0.0), tmp(count);
+    for (int p = 0; p < g->n; ++p) {                  // rank order: reproducible
+      HIPCHK(hipMemcpy(tmp.data(), g->send[p] + (size_t)e->rank * count, sizeof(double) * count, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < count; ++i) sum[i] += tmp[i];
+    }
+    pthread_barrier_wait(&g->bar);
+    HIPCHK(hipMemcpy(recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
+  if (e->shm) {
+    ShmGroup* g = e->shm;
+    if (count * (size_t)e->nranks > g->hdr->slot_doubles)
+      return fail("shared-memory transport: reduce-scatter message larger than a slot (test transport: small orders only)");
+    HIPCHK(hipMemcpyAsync(g->slots + (size_t)e->rank * g->hdr->slot_doubles, send, sizeof(double) * count * e->nranks,
+                          hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    pthread_barrier_wait(&g->hdr->bar);
+    std::vector<double> sum(count, 0.0);
+    for (int p = 0; p < e->nranks; ++p) {
+      const double* src = g->slots + (size_t)p * g->hdr->slot_doubles + (size_t)e->rank * count;
+      for (size_t i = 0; i < count; ++i) sum[i] += src[i];
+    }
+    pthread_barrier_wait(&g->hdr->bar);
+    HIPCHK(hipMemcpy(recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  }
+  return fail("no test transport");
+}
+
+void shm_release(E* e) {
+  ShmGroup* g = e->shm;
+  if (!g) return;
+  if (g->hdr) munmap(g->hdr, g->bytes);
+  if (g->owner) shm_unlink(g->name.c_str());
+  delete g;
+  e->shm = nullptr;
+}
+
+extern "C" int dav_comm_init_shm(dav_handle_t e, const char* name) {
+  if (!name || name[0] != '/') return fail("dav_comm_init_shm: name must start with '/'");
+  if (has_comm(e)) return fail("dav_comm_init_shm: the engine already has a transport");
+  if (e->nranks == 1) return 0;
+  // one slot holds the largest message: an all-gathered slab block (nslab x 16) or a small result matrix
+  size_t slot = std::max<size_t>((size_t)e->nslab * 16, std::max(e->gram_doubles, (size_t)e->ncols_pad));
+  if ((size_t)e->ncols_pad * 32 * sizeof(double) * e->nranks <= ((size_t)1 << 30))     // symmetric storage: the partial products
+    slot = std::max(slot, (size_t)e->ncols_pad * 32);
+  size_t bytes = sizeof(ShmHeader) + 64 + sizeof(double) * slot * (size_t)e->nranks;
+  ShmGroup* g = new ShmGroup();
+  g->name = name;
+  g->bytes = bytes;
+  int fd = -1;
+  if (e->rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { delete g; return fail(std::string("dav_comm_init_shm: cannot create ") + name); }
+    g->owner = true;
+  } else {
+    for (int tries = 0; tries < 3000 && fd < 0; ++tries) {       // rank 0 creates it: wait up to 30 s
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd < 0) usleep(10000);
+    }
+    if (fd < 0) { delete g; return fail(std::string("dav_comm_init_shm: cannot open ") + name); }
+    struct stat sb;
+    for (int tries = 0; tries < 3000; ++tries) {                   // ... and sizes it
+      if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+      usleep(10000);
+    }
+  }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { delete g; return fail("dav_comm_init_shm: mmap failed"); }
+  g->hdr = (ShmHeader*)p;
+  g->slots = (double*)((char*)p + ((sizeof(ShmHeader) + 63) / 64) * 64);
+  if (e->rank == 0) {
+    pthread_barrierattr_t attr;
+    pthread_barrierattr_init(&attr);
+    pthread_barrierattr_setpshared(&attr, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(&g->hdr->bar, &attr, (unsigned)e->nranks);
+    pthread_barrierattr_destroy(&attr);
+    g->hdr->slot_doubles = slot;
+    __atomic_store_n(&g->hdr->nranks, e->nranks, __ATOMIC_RELEASE);   // published last
+  } else {
+    for (int tries = 0; tries < 3000 && __atomic_load_n(&g->hdr->nranks, __ATOMIC_ACQUIRE) != e->nranks; ++tries) usleep(10000);
+    if (__atomic_load_n(&g->hdr->nranks, __ATOMIC_ACQUIRE) != e->nranks) { munmap(p, bytes); delete g; return fail("dav_comm_init_shm: rank 0 did not initialise the segment"); }
+  }
+  e->shm = g;
+  pthread_barrier_wait(&g->hdr->bar);
+  return 0;
+}
+
+extern "C" int dav_local_group_join(dav_handle_t* handles, int n) {
+  if (!handles || n < 1 || n > 16) return fail("dav_local_group_join: 1..16 engines");
+  for (int r = 0; r < n; ++r)
+    if (!handles[r] || handles[r]->nranks != n || handles[r]->rank != r || handles[r]->lg || handles[r]->comm)
+      return fail("dav_local_group_join: engine r must be created with rank r of n and have no transport yet");
+  LocalGroup* g = new LocalGroup();
+  g->n = n;
+  pthread_barrier_init(&g->bar, nullptr, (unsigned)n);
+  for (int r = 0; r < n; ++r) handles[r]->lg = g;
+  return 0;
+}
+
+#else
+bool has_test_transport(const E*) { return false; }
+size_t test_transport_max_message(const E*) { return (size_t)-1; }
+int test_allgather(E*, const double*, double*, size_t) { return fail("built without test transports"); }
+int test_allreduce(E*, double*, size_t) { return fail("built without test transports"); }
+int test_reduce_scatter(E*, const double*, double*, size_t) { return fail("built without test transports"); }
+void shm_release(E*) {}
+extern "C" int dav_comm_init_shm(dav_handle_t, const char*) { return fail("dav_comm_init_shm: built without DAV_TEST_TRANSPORTS"); }
+extern "C" int dav_local_group_join(dav_handle_t*, int) { return fail("dav_local_group_join: built without DAV_TEST_TRANSPORTS"); }
+#endif
+
+// recv[p*count .. (p+1)*count) = send of rank p, for every rank (send may alias recv + rank*count)
+#if DAV_TEST_TRANSPORTS
+// test hook (DAV_TEST_STALL_MS): a finite single-thread kernel that holds the stream for that long in front of a
+// collective's event, so that the watchdog can be seen to fire on a one-GPU box
+__global__ void watchdog_stall_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+#endif
+// an event behind the collective(s) just enqueued on `stream`, handed to the watchdog
+int watch_mark(E* e, const char* what, hipStream_t stream) {
+  Watchdog* w = e->wd;
+  if (!w || e->group_depth > 0) return 0;
+#if DAV_TEST_TRANSPORTS
+  if (const char* ev = getenv("DAV_TEST_STALL_MS"))
+    hipLaunchKernelGGL(watchdog_stall_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long)atoll(ev) * 100000ull);   // 100 MHz counter
+#endif
+  std::lock_guard<std::mutex> lk(w->mu);
+  Watchdog::Item& x = w->it[w->seq % Watchdog::NW];
+  if (x.active) return 0;                       // the ring is full of unfinished collectives: the oldest of them is being watched
+  HIPCHK(hipEventRecord(x.ev, stream));
+  x.what = what; x.seq = w->seq++; x.t0 = wall_seconds(); x.iter = e->iter_hint; x.active = true;
+  return 0;
+}
+int coll_group_begin(E* e) {
+  if (e->comm) { NCCLCHK(g_rccl.GroupStart()); ++e->group_depth; }
+  return 0;
+}
+int coll_group_end(E* e, const char* what, hipStream_t stream) {
+  if (e->comm) { NCCLCHK(g_rccl.GroupEnd()); --e->group_depth; CHK(watch_mark(e, what, stream)); }
+  return 0;
+}
+
+int coll_allgather(E* e, const double* send, double* recv, size_t count) {
+  if (has_test_transport(e)) return test_allgather(e, send, recv, count);
+  NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
+  return watch_mark(e, "all-gather", e->stream);
+}
+
+// buf <- sum over ranks of buf (same bits on every rank)
+int coll_allreduce(E* e, double* buf, size_t count) {
+  if (has_test_transport(e)) return test_allreduce(e, buf, count);
+  NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
+  return watch_mark(e, "all-reduce", e->stream);
+}
+
+// recv[0 .. count) = sum over ranks p of send_p[rank*count .. (rank+1)*count)  (send holds nranks chunks)
+int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
+  if (has_test_transport(e)) return test_reduce_scatter(e, send, recv, count);
+  NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
+  return watch_mark(e, "reduce-scatter", e->stream);
+}
+
+extern "C" int dav_ranks_agree(dav_handle_t e, const double* words, int nwords) {
+  if (nwords > 0) e->iter_hint = (long)words[0];       // the driver's first word is its iteration number (the watchdog's message)
+  if (e->nranks <= 1 || !has_comm(e)) return 0;
+  CHK(bind(e));
+  if (nwords <= 0 || (size_t)(2 * nwords) > e->gram_doubles) return fail("dav_ranks_agree: bad word count");
+  // max(x) and max(-x) through the SUM all-reduce of the transports: encode every word of rank r in slot r of a
+  // nranks-wide row, so that the sum reproduces each rank's value
+  const size_t total = (size_t)nwords * e->nranks;
+  if (total > e->gram_doubles) return fail("dav_ranks_agree: too many words");
+  std::vector<double> buf(total, 0.0);
+  for (int i = 0; i < nwords; ++i) buf[(size_t)i * e->nranks + e->rank] = words[i];
+  HIPCHK(hipMemcpyAsync(e->gram_dev, buf.data(), sizeof(double) * total, hipMemcpyHostToDevice, e->stream));
+  CHK(coll_allreduce(e, e->gram_dev, total));
+  HIPCHK(hipMemcpyAsync(buf.data(), e->gram_dev, sizeof(double) * total, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < nwords; ++i)
+    for (int r = 0; r < e->nranks; ++r)
+      if (buf[(size_t)i * e->nranks + r] != words[i])
+        return fail("ranks disagree on a control decision of the driver loop (word " + std::to_string(i) + ": rank " + std::to_string(r) +
+                    " has " + std::to_string(buf[(size_t)i * e->nranks + r]) + ", rank " + std::to_string(e->rank) + " has " +
+                    std::to_string(words[i]) + "): inputs or environment differ between the ranks");
+  return 0;
+}

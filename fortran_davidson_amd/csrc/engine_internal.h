@@ -1,0 +1,281 @@
+// Internal header of the engine translation units (engine*.hip): the engine object, error / check macros, the RCCL entry
+// points, and the functions the parts share.  Nothing here is part of the C ABI (include/davidson_hip.h); internal functions
+// have hidden visibility.
+#pragma once
+#include "../../include/davidson_hip.h"
+#include "kernels.h"
+#include "ingest.h"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <ctime>
+#include <mutex>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#pragma GCC visibility push(hidden)
+extern thread_local std::string g_err;
+int fail(const std::string& msg);
+#define HIPCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      (void)hipGetLastError(); /* reported here: do not leave it for a later hipGetLastError() */     \
+      return fail(std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" +      \
+                  std::to_string(__LINE__) + ")");                                                    \
+    }                                                                                                 \
+  } while (0)
+#define CHK(call)            \
+  do {                       \
+    int r_ = (call);         \
+    if (r_ != 0) return r_;  \
+  } while (0)
+
+// ---- RCCL, loaded lazily so that single-GPU use never touches it ------------------------------------
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+extern Rccl g_rccl;
+int rccl_load();
+#define NCCLCHK(call)                                                                              \
+  do {                                                                                             \
+    ncclResult_t r_ = (call);                                                                      \
+    if (r_ != ncclSuccess) return fail(std::string(#call) + " failed: " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+struct LocalGroup;
+struct ShmGroup;
+
+// ------------------------------------------------------------------------------------------------
+struct OpDesc {
+  int kind = DAV_KIND_NONE;
+  double* a = nullptr;       // dense: nloc_pad x ncols_pad, column-major, lda = nloc_pad
+  uint64_t seed = 0;
+  double sparsity = 0;
+  int use_diag = 0;
+  double diag_val = 0;
+  int trig = 0;
+  double* e_table = nullptr; // device
+  double* diag = nullptr;    // device, nloc_pad (local rows)
+  int storage = 0;           // dense: 0 = full, 1 = symmetric-tiled (lower block triangle)
+  float* a32 = nullptr;      // fp32 copy of the symmetric tiles: operand of the mixed-precision inner sweeps (lazy)
+  bool a32_valid = false, a32_refused = false;
+};
+
+struct SmallBuf {            // device small matrix + pinned staging
+  double* dev = nullptr;
+  double* host = nullptr;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
+constexpr int N_SMALL = 4;
+constexpr int N_EVPAIRS = 64;
+
+struct Watchdog;
+struct dav_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t n = 0, nslab = 0, nloc = 0, row0 = 0, nloc_pad = 0, ncols_pad = 0;
+  int rank = 0, nranks = 1, gev = 0;
+  int max_cols = 0, cols_alloc = 0;
+  int m = 0;
+  double* panel[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t ldp = 0;
+  double* xt = nullptr;
+  int64_t xt_group_stride = 0;
+  double* scratch = nullptr;
+  size_t scratch_doubles = 0;
+  double* gram_dev = nullptr;     // result of gram / norms on device
+  double* gram_host = nullptr;    // pinned, device-visible (zero-copy target of the reduction kernels)
+  double* gram_host_dev = nullptr;  // device address of gram_host
+  size_t gram_doubles = 0;
+  double* gather_dev = nullptr;   // nranks*nslab staging for panel_get / diagonal gather
+  int64_t* idx_dev = nullptr;
+  double* norm_partial = nullptr;
+  double* gjd_ws = nullptr;       // GJD inner-solver workspace (lazy)
+  int storage = 0;                // storage mode for dense operators set after dav_set_storage
+  int sym_nb = 0, sym_nitems = 0; // symmetric-tiled sweep: block rows, work items (runs of tiles)
+  int* sym_items = nullptr;       // device: (I, J0, J1) per item
+  int* sym_row_begin = nullptr;   // device: first item of each block row (nb + 1)
+  double* sym_slab = nullptr;     // device: direct slabs (per item) followed by transposed slabs (per tile)
+  size_t sym_slab_doubles = 0;    // grown on demand: what the largest launch so far needed (schedule x column groups)
+  bool sym_no_pair = false;       // paired 32-column launches did not fit the memory: 16 columns per launch
+  bool sym_no_quad = false;       // ... four column groups (64 columns) per launch did not
+  int inner_bits = 64;            // 32: the sweeps INSIDE the GJD correction read an fp32 copy of the stored tiles (dav_set_inner_precision)
+  // Several ranks: the lower block triangle is dealt out by groups of 4 block rows (what every schedule's super rows
+  // nest in), longest group first to the least loaded rank (sym_group_owners).  row_off[I] = first tile of block row I
+  // in this rank's storage, -1 = another rank's.
+  std::vector<int64_t> sym_row_off_h;
+  int64_t* sym_row_off = nullptr; // device copy
+  int64_t sym_ntiles_local = 0;
+  double* sym_wpart = nullptr;    // several ranks: this rank's partial of the whole product, [rank][column][row of its slab]
+  double* sym_wrecv = nullptr;    // ... and the summed chunk the reduce-scatter hands back (nslab x 32)
+  // RCCL only: a second stream for the collectives of the symmetric sweep, so that the all-gather of the NEXT 32 columns
+  // and the reduce-scatter of the PREVIOUS ones run under the sweep of the current ones; buffers alternate by chunk parity
+  Watchdog* wd = nullptr;         // watches the RCCL collectives of this engine (dav_comm_init)
+  int group_depth = 0;            // inside ncclGroupStart / ncclGroupEnd: the group is marked once, at its end
+  long iter_hint = -1;            // outer iteration the driver is in (dav_ranks_agree), for the watchdog's message
+  hipStream_t comm_stream = nullptr;
+  bool ov_ready = false;          // stream, events and buffers of apply_sym_overlapped all exist
+  hipEvent_t ov_packed[2] = {nullptr, nullptr}, ov_gathered[2] = {nullptr, nullptr}, ov_reduced[2] = {nullptr, nullptr},
+             ov_scattered[2] = {nullptr, nullptr};
+  double* sym_wpart2[2] = {nullptr, nullptr};
+  double* sym_wrecv2[2] = {nullptr, nullptr};
+  // super-row schedules (k_matvec_sym9.hip): plan p = 0 / 1 for R = 2 / 4 block rows per workgroup
+  struct SymPlan {
+    int R = 0, nitems = 0, nsuper = 0;
+    int64_t zslots = 0;               // transposed-partial slots: one per (super row, tile column below its last block row)
+    int* items = nullptr;             // device: (super row, J0, J1, slab slot) per item, longest first
+    int* row_begin = nullptr;         // device: first item of each super row (nsuper + 1)
+    int* zslot_begin = nullptr;       // device: first slot of each super row (nsuper + 1)
+  } sym_plan[2];
+  // device-resident Rayleigh-Ritz (dav_rr_enable): projected matrices, eigenpairs and their operand images stay in HBM
+  bool rr_on = false;
+  int64_t rr_ld = 0;
+  double *rr_H = nullptr, *rr_S = nullptr, *rr_Y = nullptr, *rr_theta = nullptr, *rr_work = nullptr, *rr_info = nullptr;
+  double *rr_Ypk = nullptr, *rr_Y2pk = nullptr, *rr_thpk = nullptr;
+  SmallBuf sm[N_SMALL];
+  size_t small_doubles = 0;
+  ncclComm_t comm = nullptr;
+  LocalGroup* lg = nullptr;       // loopback transport (tests); owned by rank 0
+  ShmGroup* shm = nullptr;        // shared-memory transport (tests of the multi-process launch flow)
+  OpDesc op[2];
+  std::vector<double> diag_host[2];
+  std::vector<int64_t> basis_order;   // indices of the smallest diagonal entries of A (cache of dav_init_basis)
+  // streaming ingest (dav_dense_begin .. dav_dense_end): two pinned row-major staging buffers + device twins
+  double* ing_host[2] = {nullptr, nullptr};
+  double* ing_dev[2] = {nullptr, nullptr};
+  hipEvent_t ing_done[2] = {nullptr, nullptr};
+  bool ing_pending[2] = {false, false};
+  int64_t ing_cap_rows = 0;
+  int ing_flip = 0, ing_which = -1;
+  // statistics
+  dav_stats st{};
+  hipEvent_t ev[N_EVPAIRS][2];
+  double ev_bytes[N_EVPAIRS];
+  int ev_kind[N_EVPAIRS];
+  bool ev_done[N_EVPAIRS];        // end event recorded (a call that fails between begin and end leaves a pair without one)
+  int ev_used = 0, ev_open = 0;
+  int timing_level = 1;           // 0 = nothing, 1 = block matvec only, 2 = every phase
+};
+typedef dav_engine E;
+
+// ---- collective watchdog (failure detection: the reference's convention is print + stop,
+// src/lapack_wrapper.f90:395-408) ------------------------------------------------------------------------------------
+// A rank whose peer died inside RCCL would wait for ever: the collectives are asynchronous stream operations, the host
+// only notices at its next synchronisation, which never returns.  Every RCCL collective (or group of them) is therefore
+// followed by an event, and one thread per engine checks that events complete: one that has not after
+// DAVIDSON_COLLECTIVE_TIMEOUT seconds (default 600; 0 = no watchdog) prints rank / collective / outer iteration and ends
+// the process with exit code 124 - the launcher then tears the group down.  No re-exec, nothing is retried.
+struct Watchdog {
+  static constexpr int NW = 32;
+  struct Item { hipEvent_t ev = nullptr; const char* what = ""; uint64_t seq = 0; double t0 = 0.0; long iter = -1; bool active = false; };
+  Item it[NW];
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool stop = false;
+  uint64_t seq = 0;
+  double timeout_s = 0.0;
+  int device = 0, rank = 0, nranks = 1;
+};
+
+static inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// several small matrices in ONE staging buffer and ONE host-to-device copy (each H2D command costs
+// ~10 us of launch latency, which is what the small phases are made of)
+struct SmallMat {
+  const double* src; int64_t ld; int p, q;   // in
+  double* dev; int64_t ldm;                  // out
+};
+
+// ---- engine.hip ------------------------------------------------------------------------------------------
+int fail(const std::string& msg);
+int bind(E* e);
+int collect_events(E* e);
+int timed_begin(E* e, int kind, double bytes, int* slot);
+int timed_end(E* e, int slot);
+int small_upload(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* ldm_out);
+int small_upload_multi(E* e, int i, SmallMat* mats, int n);
+double* panel_ptr(E* e, int panel, int col);
+int check_panel(E* e, int panel, int c0, int k);
+int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, int nranks);
+// ---- engine_comm.hip -------------------------------------------------------------------------------------
+int rccl_load();
+double wall_seconds();
+void watchdog_loop(Watchdog* w);
+bool has_comm(E* e);
+int need_comm(E* e);
+bool has_test_transport(const E* e);
+size_t test_transport_max_message(const E* e);
+int test_allgather(E* e, const double* send, double* recv, size_t count);
+int test_allreduce(E* e, double* buf, size_t count);
+int test_reduce_scatter(E* e, const double* send, double* recv, size_t count);
+void shm_release(E* e);
+bool has_test_transport(const E*);
+size_t test_transport_max_message(const E*);
+int test_allgather(E*, const double*, double*, size_t);
+int test_allreduce(E*, double*, size_t);
+int test_reduce_scatter(E*, const double*, double*, size_t);
+void shm_release(E*);
+int watch_mark(E* e, const char* what, hipStream_t stream);
+int coll_group_begin(E* e);
+int coll_group_end(E* e, const char* what, hipStream_t stream);
+int coll_allgather(E* e, const double* send, double* recv, size_t count);
+int coll_allreduce(E* e, double* buf, size_t count);
+int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count);
+// ---- engine_operators.hip --------------------------------------------------------------------------------
+int refresh_diag_host(E* e, int which);
+int sym_schedule(const E* e, int kk);
+std::vector<int> sym_group_owners(int nb, int nranks);
+int sym_setup(E* e);
+int sym_diag(E* e, OpDesc& o);
+int sym_ensure_slabs(E* e, size_t doubles);
+int alloc_dense(E* e, int which);
+int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind kind);
+void ingest_release(E* e);
+int ingest_acquire(E* e, double** buf, int64_t* cap_rows);
+int ingest_commit(E* e, int64_t row0, int64_t nrows);
+void ingest_wanted(E* e, int64_t* first, int64_t* count);
+OpParams op_params(const OpDesc& o);
+// ---- engine_apply.hip ------------------------------------------------------------------------------------
+bool inner_f32_tiles(E* e, OpDesc& o);
+void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
+                       int npair, int64_t dstride, int64_t tstride);
+int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner);
+int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner = false);
+int apply_impl(E* e, int which, int src_panel, int c0, int k, int dst_panel, int d0, bool timed);
+// ---- engine_solver.hip -----------------------------------------------------------------------------------
+double* result_target(E* e);
+int result_fetch(E* e, size_t count);
+int gram_impl(E* e, const double* P, int p, const double* Q, int q);
+int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, const double* theta, int method,
+                     double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg, double* theta_out,
+                     double* info_out);
+int restart_contract(E* e, int m, int keep, const double* Mdev, int64_t ldm);
+#pragma GCC visibility pop
