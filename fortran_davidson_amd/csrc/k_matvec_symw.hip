@@ -48,7 +48,7 @@ __device__ __forceinline__ void symw_static_for(F&& f) { symw_static_for_impl(f,
 // (x = +0..1, y = +2..3), the ring ending at a223; X_J operand set s (unit parity), column quad u, group bcb: a[XJ(s,u,bcb) .. +1]
 #define SYMW_RING(k, u) (224 - 16 * NSLOT + 16 * (k) + 4 * (u))
 #define SYMW_XJ(s, u, bcb) (224 + 16 * (s) + 4 * (u) + 2 * (bcb))
-constexpr int symw_fixed_lo(int nb) { return nb == 1 ? 224 - 16 * 8 : 224 - 16 * 4; }   // first fixed register (tests/test_isa_lint.py)
+constexpr int symw_fixed_lo() { return 224 - 16 * 4; }   // first fixed register (tests/test_isa_lint.py)
 
 __device__ double symw_zero_page[16 * 16];     // B operand of a tile that is not there
 
@@ -66,10 +66,21 @@ extern "C" int dav_symw_stamps(unsigned long long* out) {
 #define STAMP(t) do { } while (0)
 #endif
 
+// a wave-uniform value as the compiler must see it to keep it in scalar registers (asm "s" operands): through v_readfirstlane
+__device__ __forceinline__ unsigned symw_uniform(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ int64_t symw_uniform(int64_t x) {
+  const uint64_t u = (uint64_t)x;
+  return (int64_t)(((uint64_t)symw_uniform((unsigned)(u >> 32)) << 32) | symw_uniform((unsigned)u));
+}
+__device__ __forceinline__ const char* symw_uniform(const char* p) { return reinterpret_cast<const char*>(symw_uniform((int64_t)reinterpret_cast<uintptr_t>(p))); }
+
 // descriptor of a raw buffer (stride 0) at p: the hardware adds a per-lane and a scalar 32-bit offset
 __device__ __forceinline__ i32x4 symw_desc(const void* p, int bytes) {
+  // the two address words through v_readfirstlane: the compiler otherwise builds some descriptors in VGPRs (uniform values it
+  // chose to compute on the VALU), which an asm "s" operand cannot take.  A buffer instruction that reads a scalar register
+  // written by a VALU instruction needs 5 wait states in between: the first load of every descriptor opens with s_nop 4.
   const uint64_t a = reinterpret_cast<uint64_t>(p);
-  return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), bytes, 0x00020000};
+  return i32x4{(int)symw_uniform((unsigned)a), (int)symw_uniform((unsigned)(a >> 32) & 0xffffu), bytes, 0x00020000};
 }
 
 template <int NB>
@@ -82,9 +93,9 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   constexpr int NRS = 4;                // 128-row slices = waves
   constexpr unsigned UPJ = SYM_TB / 16; // units (16 tile columns) per tile column
   constexpr unsigned UPS = 4;           // units per 64-column strip of the stage
-  // ring of tile loads: 4 slots / 3 half-steps of lookahead next to 32 columns of operands; 8 / 7 for 16 columns, where the
-  // sweep is HBM-bound (k = 16: 636 cycles per unit in the vmcnt waits of the 4-slot ring) and the registers are there
-  constexpr int NSLOT = NB == 1 ? 8 : 4;
+  // ring of tile loads: 4 slots, 3 half-steps of lookahead (an 8-slot ring at 16 columns, where the sweep is HBM-bound and
+  // the registers are there, measured no gain: the sweep runs at what the partial-sum writes leave of the HBM rate)
+  constexpr int NSLOT = 4;
   constexpr int DEPTH = NSLOT - 1;
   constexpr int TRS = 34, TRW = 16 * TRS, RS = 33;
   constexpr int ZW = 64, ZS = ZW + 2;   // stage strip: 64 tile columns, padded
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 #pragma unroll
       for (int bcb = 0; bcb < NB; ++bcb) acc[hs][par][bcb] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  const unsigned nunits = (unsigned)(J1 - J0) * UPJ;
+  const unsigned nunits = symw_uniform((unsigned)(J1 - J0) * UPJ);
   double* tw = tr + wave * TRW;
   // LDS byte addresses (the low 32 bits of a generic pointer into LDS are the LDS offset)
   unsigned long long st_vm = 0;      // (diagnostic build) cycles in the vmcnt waits of the transpositions
@@ -166,16 +177,20 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   unsigned voff[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) voff[u] = ((4 * u + g) * SYM_TB + 2 * c) * (unsigned)sizeof(double);
-  // tile this wave works on in tile column J: its own if it is stored, else the (stored) tile of block row Imax
-  // (the two block rows a wave can touch: their first tiles are read once - a scalar load per unit would expose its latency)
-  const double* const trow_own = tiles + row_off[have_row ? I : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf;
-  const double* const trow_max = tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf;
+  // Tile this wave works on in tile column J: its own if it is stored, else the (stored) tile of block row Imax (masked).
+  // The tiles of a block row are contiguous in J and a unit is 16 tile columns = 32 KiB of a tile: the sub-block of unit q
+  // starts (J0 16 + q) 32 KiB behind the block row's first tile - linear in q, no division, no per-unit table look-up
+  // (a scalar instruction costs ~5 cycles of matrix-pipe time here, profiles/ubench/r03_fatwave_vgpr_acc.log).
+  constexpr int64_t UNIT_BYTES = 16 * SYM_TB * (int64_t)sizeof(double);
+  const int64_t unit0 = (int64_t)J0 * UPJ * UNIT_BYTES;
+  const char* const trow_own = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[have_row ? I : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
+  const char* const trow_max = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
+  // units whose tile is stored for this wave (J <= I) / lies below the diagonal (J < I): q < qlim_*
+  const unsigned qlim_d = symw_uniform(have_row ? (I >= J0 ? (unsigned)(I - J0 + 1) * UPJ : 0u) : 0u);
+  const unsigned qlim_z = symw_uniform(have_row ? (I > J0 ? (unsigned)(I - J0) * UPJ : 0u) : 0u);
   auto unit_desc = [&](unsigned q) {
     q = q < nunits ? q : nunits - 1;
-    const int J = J0 + (int)(q / UPJ);
-    const unsigned col = (q % UPJ) * 16;
-    const double* ub = ((have_row && J <= I) ? trow_own : trow_max) + (int64_t)J * (SYM_TB * SYM_TB) + col * SYM_TB;
-    return symw_desc(ub, 16 * SYM_TB * (int)sizeof(double));
+    return symw_desc((q < qlim_d ? trow_own : trow_max) + (int64_t)q * UNIT_BYTES, (int)UNIT_BYTES);
   };
   // 4 buffer loads of half-step hs of the unit behind `d` into ring slot SLOT
   auto load_hs = [&](auto slot, const i32x4& d, int hs) {
@@ -186,40 +201,54 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
       const unsigned vo = voff[U];           // (operands of an asm statement inside a generic lambda are not captured by themselves)
       const i32x4 dd = d;
       const int soo = so;
-      asm volatile("buffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
-                   :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
+      if constexpr (U == 0)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
+                     :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
+      else
+        asm volatile("buffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
+                     :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
     });
   };
-  // B operand of the direct product for unit q -> set SET: X_J rows of the unit's 16 tile columns - or, where this wave
-  // has no stored tile (above the diagonal inside the diagonal super block, block row past the end), a page of zeros
+  // B operand of the direct product for unit q -> set SET: X_J rows of the unit's 16 tile columns (16 rows of Xt = 2 KiB per
+  // unit, contiguous over the whole run) - or, where this wave has no stored tile (above the diagonal inside the diagonal
+  // super block, block row past the end), a page of zeros.  One descriptor per 16-column group, the column quad as one of
+  // four constant scalar offsets.
   const unsigned boff = (g * 16 + c) * (unsigned)sizeof(double);
+  const char* const xj0 = symw_uniform(reinterpret_cast<const char*>(xt + (int64_t)J0 * SYM_TB * 16));
+  const char* xjg[NB];               // first X_J row of the run, per 16-column group
+#pragma unroll
+  for (int bcb = 0; bcb < NB; ++bcb) xjg[bcb] = symw_uniform(xj0 + bcb * xt_gstride * (int64_t)sizeof(double));
+  const char* const zpage = symw_uniform(reinterpret_cast<const char*>(symw_zero_page));
+  int xso[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) xso[u] = (4 * u) * 16 * (int)sizeof(double);
   auto load_b = [&](auto set, unsigned q) {
     constexpr int SET = decltype(set)::value;
     q = q < nunits ? q : nunits - 1;
-    const int J = J0 + (int)(q / UPJ);
-    const bool stored = have_row && J <= I;
-    const double* xj = stored ? xt + ((int64_t)J * SYM_TB + (q % UPJ) * 16) * 16 : symw_zero_page;
-    const int gs = stored ? (int)(xt_gstride * (int64_t)sizeof(double)) : 0;
-    const i32x4 d = symw_desc(xj, 0x7fffffff);
-    symw_static_for<4>([&](auto u) {
-      constexpr int U = decltype(u)::value;
-      symw_static_for<NB>([&](auto bcb) {
-        constexpr int B = decltype(bcb)::value;
-        const int so = B * gs + (4 * U) * 16 * (int)sizeof(double);
+    const bool stored = q < qlim_d;
+    symw_static_for<NB>([&](auto bcb) {
+      constexpr int B = decltype(bcb)::value;
+      const char* xj = stored ? xjg[B] + (int64_t)q * (16 * 16 * (int64_t)sizeof(double)) : zpage;
+      const i32x4 d = symw_desc(xj, 16 * 16 * (int)sizeof(double));
+      symw_static_for<4>([&](auto u) {
+        constexpr int U = decltype(u)::value;
         const unsigned bo = boff;
         const i32x4 dd = d;
-        asm volatile("buffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
-                     :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
+        const int so = xso[U];
+        if constexpr (U == 0)
+          asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
+                       :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
+        else
+          asm volatile("buffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
+                       :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
       });
     });
   };
   // LDS transposition of the 32 x 16 sub-block in ring slot SLOT: direct layout (rows 2c, 2c+1 of column 4u + g) -> Gram
   // layout (p[ib][j] = rows 16 ib + 4 g + 2 j, + 1 of column c); wave-private, DS operations of a wave execute in order:
   // no barrier.  YOUNGER = vector-memory operations issued after the slot's loads: what may still be in flight.
-  auto transpose = [&](auto slot, auto younger, f64x2 (&p)[2][2], bool early = false) {
+  auto transpose = [&](auto slot, auto younger, f64x2 (&p)[2][2]) {
     constexpr int SLOT = decltype(slot)::value;
-    // early (the first units of an item): fewer X_J loads have been issued than the steady-state count assumes
-    if (early) asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
 #if DAV_SYMW_STAMPS > 1
     unsigned long long w0, w1;
     STAMP(w0);
@@ -295,6 +324,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   // half-step hs the 4 loads of step s + DEPTH (s = 4 q + hs).  The transposition in half-step hs reads step s + 1: issued
   // after it are DEPTH - 1 steps of loads plus the X_J loads of every unit boundary in between.  X_J(q) itself must have
   // landed before the MFMAs of unit q: after it come the 16 loads of unit q - 1, X_J(q + 1) and the 4 loads of hs = 0.
+  static_assert(DEPTH == 3, "the counts below hold from the first unit on only for a 4-slot ring");
   constexpr auto younger = [](int hs) {
     int nx = 0;
     for (int d = 0; d <= DEPTH - 2; ++d) nx += ((hs - d) % 4 + 4) % 4 == 0;
@@ -317,20 +347,21 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     constexpr int S0 = NSLOT == 8 ? 4 * SET : 0;       // ring slot of this unit's half-step 0
     load_b(std::integral_constant<int, 1 - SET>{}, q + 1);
     const i32x4 udn = unit_desc(q + 3);
-    const int J = J0 + (int)(q / UPJ);
-    const double zm = (have_row && J < I) ? 1.0 : 0.0;   // the tile lies below the diagonal: it feeds the transposed product
+    const double zm = q < qlim_z ? 1.0 : 0.0;            // the tile lies below the diagonal: it feeds the transposed product
     const bool flush_due = (q & 3) == 1 && q >= 5;       // the sums of strip (q - 5) / 4 were staged during unit q - 1
     f64x4 zc[NB];                              // transposed partials of the unit
     symw_static_for<4>([&](auto hsc) {
       constexpr int hs = decltype(hsc)::value;
-      if (hs == 1 && q > 0) {
+      // (unit 0 goes through the exchange of a unit "-1" too: it sums whatever LDS holds into a stage entry that unit 7
+      // overwrites before its strip leaves - cheaper than a branch per unit)
+      if (hs == 1) {
         STAMP(t1);
         __syncthreads();
         STAMP(t2);
         if (flush_due) flush_strip((q - 5) / 4);       // once per four units: not worth registers across MFMAs
         sum_issue(q - 1);
       }
-      if (hs == 2 && q > 0) {
+      if (hs == 2) {
         sum_finish(q - 1);
         STAMP(t3);
       }
@@ -350,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 #if DAV_SYMW_STAMPS > 1
       STAMP(fb);
 #endif
-      transpose(std::integral_constant<int, (S0 + hs + 1) % NSLOT>{}, std::integral_constant<int, younger(hs)>{}, p[(hs + 1) & 1], q < 2);
+      transpose(std::integral_constant<int, (S0 + hs + 1) % NSLOT>{}, std::integral_constant<int, younger(hs)>{}, p[(hs + 1) & 1]);
       const f64x2(&pc)[2][2] = p[hs & 1];
 #if DAV_SYMW_STAMPS > 1
       STAMP(fc);

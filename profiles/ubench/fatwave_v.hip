@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 1) void k(const double* __restrict__ src, doub
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src) + blockIdx.x % 8 * 8192, 0, 65536, 0x00020000);
   unsigned voff[4];
   for (int u = 0; u < 4; ++u) voff[u] = ((4 * u + g) * 256 + 2 * c) * 8;
-  unsigned sacc = iters, vacc = lane;
+  unsigned sacc = 0, vacc = lane;
   unsigned long long t0, t1, r0, r1;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
   for (int it = 0; it < iters; ++it) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void k(const double* __restrict__ src, doub
     }
     if (NSALU > 0) {
 #pragma unroll
-      for (int i = 0; i < NSALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+      for (int i = 0; i < NSALU; ++i) asm volatile("s_add_u32 s90, s90, 1\n\ts_cselect_b32 s91, s90, s91" ::: "s90", "s91", "scc");   // 2 scalar ALU instructions
     }
     if (NVALU > 0) {
 #pragma unroll
@@ -125,7 +125,7 @@ int main() {
   run<false, true, true>("+ 4 ds_write_b128 + 4 ds_read_b128", src, out, cyc, 32);
   run<true, true, true>("+ loads + LDS transposition", src, out, cyc, 32);
   run<true, true, false>("the same, one statement per MFMA", src, out, cyc, 32);
-  run<false, false, true, 16, 0>("+ 16 s_add_u32", src, out, cyc, 32);
+  run<false, false, true, 16, 0>("+ 32 scalar ALU instructions", src, out, cyc, 32);
   run<false, false, true, 0, 16>("+ 16 v_add_u32", src, out, cyc, 32);
   return 0;
 }
