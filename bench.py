@@ -137,17 +137,21 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
     """(HBM bytes per launch, provenance) of a roofline kernel from the rocprofv3 PMC summary under profiles/ - an OFFLINE figure
     (counters cannot be read from inside the run): collected with `rocprofv3 --pmc` on this command at the commit the
     file names (profiles/summarize.py).  `kernel` = name prefix; launches of one kernel are grouped by grid size
-    (column groups per launch) - rank_by_grid 0 = largest grid.  None when no summary matches the workload."""
+    (column groups per launch).  rank_by_grid = i: the i-th largest grid; None: the mean over the grid sizes (a solve
+    launches each of them once: 32 and 64 columns).  None when no summary matches the workload."""
     path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_n{n}_{storage}.json")
     try:
         with open(path) as f:
             doc = json.load(f)
         rows = sorted((k for k in doc["kernels"] if k["kernel"].startswith(kernel)), key=lambda k: -k["grid_size"])
+        prov = {"source": os.path.relpath(path, ROOT), "collected_at_commit": doc.get("commit"),
+                "note": "offline rocprofv3 --pmc pass (2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), not measured in this run"}
+        if rank_by_grid is None:
+            prov.update(kernel=rows[0]["kernel"], per_grid_size={str(r["grid_size"]): r["hbm_bytes_per_launch_corrected"] for r in rows})
+            return round(sum(r["hbm_bytes_per_launch_corrected"] for r in rows) / len(rows)), prov
         row = rows[rank_by_grid]
-        return row["hbm_bytes_per_launch_corrected"], {
-            "kernel": row["kernel"], "grid_size": row["grid_size"], "source": os.path.relpath(path, ROOT),
-            "collected_at_commit": doc.get("commit"),
-            "note": "offline rocprofv3 --pmc pass (2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), not measured in this run"}
+        prov.update(kernel=row["kernel"], grid_size=row["grid_size"])
+        return row["hbm_bytes_per_launch_corrected"], prov
     except Exception:      # noqa: BLE001
         return None, None
 
@@ -330,7 +334,7 @@ def main():
                    "in the solve) / matvec_sym9_kernel<4> (4 block rows, 4x4x4 MFMA) at k <= 8") if storage == "symmetric" else "matvec_dense_kernel<NT> (K1: row slab)"
     hbm_in_solve = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
     mfma_bound = cols_per_launch > 16
-    tr_solve = pmc_traffic(n, storage, "matvec_symw_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", 0) if world == 1 else (None, None)
+    tr_solve = pmc_traffic(n, storage, "matvec_symw_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", None) if world == 1 else (None, None)
     tr_k8 = pmc_traffic(n, storage, "matvec_sym9_kernel<4", 0) if (world == 1 and storage == "symmetric") else (None, None)
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kernel_name,
                 "achieved": round(tflops, 2) if mfma_bound else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9, 1),
@@ -427,6 +431,25 @@ def main():
                     "eigenvalues": [float(x) for x in lam_g[:3]],
                     "note": "sweeps_of_A x ms_per_sweep + the same number of generated-B sweeps is the device floor; the "
                             "remainder is host latency of the inner MINRES (dot-product round trips, small uploads)"}
+                # rooflines of the two sweeps (per 16-column group; B is generated once per group): A against HBM, B against the
+                # integer-VALU bound of its generator (same model as configs4_free)
+                groups = max(int(sg.apply_cols) // 16, 1)
+                ms_b_group = max(dev_other - 0.0, 0.0) / groups
+                evals_b = 0.5 * float(gn) * float(gn)
+                peak_evals = 1024 * 2.4e9 * 64 / 208.0
+                extras["configs3_gjd"]["roofline"] = {
+                    "A_sweeps": {"bound": "hbm (16 columns) / mfma (32, 64)", "ms_per_sweep_end_to_end": round(sg.apply_ms / max(sg.applies, 1), 3),
+                                 "GBps_end_to_end": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9, 1) if sg.apply_ms > 0 else None,
+                                 "frac_of_8TBps": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sg.apply_ms > 0 else None,
+                                 "TFLOPs_kernel_only": round(sg.apply_flops / (sg.apply_kernel_ms * 1e-3) / 1e12, 2) if sg.apply_kernel_ms > 0 else None},
+                    "B_sweeps": {"bound": "valu-int (generator)", "sixteen_column_groups": groups, "ms_per_group_upper_bound": round(ms_b_group, 2),
+                                 "hash_evaluations_per_s_lower_bound": round(evals_b / (ms_b_group * 1e-3), 0) if ms_b_group > 0 else None,
+                                 "peak": round(peak_evals, 0),
+                                 "frac_lower_bound": round(evals_b / (ms_b_group * 1e-3) / peak_evals, 4) if ms_b_group > 0 else None,
+                                 "note": "upper bound on the time: all other device phases of the solve (Gram, panel products) are counted into it"},
+                    "device_floor_seconds": round((sg.apply_ms + dev_other) * 1e-3, 3),
+                    "note": "fp64 MFMA and the generator's integer VALU work share the SIMD's issue port (DESIGN section 0, item 3): a fused A + B pass "
+                            "could hide generation only under the HBM stalls of the 16-column A sweeps"}
                 # opt-in mixed-precision correction path: the inner sweeps of A read an fp32 copy of its tiles
                 try:
                     g.set_inner_precision(32)
