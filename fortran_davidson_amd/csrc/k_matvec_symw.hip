@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   constexpr int ZW = 64, ZS = ZW + 2;   // stage strip: 64 tile columns, padded
   constexpr int NBL = 4 * NB;           // X_J loads per unit
   __shared__ __attribute__((aligned(16))) double tr[NRS * TRW];
-  __shared__ __attribute__((aligned(16))) double zred[2][NRS][NB * 256];   // [unit parity][wave][group][f64x4 per lane]
+  __shared__ __attribute__((aligned(16))) double zred[2][NRS][2][NB * 256];   // [pair parity][wave][unit of the pair][group][f64x4 per lane]
   __shared__ __attribute__((aligned(16))) double zst[2][NB * 16 * ZS];      // [strip parity][block column][tile column]
   static_assert(TRW >= 16 * RS, "the end-of-run exchange reuses the transposition scratch");
 
@@ -272,11 +272,12 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   };
 
   const int64_t zbase = zslot_begin[S];
-  // The exchange of a unit's transposed partials is spread over the NEXT unit, so that what it waits for hides behind
-  // MFMAs: end of unit q: partial -> LDS (no wait); unit q + 1: after half-step 0 one workgroup barrier (the writes are
-  // 2000 cycles old; what is left is the skew between the four waves), the LDS reads of the cross-wave sum are issued,
-  // half-step 1 runs, then the sum is formed and staged.  zred alternates with the unit parity: a wave that runs ahead
-  // cannot overwrite what a slower one still sums, because to get there it has to pass the next barrier.
+  // The exchange of the transposed partials happens once per PAIR of units (the loop body) and is spread over the next
+  // pair, so that what it waits for hides behind MFMAs: end of the pair: both partials -> LDS (no wait); next pair: after
+  // half-step 0 of its first unit ONE workgroup barrier (the writes are 2000 cycles old; what is left is the skew
+  // between the four waves), then per unit of that pair: the LDS reads of one cross-wave sum are issued, half-step 1
+  // runs, the sum is formed and staged.  zred alternates with the pair parity: a wave that runs ahead cannot overwrite
+  // what a slower one still sums, because to get there it has to pass the next barrier.
   unsigned zoff[NB];                 // stage offsets of the entries this lane sums (constant; + 16 (q & 3) + strip parity)
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
-      for (int sl = 0; sl < NRS; ++sl) sreg[sl][t] = zred[qp & 1][sl][wave * (NB * 64) + 64 * t + lane];
+      for (int sl = 0; sl < NRS; ++sl) sreg[sl][t] = zred[(qp >> 1) & 1][sl][qp & 1][wave * (NB * 64) + 64 * t + lane];
   };
   auto sum_finish = [&](unsigned qp) {         // slices in fixed order -> stage
     double* zs = zst[(qp / UPS) & 1] + (qp & 3) * 16;
@@ -339,30 +340,31 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   });
   transpose(std::integral_constant<int, 0>{}, std::integral_constant<int, 4 * (DEPTH - 1)>{}, p[0]);
 
+  f64x4 zcs[2][NB];                  // transposed partials of the two units of a pair
   auto unit = [&](unsigned q, auto set) {
-    constexpr int SET = decltype(set)::value;          // X_J operand set of this unit; the next unit's goes to the other
+    constexpr int SET = decltype(set)::value;          // unit of the pair = X_J operand set; the next unit's goes to the other
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     (void)t0; (void)t1; (void)t2; (void)t3;
     STAMP(t0);
     constexpr int S0 = NSLOT == 8 ? 4 * SET : 0;       // ring slot of this unit's half-step 0
     load_b(std::integral_constant<int, 1 - SET>{}, q + 1);
     const i32x4 udn = unit_desc(q + 3);
-    const double zm = q < qlim_z ? 1.0 : 0.0;            // the tile lies below the diagonal: it feeds the transposed product
-    const bool flush_due = (q & 3) == 1 && q >= 5;       // the sums of strip (q - 5) / 4 were staged during unit q - 1
-    f64x4 zc[NB];                              // transposed partials of the unit
+    // the sums of strip st were staged by unit 4 st + 5; the barrier of unit 4 st + 6 publishes them
+    const bool flush_due = SET == 0 && (q & 3) == 2 && q >= 6;
+    f64x4(&zc)[NB] = zcs[SET];                 // transposed partials of the unit
     symw_static_for<4>([&](auto hsc) {
       constexpr int hs = decltype(hsc)::value;
-      // (unit 0 goes through the exchange of a unit "-1" too: it sums whatever LDS holds into a stage entry that unit 7
-      // overwrites before its strip leaves - cheaper than a branch per unit)
+      // (the first pair goes through the exchange of units "-2" and "-1" too: it sums whatever LDS holds into stage entries
+      // that units 6 and 7 overwrite before their strip leaves - cheaper than a branch per unit)
       if (hs == 1) {
         STAMP(t1);
-        __syncthreads();
+        if constexpr (SET == 0) __syncthreads();
         STAMP(t2);
-        if (flush_due) flush_strip((q - 5) / 4);       // once per four units: not worth registers across MFMAs
-        sum_issue(q - 1);
+        if (flush_due) flush_strip((q - 6) / 4);       // once per four units: not worth registers across MFMAs
+        sum_issue(q - 2);
       }
       if (hs == 2) {
-        sum_finish(q - 1);
+        sum_finish(q - 2);
         STAMP(t3);
       }
       // The compiler counts only its own LDS operations: a wait for this half-step's Gram operands (read one half-step
@@ -420,16 +422,21 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
       st_f[0] += fb - fa; st_f[1] += fc - fb; st_f[2] += fd - fc;
 #endif
     });
-    // z[reg]: tile column col + g + 4 reg, block column c of group bcb, summed over this wave's 128 rows -> LDS
-    {
-      double* zr = &zred[q & 1][wave][0];
-      if constexpr (NB == 2) asm volatile(MFMA_DRAIN : "+v"(zc[0]), "+v"(zc[1]));
-      else asm volatile(MFMA_DRAIN : "+v"(zc[0]));
+    // end of a pair: z[reg] of both units - tile column col + g + 4 reg, block column c of group bcb, summed over this wave's
+    // 128 rows, times 1 or 0 (the tile lies below the diagonal: it feeds the transposed product) -> LDS
+    if constexpr (SET == 1) {
+      if constexpr (NB == 2) asm volatile(MFMA_DRAIN : "+v"(zcs[0][0]), "+v"(zcs[0][1]), "+v"(zcs[1][0]), "+v"(zcs[1][1]));
+      else asm volatile(MFMA_DRAIN : "+v"(zcs[0][0]), "+v"(zcs[1][0]));
 #pragma unroll
-      for (int bcb = 0; bcb < NB; ++bcb) {
-        const f64x4 z = zc[bcb] * zm;
-        *reinterpret_cast<f64x2*>(zr + 256 * bcb + 2 * lane) = f64x2{z[0], z[1]};
-        *reinterpret_cast<f64x2*>(zr + 256 * bcb + 128 + 2 * lane) = f64x2{z[2], z[3]};
+      for (int un = 0; un < 2; ++un) {
+        double* zr = &zred[(q >> 1) & 1][wave][un][0];
+        const double zm = q - 1 + un < qlim_z ? 1.0 : 0.0;
+#pragma unroll
+        for (int bcb = 0; bcb < NB; ++bcb) {
+          const f64x4 z = zcs[un][bcb] * zm;
+          *reinterpret_cast<f64x2*>(zr + 256 * bcb + 2 * lane) = f64x2{z[0], z[1]};
+          *reinterpret_cast<f64x2*>(zr + 256 * bcb + 128 + 2 * lane) = f64x2{z[2], z[3]};
+        }
       }
     }
     ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn;
@@ -447,8 +454,10 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   }
   // every load of the loop has landed before anything else (the compiler does not know about them)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // the last unit's sum, then the last strip
+  // the last pair's sums, then the last strip
   __syncthreads();
+  sum_issue(nunits - 2);
+  sum_finish(nunits - 2);
   sum_issue(nunits - 1);
   sum_finish(nunits - 1);
   __syncthreads();
