@@ -360,3 +360,47 @@ extern "C" int dav_bench_apply2(dav_handle_t e, int which, int k, int reps, doub
   e->st = saved;
   return 0;
 }
+
+// What the HBM of THIS box delivers to a plain streaming kernel: device copy (a = b) and triad (a = b + s c) over arrays of
+// `doubles` entries each (0 = 2^28: 2 GiB per array), read + written bytes per second ("re-measure achievable BW
+// with a stream-triad on the box and report fraction of both").  Allocates and frees its three arrays.
+extern "C" int dav_bench_stream(dav_handle_t e, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps) {
+  CHK(bind(e));
+  const int64_t n = doubles > 0 ? doubles / 2 * 2 : (int64_t)1 << 28;
+  if (reps <= 0) reps = 5;
+  double *a = nullptr, *b = nullptr, *c = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  auto cleanup = [&]() {
+    hipFree(a); hipFree(b); hipFree(c);
+    for (hipEvent_t v : ev) if (v) hipEventDestroy(v);
+  };
+  if (hipMalloc(&a, sizeof(double) * n) != hipSuccess || hipMalloc(&b, sizeof(double) * n) != hipSuccess ||
+      hipMalloc(&c, sizeof(double) * n) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    return fail("dav_bench_stream: could not allocate three arrays of " + std::to_string(n) + " doubles");
+  }
+  double out[2] = {0.0, 0.0};
+  int rc = 0;
+  auto run = [&]() -> int {
+    HIPCHK(hipMemsetAsync(b, 0, sizeof(double) * n, e->stream));
+    HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * n, e->stream));
+    for (int mode = 0; mode < 2; ++mode) {
+      launch_stream(e->stream, mode, a, b, c, 0.5, n);                        // warm-up
+      HIPCHK(hipEventRecord(ev[0], e->stream));
+      for (int r = 0; r < reps; ++r) launch_stream(e->stream, mode, a, b, c, 0.5, n);
+      HIPCHK(hipEventRecord(ev[1], e->stream));
+      HIPCHK(hipEventSynchronize(ev[1]));
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+      out[mode] = (mode == 0 ? 2.0 : 3.0) * 8.0 * (double)n * reps / (ms * 1e-3) / 1e9;
+    }
+    return 0;
+  };
+  rc = run();
+  cleanup();
+  if (rc != 0) return rc;
+  if (copy_GBps) *copy_GBps = out[0];
+  if (triad_GBps) *triad_GBps = out[1];
+  return 0;
+}

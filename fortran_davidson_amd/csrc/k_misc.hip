@@ -104,3 +104,40 @@ void launch_chunk_to_panel(hipStream_t st, const double* src, int64_t lds, int64
   hipLaunchKernelGGL(chunk_to_panel_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, src, lds, nloc, nrows_pad,
                      dst, ldd);
 }
+
+// ---- stream microbenchmark (dav_bench_stream): what the HBM delivers to plain streaming kernels on this box ------------------
+// 16 bytes per lane, four independent accesses in flight per lane, grid-stride over 2048 workgroups (Guideline 11 / 13 of the
+// CDNA4 guide); MODE 0: copy a = b (one read, one write), MODE 1: triad a = b + s c (two reads, one write)
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_kernel(double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c,
+                                                     double s, int64_t n2) {
+  // a workgroup moves contiguous 32 KiB pieces (256 lanes x 16 B x 8 accesses in flight per lane), grid-stride over the pieces
+  constexpr int U = 8;
+  const int64_t piece = 256 * U, stride = (int64_t)gridDim.x * piece;
+  int64_t i = (int64_t)blockIdx.x * piece + threadIdx.x;
+  for (; i + (U - 1) * 256 < n2; i += stride) {
+    f64x2 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(b) + i + u * 256);
+    if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(c) + i + u * 256);
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = x[u] + s * y[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_nontemporal_store(x[u], reinterpret_cast<f64x2*>(a) + i + u * 256);
+  }
+  for (int u = 0; u < U; ++u) {
+    const int64_t j = i + u * 256;
+    if (j < n2 && j >= (n2 / piece) * piece) {                               // the last, partial piece
+      f64x2 x = reinterpret_cast<const f64x2*>(b)[j];
+      if (MODE == 1) x = x + s * reinterpret_cast<const f64x2*>(c)[j];
+      reinterpret_cast<f64x2*>(a)[j] = x;
+    }
+  }
+}
+void launch_stream(hipStream_t st, int mode, double* a, const double* b, const double* c, double s, int64_t n) {
+  if (mode == 0) hipLaunchKernelGGL(stream_kernel<0>, dim3(2048), dim3(256), 0, st, a, b, c, s, n / 2);
+  else hipLaunchKernelGGL(stream_kernel<1>, dim3(2048), dim3(256), 0, st, a, b, c, s, n / 2);
+}

@@ -64,6 +64,8 @@ void launch_unit_columns(hipStream_t st, const int64_t* idx_dev, int k, int64_t 
                          int64_t nrows_pad, double* dst, int64_t ldd);
 void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double* dst, int64_t ldd,
                          int64_t nrows_pad, int k);
+// stream microbenchmark over n doubles (n even): mode 0: a = b, mode 1: a = b + s c
+void launch_stream(hipStream_t st, int mode, double* a, const double* b, const double* c, double s, int64_t n);
 
 
 

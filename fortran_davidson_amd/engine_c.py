@@ -271,6 +271,12 @@ class CEngine:
                                            C.byref(nbytes)))
         return ms.value, nbytes.value
 
+    def bench_stream(self, doubles=0, reps=5):
+        """(copy GB/s, triad GB/s) of plain streaming kernels on this box (read + written bytes)"""
+        cp, tr = C.c_double(), C.c_double()
+        self._chk(self.lib.dav_bench_stream(self.h, C.c_int64(doubles), C.c_int(reps), C.byref(cp), C.byref(tr)))
+        return cp.value, tr.value
+
     def bench_apply2(self, k, reps, which=OP_A):
         """(ms per apply end to end, ms of the block-matvec kernel alone, algorithmic bytes, flops) per apply"""
         ms, kms, nbytes, flops = C.c_double(), C.c_double(), C.c_double(), C.c_double()

@@ -265,6 +265,10 @@ int dav_set_width(dav_handle_t h, int m);
  * (8*S + 16*N*k).  dav_bench_apply2 also returns the average of the block-matvec kernel
  * alone (kernel_ms) and the flops per apply. */
 int dav_bench_apply(dav_handle_t h, int which, int k, int reps, double* avg_ms, double* bytes);
+/* What the HBM of this box delivers to a plain streaming kernel (16 B per lane): device copy a = b and triad a = b + s c over
+ * three arrays of `doubles` entries (0 = 2^28, i.e. 2 GiB each), read + written GB/s - the measured counterpart of the data
+ * sheet's 8 TB/s that every HBM fraction of bench.py is also quoted against. */
+int dav_bench_stream(dav_handle_t h, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps);
 int dav_bench_apply2(dav_handle_t h, int which, int k, int reps, double* avg_ms, double* kernel_ms, double* bytes,
                      double* flops);
 

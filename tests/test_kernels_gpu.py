@@ -528,3 +528,10 @@ print("OK")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root,
                          env=dict(os.environ, PYTHONPATH=root, DAVIDSON_FORCE_RCCL="1", DAV_SYM_R="2", DAV_SYM_OVERLAP="1"))
     assert res.returncode == 0 and "OK" in res.stdout, (res.stdout + res.stderr)[-2000:]
+
+
+def test_stream_microbenchmark_reports_a_plausible_hbm_rate():
+    """dav_bench_stream: copy and triad rates of the box (what bench.py quotes HBM fractions against besides the 8 TB/s spec)."""
+    with fd.CEngine(n=1024, max_cols=16) as e:
+        copy, triad = e.bench_stream(1 << 26, 3)       # 512 MiB per array: beyond the 256 MiB Infinity Cache
+        assert 1000.0 < copy < 8000.0 and 1000.0 < triad < 8000.0, (copy, triad)
