@@ -46,9 +46,11 @@ __device__ __forceinline__ void symw_static_for(F&& f) { symw_static_for_impl(f,
 
 // fixed accumulation registers: ring slot k (step mod NSLOT), load u: a[RING(k,u) .. +3] = rows 2c, 2c+1 of tile column 4u + g
 // (x = +0..1, y = +2..3), the ring ending at a223; X_J operand set s (unit parity), column quad u, group bcb: a[XJ(s,u,bcb) .. +1]
+// Gram-layout (transposed) operands of half-step parity par, 16-row block ib, row pair j: a[P(par,ib,j) .. +3] (x = +0..1, y = +2..3)
 #define SYMW_RING(k, u) (224 - 16 * NSLOT + 16 * (k) + 4 * (u))
 #define SYMW_XJ(s, u, bcb) (224 + 16 * (s) + 4 * (u) + 2 * (bcb))
-constexpr int symw_fixed_lo() { return 224 - 16 * 4; }   // first fixed register (tests/test_isa_lint.py)
+#define SYMW_P(par, ib, j) (128 + 16 * (par) + 8 * (ib) + 4 * (j))
+constexpr int symw_fixed_lo() { return 128; }   // first fixed register (tests/test_isa_lint.py)
 
 __device__ double symw_zero_page[16 * 16];     // B operand of a tile that is not there
 
@@ -167,9 +169,6 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   const unsigned nunits = symw_uniform((unsigned)(J1 - J0) * UPJ);
   double* tw = tr + wave * TRW;
   // LDS byte addresses (the low 32 bits of a generic pointer into LDS are the LDS offset)
-  unsigned long long st_vm = 0;      // (diagnostic build) cycles in the vmcnt waits of the transpositions
-  unsigned long long st_f[3] = {0, 0, 0};   // ... in the tile loads, in the transposition (wait included), in the 32 MFMAs of a half-step
-  (void)st_vm; (void)st_f;
   const unsigned tw_wr = (unsigned)reinterpret_cast<uintptr_t>(tw + g * TRS + 2 * c);    // + 4 u rows of TRS: the direct layout
 
   // tile loads: a scalar descriptor on the unit's 128 x 16 sub-block, constant per-lane offsets (rows 2c, 2c+1 of column
@@ -192,27 +191,27 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     q = q < nunits ? q : nunits - 1;
     return symw_desc((q < qlim_d ? trow_own : trow_max) + (int64_t)q * UNIT_BYTES, (int)UNIT_BYTES);
   };
-  // 4 buffer loads of half-step hs of the unit behind `d` into ring slot SLOT
-  auto load_hs = [&](auto slot, const i32x4& d, int hs) {
-    constexpr int SLOT = decltype(slot)::value;
-    const int so = hs * 32 * (int)sizeof(double);
-    symw_static_for<4>([&](auto u) {
-      constexpr int U = decltype(u)::value;
-      const unsigned vo = voff[U];           // (operands of an asm statement inside a generic lambda are not captured by themselves)
-      const i32x4 dd = d;
-      const int soo = so;
-      if constexpr (U == 0)
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
-                     :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
-      else
-        asm volatile("buffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
-                     :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
-    });
+  // One vector-memory / LDS operation per call, each its own asm statement.  In the loop they are placed BETWEEN the MFMAs, one
+  // behind every second MFMA, never in bursts: next to 64-cycle MFMAs a lone wave pays 1-2 cycles for a memory instruction
+  // that follows an MFMA, but 8 (buffer load) to 29 (DS) cycles for each instruction of a burst - 263 against 12 cycles per
+  // half-step for its 8 loads + 8 DS operations (profiles/ubench/loadcost.hip, r03_loadcost.log).
+  // tile load U of half-step hs of the unit behind `d` into ring slot SLOT
+  auto t_load = [&](auto slot, auto uc, const i32x4& d, int hs) {
+    constexpr int SLOT = decltype(slot)::value, U = decltype(uc)::value;
+    const unsigned vo = voff[U];           // (operands of an asm statement inside a generic lambda are not captured by themselves)
+    const i32x4 dd = d;
+    const int soo = hs * 32 * (int)sizeof(double);
+    if constexpr (U == 0)
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
+                   :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
+    else
+      asm volatile("buffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
+                   :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
   };
-  // B operand of the direct product for unit q -> set SET: X_J rows of the unit's 16 tile columns (16 rows of Xt = 2 KiB per
-  // unit, contiguous over the whole run) - or, where this wave has no stored tile (above the diagonal inside the diagonal
-  // super block, block row past the end), a page of zeros.  One descriptor per 16-column group, the column quad as one of
-  // four constant scalar offsets.
+  // B operand of the direct product for unit q: X_J rows of the unit's 16 tile columns (16 rows of Xt = 2 KiB per unit,
+  // contiguous over the whole run) - or, where this wave has no stored tile (above the diagonal inside the diagonal super
+  // block, block row past the end), a page of zeros.  One descriptor per 16-column group, the column quad as one of four
+  // constant scalar offsets.
   const unsigned boff = (g * 16 + c) * (unsigned)sizeof(double);
   const char* const xj0 = symw_uniform(reinterpret_cast<const char*>(xt + (int64_t)J0 * SYM_TB * 16));
   const char* xjg[NB];               // first X_J row of the run, per 16-column group
@@ -222,53 +221,38 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   int xso[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) xso[u] = (4 * u) * 16 * (int)sizeof(double);
-  auto load_b = [&](auto set, unsigned q) {
-    constexpr int SET = decltype(set)::value;
+  auto x_desc = [&](unsigned q, int bcb) {
     q = q < nunits ? q : nunits - 1;
-    const bool stored = q < qlim_d;
-    symw_static_for<NB>([&](auto bcb) {
-      constexpr int B = decltype(bcb)::value;
-      const char* xj = stored ? xjg[B] + (int64_t)q * (16 * 16 * (int64_t)sizeof(double)) : zpage;
-      const i32x4 d = symw_desc(xj, 16 * 16 * (int)sizeof(double));
-      symw_static_for<4>([&](auto u) {
-        constexpr int U = decltype(u)::value;
-        const unsigned bo = boff;
-        const i32x4 dd = d;
-        const int so = xso[U];
-        if constexpr (U == 0)
-          asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
-                       :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
-        else
-          asm volatile("buffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
-                       :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
-      });
-    });
+    return symw_desc(q < qlim_d ? xjg[bcb] + (int64_t)q * (16 * 16 * (int64_t)sizeof(double)) : zpage, 16 * 16 * (int)sizeof(double));
   };
-  // LDS transposition of the 32 x 16 sub-block in ring slot SLOT: direct layout (rows 2c, 2c+1 of column 4u + g) -> Gram
-  // layout (p[ib][j] = rows 16 ib + 4 g + 2 j, + 1 of column c); wave-private, DS operations of a wave execute in order:
-  // no barrier.  YOUNGER = vector-memory operations issued after the slot's loads: what may still be in flight.
-  auto transpose = [&](auto slot, auto younger, f64x2 (&p)[2][2]) {
-    constexpr int SLOT = decltype(slot)::value;
-#if DAV_SYMW_STAMPS > 1
-    unsigned long long w0, w1;
-    STAMP(w0);
-    asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(decltype(younger)::value) : "memory");
-    STAMP(w1);
-    st_vm += w1 - w0;
-#else
-    asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(decltype(younger)::value) : "memory");
-#endif
-    symw_static_for<4>([&](auto u) {
-      constexpr int U = decltype(u)::value;
-      const unsigned wa = tw_wr;
-      asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3"
-                   :: "v"(wa), "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "i"(4 * U * TRS * (int)sizeof(double)) : "memory");
-    });
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      p[ib][0] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g);
-      p[ib][1] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g + 2);
-    }
+  // column quad U of group B of the unit behind `d` -> X_J operand set SET
+  auto x_load = [&](auto set, auto uc, auto bc, const i32x4& d) {
+    constexpr int SET = decltype(set)::value, U = decltype(uc)::value, B = decltype(bc)::value;
+    const unsigned bo = boff;
+    const i32x4 dd = d;
+    const int so = xso[U];
+    if constexpr (U == 0)
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
+                   :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
+    else
+      asm volatile("buffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
+                   :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
+  };
+  // LDS transposition of the 32 x 16 sub-block in a ring slot: direct layout (rows 2c, 2c+1 of column 4u + g) -> Gram layout
+  // (P(par, ib, j) = rows 16 ib + 4 g + 2 j, + 1 of column c); wave-private, DS operations of a wave execute in order: no
+  // barrier, and the four reads may follow the four writes without a wait.
+  const unsigned tw_rd = (unsigned)reinterpret_cast<uintptr_t>(tw + c * TRS + 4 * g);
+  auto ds_w = [&](auto slot, auto uc) {
+    constexpr int SLOT = decltype(slot)::value, U = decltype(uc)::value;
+    const unsigned wa = tw_wr;
+    asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3"
+                 :: "v"(wa), "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "i"(4 * U * TRS * (int)sizeof(double)) : "memory");
+  };
+  auto ds_r = [&](auto parc, auto tc) {
+    constexpr int PAR = decltype(parc)::value, IB = decltype(tc)::value >> 1, JJ = decltype(tc)::value & 1;
+    const unsigned ra = tw_rd;
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3"
+                 :: "v"(ra), "i"(SYMW_P(PAR, IB, JJ)), "i"(SYMW_P(PAR, IB, JJ) + 3), "i"((16 * IB + 2 * JJ) * (int)sizeof(double)) : "memory");
   };
 
   const int64_t zbase = zslot_begin[S];
@@ -285,8 +269,8 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     const unsigned bcb = e >> 8, half = (e >> 7) & 1, ln = (e & 127) >> 1, jj = e & 1;
     zoff[t] = (16 * bcb + (ln & 15)) * ZS + (ln >> 4) + 4 * (2 * half + jj);
   }
-  unsigned long long st_hs = 0, st_bar = 0, st_sum = 0, st_unit = 0;
-  (void)st_hs; (void)st_bar; (void)st_sum; (void)st_unit;
+  unsigned long long st_hs = 0, st_bar = 0, st_sum = 0, st_unit = 0, st_vm = 0;   // (diagnostic build; st_vm: cycles in the waits that open the half-steps)
+  (void)st_hs; (void)st_bar; (void)st_sum; (void)st_unit; (void)st_vm;
 #ifdef DAV_SYMW_STAMPS
   unsigned long long tk0, tr0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0), "=s"(tr0) :: "memory");
@@ -320,25 +304,25 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     }
   };
 
-  f64x2 p[2][2][2];                 // [half-step parity]: Gram-layout operands of the current and of the next half-step
-  // Vector-memory operations in program order from here on: X_J(0), L(0) .. L(DEPTH - 1); per unit q: X_J(q + 1), then per
-  // half-step hs the 4 loads of step s + DEPTH (s = 4 q + hs).  The transposition in half-step hs reads step s + 1: issued
-  // after it are DEPTH - 1 steps of loads plus the X_J loads of every unit boundary in between.  X_J(q) itself must have
-  // landed before the MFMAs of unit q: after it come the 16 loads of unit q - 1, X_J(q + 1) and the 4 loads of hs = 0.
-  static_assert(DEPTH == 3, "the counts below hold from the first unit on only for a 4-slot ring");
-  constexpr auto younger = [](int hs) {
-    int nx = 0;
-    for (int d = 0; d <= DEPTH - 2; ++d) nx += ((hs - d) % 4 + 4) % 4 == 0;
-    const int y = 4 * (DEPTH - 1) + NBL * nx;
-    return hs == 0 && y > 20 + NBL ? 20 + NBL : y;
-  };
+  // Vector-memory operations in program order from here on: X_J(0), L(0) .. L(DEPTH - 1) (the prologue, in bursts); then per
+  // half-step hs of unit q (step s = 4 q + hs), spread over its MFMAs: the 4 tile loads of step s + DEPTH and, in half-steps 0
+  // and 1, one half (NBL / 2) of the X_J loads of unit q + 1.  The transposition in half-step hs reads step s + 1, whose
+  // loads went out in step s - 2: issued after them are the X_J halves of step s - 2 (they follow the tile loads), the
+  // tile loads of step s - 1 and its X_J half.  X_J(q) is older than the 8 tile loads of steps 4 q - 2, 4 q - 1.
+  static_assert(DEPTH == 3 && NSLOT == 4, "the counts below hold for a 4-slot ring with 3 half-steps of lookahead");
+  constexpr auto younger = [](int hs) { return 4 + (NBL / 2) * (hs == 0 ? 0 : hs == 2 ? 2 : 1); };
   i32x4 ud[3] = {unit_desc(0), unit_desc(1), unit_desc(2)};     // descriptors of units q, q + 1, q + 2
-  load_b(std::integral_constant<int, 0>{}, 0);
+  symw_static_for<NB>([&](auto bc) {
+    const i32x4 d = x_desc(0, decltype(bc)::value);
+    symw_static_for<4>([&](auto uc) { x_load(std::integral_constant<int, 0>{}, uc, bc, d); });
+  });
   symw_static_for<DEPTH>([&](auto sc) {
     constexpr int st = decltype(sc)::value;
-    load_hs(std::integral_constant<int, st % NSLOT>{}, ud[st / 4], st % 4);
+    symw_static_for<4>([&](auto uc) { t_load(std::integral_constant<int, st % NSLOT>{}, uc, ud[st / 4], st % 4); });
   });
-  transpose(std::integral_constant<int, 0>{}, std::integral_constant<int, 4 * (DEPTH - 1)>{}, p[0]);
+  asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
+  symw_static_for<4>([&](auto uc) { ds_w(std::integral_constant<int, 0>{}, uc); });
+  symw_static_for<4>([&](auto tc) { ds_r(std::integral_constant<int, 0>{}, tc); });
 
   f64x4 zcs[2][NB];                  // transposed partials of the two units of a pair
   auto unit = [&](unsigned q, auto set) {
@@ -346,8 +330,9 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     (void)t0; (void)t1; (void)t2; (void)t3;
     STAMP(t0);
-    constexpr int S0 = NSLOT == 8 ? 4 * SET : 0;       // ring slot of this unit's half-step 0
-    load_b(std::integral_constant<int, 1 - SET>{}, q + 1);
+    i32x4 xd[NB];                                      // X_J of unit q + 1
+#pragma unroll
+    for (int bcb = 0; bcb < NB; ++bcb) xd[bcb] = x_desc(q + 1, bcb);
     const i32x4 udn = unit_desc(q + 3);
     // the sums of strip st were staged by unit 4 st + 5; the barrier of unit 4 st + 6 publishes them
     const bool flush_due = SET == 0 && (q & 3) == 2 && q >= 6;
@@ -361,66 +346,84 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
         if constexpr (SET == 0) __syncthreads();
         STAMP(t2);
         if (flush_due) flush_strip((q - 6) / 4);       // once per four units: not worth registers across MFMAs
-        sum_issue(q - 2);
       }
       if (hs == 2) {
         sum_finish(q - 2);
         STAMP(t3);
       }
-      // The compiler counts only its own LDS operations: a wait for this half-step's Gram operands (read one half-step
-      // ago) placed among the MFMAs would, with the transposition's asm DS writes queued behind them, turn into a wait
-      // for those writes.  Named here, the wait lands before the transposition is issued, where it costs nothing.
-      {
-        const f64x2(&pw)[2][2] = p[hs & 1];
-        asm volatile("" :: "v"(pw[0][0]), "v"(pw[0][1]), "v"(pw[1][0]), "v"(pw[1][1]));
-      }
-      // the ring slot being refilled held half-step hs - 1, whose MFMAs have been issued
+      // this half-step's Gram operands (read from LDS during the previous half-step) and the tile entries its transposition
+      // moves (step s + 1) have landed
 #if DAV_SYMW_STAMPS > 1
-      unsigned long long fa, fb, fc, fd;
-      STAMP(fa);
+      unsigned long long w0, w1;
+      STAMP(w0);
 #endif
-      load_hs(std::integral_constant<int, (S0 + hs + DEPTH) % NSLOT>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
+      asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" :: "i"(younger(hs)) : "memory");
 #if DAV_SYMW_STAMPS > 1
-      STAMP(fb);
+      STAMP(w1);
+      st_vm += w1 - w0;
 #endif
-      transpose(std::integral_constant<int, (S0 + hs + 1) % NSLOT>{}, std::integral_constant<int, younger(hs)>{}, p[(hs + 1) & 1]);
-      const f64x2(&pc)[2][2] = p[hs & 1];
-#if DAV_SYMW_STAMPS > 1
-      STAMP(fc);
-#endif
+      if (hs == 1) sum_issue(q - 2);                   // behind the wait: their latency hides under this half-step's MFMAs
+      // The memory operations of the half-step, one slot behind every second MFMA: the transposition of step s + 1 (ring slot
+      // -> LDS -> Gram operands of the other parity; its reads are 16 NB MFMAs old when the next half-step starts), the tile
+      // loads of step s + DEPTH (their ring slot held step s - 1, whose MFMAs and DS reads have been issued), X_J of unit q + 1
+      // (its set was last read by unit q - 1).
+      auto mem_slot = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        using WS = std::integral_constant<int, (hs + 1) % NSLOT>;
+        using LS = std::integral_constant<int, (hs + DEPTH) % NSLOT>;
+        using NP = std::integral_constant<int, (hs + 1) & 1>;
+        using XS = std::integral_constant<int, 1 - SET>;
+        if constexpr (NB == 2) {
+          if constexpr (k < 4) ds_w(WS{}, std::integral_constant<int, k>{});
+          else if constexpr (k < 8) ds_r(NP{}, std::integral_constant<int, k - 4>{});
+          else if constexpr (k < 12) t_load(LS{}, std::integral_constant<int, k - 8>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
+          else if constexpr (hs < 2) x_load(XS{}, std::integral_constant<int, k - 12>{}, std::integral_constant<int, hs>{}, xd[hs < 2 ? hs : 0]);
+        } else {
+          if constexpr (k < 2) {
+            ds_w(WS{}, std::integral_constant<int, 2 * k>{});
+            ds_w(WS{}, std::integral_constant<int, 2 * k + 1>{});
+          } else if constexpr (k < 4) {
+            ds_r(NP{}, std::integral_constant<int, 2 * (k - 2)>{});
+            ds_r(NP{}, std::integral_constant<int, 2 * (k - 2) + 1>{});
+          } else if constexpr (k < 6) {
+            t_load(LS{}, std::integral_constant<int, 2 * (k - 4)>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
+            t_load(LS{}, std::integral_constant<int, 2 * (k - 4) + 1>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
+          } else if constexpr (hs < 2) {
+            x_load(XS{}, std::integral_constant<int, 2 * hs + k - 6>{}, std::integral_constant<int, 0>{}, xd[0]);
+          }
+        }
+      };
       // direct: D[row 2 (g + 4 reg) + par, block column c] += sum_k A[row, tile column 4 u + k] X_J[tile column, c]
       // transposed: Z[tile column g + 4 reg, block column c] += sum_k P[row 16 ib + 4 k + 2 j + xy, tile column] X_I[row, c]
       symw_static_for<4>([&](auto uc) {
         constexpr int u = decltype(uc)::value, ib = u >> 1, j = u & 1;
         symw_static_for<NB>([&](auto bc) {
-          constexpr int bcb = decltype(bc)::value;
+          constexpr int bcb = decltype(bc)::value, gi = u * NB + bcb;
           // (named here: operands of an asm statement inside a generic lambda are not captured by themselves)
           f64x4 &d0 = acc[hs][0][bcb], &d1 = acc[hs][1][bcb], &zz = zc[bcb];
-          const double px = pc[ib][j].x, py = pc[ib][j].y, x0 = xI[hs][ib][j][0][bcb], x1 = xI[hs][ib][j][1][bcb];
-          // four MFMAs as ONE statement (the compiler pads every asm statement with an s_nop): direct (rows of parity 0),
-          // transposed (row pair's first row), direct (parity 1), transposed (second row)
+          const double x0 = xI[hs][ib][j][0][bcb], x1 = xI[hs][ib][j][1][bcb];
+          // two MFMAs per statement: direct (rows of parity 0 / 1), transposed (the row pair's first / second row)
           if constexpr (hs == 0 && u == 0)
-            asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c7:%c8], a[%c11:%c12], %0\n\t"
-                         "v_mfma_f64_16x16x4_f64 %2, %3, %5, 0\n\t"
-                         "v_mfma_f64_16x16x4_f64 %1, a[%c9:%c10], a[%c11:%c12], %1\n\t"
-                         "v_mfma_f64_16x16x4_f64 %2, %4, %6, %2"
-                         : "+v"(d0), "+v"(d1), "=&v"(zz)
-                         : "v"(px), "v"(py), "a"(x0), "a"(x1), "i"(SYMW_RING(S0 + hs, u)), "i"(SYMW_RING(S0 + hs, u) + 1), "i"(SYMW_RING(S0 + hs, u) + 2),
-                           "i"(SYMW_RING(S0 + hs, u) + 3), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1));
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c3:%c4], a[%c5:%c6], %0\n\t"
+                         "v_mfma_f64_16x16x4_f64 %1, a[%c7:%c8], %2, 0"
+                         : "+v"(d0), "=&v"(zz)
+                         : "a"(x0), "i"(SYMW_RING(hs, u)), "i"(SYMW_RING(hs, u) + 1), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1),
+                           "i"(SYMW_P(hs & 1, ib, j)), "i"(SYMW_P(hs & 1, ib, j) + 1));
           else
-            asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c7:%c8], a[%c11:%c12], %0\n\t"
-                         "v_mfma_f64_16x16x4_f64 %2, %3, %5, %2\n\t"
-                         "v_mfma_f64_16x16x4_f64 %1, a[%c9:%c10], a[%c11:%c12], %1\n\t"
-                         "v_mfma_f64_16x16x4_f64 %2, %4, %6, %2"
-                         : "+v"(d0), "+v"(d1), "+v"(zz)
-                         : "v"(px), "v"(py), "a"(x0), "a"(x1), "i"(SYMW_RING(S0 + hs, u)), "i"(SYMW_RING(S0 + hs, u) + 1), "i"(SYMW_RING(S0 + hs, u) + 2),
-                           "i"(SYMW_RING(S0 + hs, u) + 3), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1));
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c3:%c4], a[%c5:%c6], %0\n\t"
+                         "v_mfma_f64_16x16x4_f64 %1, a[%c7:%c8], %2, %1"
+                         : "+v"(d0), "+v"(zz)
+                         : "a"(x0), "i"(SYMW_RING(hs, u)), "i"(SYMW_RING(hs, u) + 1), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1),
+                           "i"(SYMW_P(hs & 1, ib, j)), "i"(SYMW_P(hs & 1, ib, j) + 1));
+          mem_slot(std::integral_constant<int, 2 * gi>{});
+          asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c3:%c4], a[%c5:%c6], %0\n\t"
+                       "v_mfma_f64_16x16x4_f64 %1, a[%c7:%c8], %2, %1"
+                       : "+v"(d1), "+v"(zz)
+                       : "a"(x1), "i"(SYMW_RING(hs, u) + 2), "i"(SYMW_RING(hs, u) + 3), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1),
+                         "i"(SYMW_P(hs & 1, ib, j) + 2), "i"(SYMW_P(hs & 1, ib, j) + 3));
+          mem_slot(std::integral_constant<int, 2 * gi + 1>{});
         });
       });
-#if DAV_SYMW_STAMPS > 1
-      STAMP(fd);
-      st_f[0] += fb - fa; st_f[1] += fc - fb; st_f[2] += fd - fc;
-#endif
     });
     // end of a pair: z[reg] of both units - tile column col + g + 4 reg, block column c of group bcb, summed over this wave's
     // 128 rows, times 1 or 0 (the tile lies below the diagonal: it feeds the transposed product) -> LDS
@@ -452,8 +455,8 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     unit(q, std::integral_constant<int, 0>{});
     unit(q + 1, std::integral_constant<int, 1>{});
   }
-  // every load of the loop has landed before anything else (the compiler does not know about them)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // every load and LDS read of the loop has landed before anything else (the compiler does not know about them)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   // the last pair's sums, then the last strip
   __syncthreads();
   sum_issue(nunits - 2);
@@ -470,7 +473,6 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     atomicAdd(&symw_stamp[3], (unsigned long long)nunits);
     atomicAdd(&symw_stamp[4], tk1 - tk0); atomicAdd(&symw_stamp[5], tr1 - tr0); atomicAdd(&symw_stamp[6], st_vm);
     atomicAdd(&symw_stamp[10], st_unit); atomicAdd(&symw_stamp[11], 1ull);
-    atomicAdd(&symw_stamp[7], st_f[0]); atomicAdd(&symw_stamp[8], st_f[1]); atomicAdd(&symw_stamp[9], st_f[2]);
   }
 #endif
 
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   }
   // block rows of the super row past the end of the matrix: their slab rows are read by nobody
   // the fixed registers belong to this kernel: the descriptor must allocate all 256 accumulation registers
-  asm volatile("" ::: "a160", "a255");
+  asm volatile("" ::: "a128", "a255");
 }
 
 void launch_matvec_symw(hipStream_t st, int nbw, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,

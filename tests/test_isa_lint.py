@@ -3,8 +3,8 @@
 The kernel's MFMAs are inline assembly (the compiler does not know them as such, so it neither pads their hazards nor keeps
 out of the accumulation registers the kernel names literally).  The kernel header states the rules that make that safe; this
 test checks the EMITTED code for them:
-  1. no compiler-generated instruction (outside ;;#ASMSTART / ;;#ASMEND) names the kernel's fixed registers (a[160:255] with 32
-     columns per workgroup, a[96:255] with 16);
+  1. no compiler-generated instruction (outside ;;#ASMSTART / ;;#ASMEND) names the kernel's fixed registers (a[128:255]: Gram-layout operands,
+     load ring, X_J operand);
   2. no VALU instruction writes a register that an MFMA reads within the next two instructions (2 wait states);
   3. a register written by an MFMA is read by a non-MFMA instruction only after an `s_nop 15` (+ `s_nop 3`): 18+ wait states;
   4. no register moves between the halves (v_accvgpr_*) and no scratch in the kernel at all.
@@ -19,7 +19,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fortran_davidson_amd", "csrc", "k_matvec_symw.hip")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FIXED_LO = {1: 160, 2: 160}   # first fixed accumulation register (symw_fixed_lo in the kernel file), by columns / 16 per workgroup
+FIXED_LO = {1: 128, 2: 128}   # first fixed accumulation register (symw_fixed_lo in the kernel file), by columns / 16 per workgroup
 
 
 def _regs(tok):
