@@ -196,12 +196,12 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   // that follows an MFMA, but 8 (buffer load) to 29 (DS) cycles for each instruction of a burst - 263 against 12 cycles per
   // half-step for its 8 loads + 8 DS operations (profiles/ubench/loadcost.hip, r03_loadcost.log).
   // tile load U of half-step hs of the unit behind `d` into ring slot SLOT
-  auto t_load = [&](auto slot, auto uc, const i32x4& d, int hs) {
+  auto t_load = [&](auto slot, auto uc, const i32x4& d, int hs, auto fresh) {
     constexpr int SLOT = decltype(slot)::value, U = decltype(uc)::value;
     const unsigned vo = voff[U];           // (operands of an asm statement inside a generic lambda are not captured by themselves)
     const i32x4 dd = d;
     const int soo = hs * 32 * (int)sizeof(double);
-    if constexpr (U == 0)
+    if constexpr (U == 0 && decltype(fresh)::value)
       asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
                    :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
     else
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     return symw_desc(q < qlim_d ? xjg[bcb] + (int64_t)q * (16 * 16 * (int64_t)sizeof(double)) : zpage, 16 * 16 * (int)sizeof(double));
   };
   // column quad U of group B of the unit behind `d` -> X_J operand set SET
-  auto x_load = [&](auto set, auto uc, auto bc, const i32x4& d) {
+  auto x_load = [&](auto set, auto uc, auto bc, const i32x4& d, auto fresh) {
     constexpr int SET = decltype(set)::value, U = decltype(uc)::value, B = decltype(bc)::value;
     const unsigned bo = boff;
     const i32x4 dd = d;
     const int so = xso[U];
-    if constexpr (U == 0)
+    if constexpr (U == 0 && decltype(fresh)::value)
       asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c0:%c1], %2, %3, %4 offen"
                    :: "i"(SYMW_XJ(SET, U, B)), "i"(SYMW_XJ(SET, U, B) + 1), "v"(bo), "s"(dd), "s"(so) : "memory");
     else
@@ -256,12 +256,16 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   };
 
   const int64_t zbase = zslot_begin[S];
-  // The exchange of the transposed partials happens once per PAIR of units (the loop body) and is spread over the next
-  // pair, so that what it waits for hides behind MFMAs: end of the pair: both partials -> LDS (no wait); next pair: after
-  // half-step 0 of its first unit ONE workgroup barrier (the writes are 2000 cycles old; what is left is the skew
-  // between the four waves), then per unit of that pair: the LDS reads of one cross-wave sum are issued, half-step 1
-  // runs, the sum is formed and staged.  zred alternates with the pair parity: a wave that runs ahead cannot overwrite
-  // what a slower one still sums, because to get there it has to pass the next barrier.
+  // The exchange of the transposed partials happens once per PAIR of units and is spread over the NEXT pair, every piece of it
+  // in a slot between MFMAs: half-step 0 of the next pair's first unit: both partials of the pair -> LDS (they are thousands of
+  // cycles old: no drain, no wait; the accumulators alternate with the pair parity); ONE workgroup barrier before its half-step
+  // 1 (what it waits for is the skew between the four waves); then per unit of that pair: the LDS reads of one cross-wave sum
+  // (half-step 1), the sum in fixed slice order, masked, -> stage (half-step 2).  zred alternates with the pair parity: a wave
+  // that runs ahead cannot overwrite what a slower one still sums, because to get there it has to pass the next barrier.
+  // Mask: the slices of block row r feed the transposed product of unit q only where its tile lies below the diagonal.
+  unsigned qz[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) qz[r] = symw_uniform(I0 + r <= Imax && I0 + r > J0 ? (unsigned)(I0 + r - J0) * UPJ : 0u);
   unsigned zoff[NB];                 // stage offsets of the entries this lane sums (constant; + 16 (q & 3) + strip parity)
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
@@ -276,16 +280,21 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0), "=s"(tr0) :: "memory");
 #endif
   double sreg[NRS][NB];              // the slices of the entries this lane sums, on their way from LDS
-  auto sum_issue = [&](unsigned qp) {          // cross-wave sum of unit qp: LDS reads
+  auto sum_issue = [&](unsigned qp, int sl) {  // cross-wave sum of unit qp: LDS reads of slice sl
 #pragma unroll
-    for (int t = 0; t < NB; ++t)
-#pragma unroll
-      for (int sl = 0; sl < NRS; ++sl) sreg[sl][t] = zred[(qp >> 1) & 1][sl][qp & 1][wave * (NB * 64) + 64 * t + lane];
+    for (int t = 0; t < NB; ++t) sreg[sl][t] = zred[(qp >> 1) & 1][sl][qp & 1][wave * (NB * 64) + 64 * t + lane];
   };
-  auto sum_finish = [&](unsigned qp) {         // slices in fixed order -> stage
+  auto sum_finish = [&](unsigned qp, int t) {  // slices in fixed order, times 1 or 0 -> stage
     double* zs = zst[(qp / UPS) & 1] + (qp & 3) * 16;
-#pragma unroll
-    for (int t = 0; t < NB; ++t) zs[zoff[t]] = ((sreg[0][t] + sreg[1][t]) + sreg[2][t]) + sreg[3][t];
+    const double m0 = qp < qz[0] ? 1.0 : 0.0, m1 = qp < qz[1] ? 1.0 : 0.0;
+    zs[zoff[t]] = __builtin_fma(m1, sreg[3][t], __builtin_fma(m1, sreg[2][t], __builtin_fma(m0, sreg[1][t], m0 * sreg[0][t])));
+  };
+  // both partials of a pair (un = unit of the pair) -> zred[parity of the pair]: z[reg] = tile column col + g + 4 reg, block
+  // column c of group bcb, summed over this wave's 128 rows
+  auto z_write = [&](const f64x4 (&z)[2][NB], unsigned pair, int w) {
+    const int un = w / (2 * NB), bcb = (w / 2) % NB, half = w & 1;
+    double* zr = &zred[pair & 1][wave][un][0];
+    *reinterpret_cast<f64x2*>(zr + 256 * bcb + 128 * half + 2 * lane) = f64x2{z[un][bcb][2 * half], z[un][bcb][2 * half + 1]};
   };
   // strip st of the run (64 tile columns x 16 NB block columns = 512 NB f64x2 = 2 NB per thread): stage -> slabT
   auto flush_strip = [&](unsigned st) {
@@ -314,19 +323,26 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   i32x4 ud[3] = {unit_desc(0), unit_desc(1), unit_desc(2)};     // descriptors of units q, q + 1, q + 2
   symw_static_for<NB>([&](auto bc) {
     const i32x4 d = x_desc(0, decltype(bc)::value);
-    symw_static_for<4>([&](auto uc) { x_load(std::integral_constant<int, 0>{}, uc, bc, d); });
+    symw_static_for<4>([&](auto uc) { x_load(std::integral_constant<int, 0>{}, uc, bc, d, std::true_type{}); });
   });
   symw_static_for<DEPTH>([&](auto sc) {
     constexpr int st = decltype(sc)::value;
-    symw_static_for<4>([&](auto uc) { t_load(std::integral_constant<int, st % NSLOT>{}, uc, ud[st / 4], st % 4); });
+    symw_static_for<4>([&](auto uc) { t_load(std::integral_constant<int, st % NSLOT>{}, uc, ud[st / 4], st % 4, std::true_type{}); });
   });
   asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
   symw_static_for<4>([&](auto uc) { ds_w(std::integral_constant<int, 0>{}, uc); });
   symw_static_for<4>([&](auto tc) { ds_r(std::integral_constant<int, 0>{}, tc); });
 
-  f64x4 zcs[2][NB];                  // transposed partials of the two units of a pair
-  auto unit = [&](unsigned q, auto set) {
+  f64x4 zcs[2][2][NB];               // transposed partials: [pair parity][unit of the pair][group]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int un = 0; un < 2; ++un)
+#pragma unroll
+      for (int bcb = 0; bcb < NB; ++bcb) zcs[i][un][bcb] = f64x4{0.0, 0.0, 0.0, 0.0};
+  auto unit = [&](unsigned q, auto set, auto ppc) {
     constexpr int SET = decltype(set)::value;          // unit of the pair = X_J operand set; the next unit's goes to the other
+    constexpr int PP = decltype(ppc)::value;           // parity of the pair
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     (void)t0; (void)t1; (void)t2; (void)t3;
     STAMP(t0);
@@ -336,21 +352,18 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     const i32x4 udn = unit_desc(q + 3);
     // the sums of strip st were staged by unit 4 st + 5; the barrier of unit 4 st + 6 publishes them
     const bool flush_due = SET == 0 && (q & 3) == 2 && q >= 6;
-    f64x4(&zc)[NB] = zcs[SET];                 // transposed partials of the unit
+    f64x4(&zc)[NB] = zcs[PP][SET];             // transposed partials of the unit
     symw_static_for<4>([&](auto hsc) {
       constexpr int hs = decltype(hsc)::value;
-      // (the first pair goes through the exchange of units "-2" and "-1" too: it sums whatever LDS holds into stage entries
-      // that units 6 and 7 overwrite before their strip leaves - cheaper than a branch per unit)
+      // (the first pair goes through the exchange of units "-2" and "-1" too: zeros into stage entries that units 6 and 7
+      // overwrite before their strip leaves - cheaper than a branch per unit)
       if (hs == 1) {
         STAMP(t1);
         if constexpr (SET == 0) __syncthreads();
         STAMP(t2);
         if (flush_due) flush_strip((q - 6) / 4);       // once per four units: not worth registers across MFMAs
       }
-      if (hs == 2) {
-        sum_finish(q - 2);
-        STAMP(t3);
-      }
+      if (hs == 2) STAMP(t3);
       // this half-step's Gram operands (read from LDS during the previous half-step) and the tile entries its transposition
       // moves (step s + 1) have landed
 #if DAV_SYMW_STAMPS > 1
@@ -362,7 +375,6 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
       STAMP(w1);
       st_vm += w1 - w0;
 #endif
-      if (hs == 1) sum_issue(q - 2);                   // behind the wait: their latency hides under this half-step's MFMAs
       // The memory operations of the half-step, one slot behind every second MFMA: the transposition of step s + 1 (ring slot
       // -> LDS -> Gram operands of the other parity; its reads are 16 NB MFMAs old when the next half-step starts), the tile
       // loads of step s + DEPTH (their ring slot held step s - 1, whose MFMAs and DS reads have been issued), X_J of unit q + 1
@@ -373,11 +385,16 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
         using LS = std::integral_constant<int, (hs + DEPTH) % NSLOT>;
         using NP = std::integral_constant<int, (hs + 1) & 1>;
         using XS = std::integral_constant<int, 1 - SET>;
+        constexpr std::false_type old{};                // descriptors of the loop are scalar-ALU results: no wait states needed
         if constexpr (NB == 2) {
           if constexpr (k < 4) ds_w(WS{}, std::integral_constant<int, k>{});
           else if constexpr (k < 8) ds_r(NP{}, std::integral_constant<int, k - 4>{});
-          else if constexpr (k < 12) t_load(LS{}, std::integral_constant<int, k - 8>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
-          else if constexpr (hs < 2) x_load(XS{}, std::integral_constant<int, k - 12>{}, std::integral_constant<int, hs>{}, xd[hs < 2 ? hs : 0]);
+          else if constexpr (k < 12) t_load(LS{}, std::integral_constant<int, k - 8>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4, old);
+          else if constexpr (hs < 2) x_load(XS{}, std::integral_constant<int, k - 12>{}, std::integral_constant<int, hs>{}, xd[hs < 2 ? hs : 0], old);
+          // the exchange (compiler-visible LDS operations: the asm statements around them keep them in their slots)
+          if constexpr (SET == 0 && hs == 0 && k < 8) z_write(zcs[1 - PP], (q >> 1) - 1, k);
+          if constexpr (hs == 1 && k >= 8 && k < 12) sum_issue(q - 2, k - 8);
+          if constexpr (hs == 2 && (k == 12 || k == 14)) sum_finish(q - 2, (k - 12) / 2);
         } else {
           if constexpr (k < 2) {
             ds_w(WS{}, std::integral_constant<int, 2 * k>{});
@@ -386,11 +403,14 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
             ds_r(NP{}, std::integral_constant<int, 2 * (k - 2)>{});
             ds_r(NP{}, std::integral_constant<int, 2 * (k - 2) + 1>{});
           } else if constexpr (k < 6) {
-            t_load(LS{}, std::integral_constant<int, 2 * (k - 4)>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
-            t_load(LS{}, std::integral_constant<int, 2 * (k - 4) + 1>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4);
+            t_load(LS{}, std::integral_constant<int, 2 * (k - 4)>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4, old);
+            t_load(LS{}, std::integral_constant<int, 2 * (k - 4) + 1>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4, old);
           } else if constexpr (hs < 2) {
-            x_load(XS{}, std::integral_constant<int, 2 * hs + k - 6>{}, std::integral_constant<int, 0>{}, xd[0]);
+            x_load(XS{}, std::integral_constant<int, 2 * hs + k - 6>{}, std::integral_constant<int, 0>{}, xd[0], old);
           }
+          if constexpr (SET == 0 && hs == 0 && k >= 4) z_write(zcs[1 - PP], (q >> 1) - 1, k - 4);
+          if constexpr (hs == 1 && k >= 4) sum_issue(q - 2, k - 4);
+          if constexpr (hs == 2 && k == 6) sum_finish(q - 2, 0);
         }
       };
       // direct: D[row 2 (g + 4 reg) + par, block column c] += sum_k A[row, tile column 4 u + k] X_J[tile column, c]
@@ -425,23 +445,6 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
         });
       });
     });
-    // end of a pair: z[reg] of both units - tile column col + g + 4 reg, block column c of group bcb, summed over this wave's
-    // 128 rows, times 1 or 0 (the tile lies below the diagonal: it feeds the transposed product) -> LDS
-    if constexpr (SET == 1) {
-      if constexpr (NB == 2) asm volatile(MFMA_DRAIN : "+v"(zcs[0][0]), "+v"(zcs[0][1]), "+v"(zcs[1][0]), "+v"(zcs[1][1]));
-      else asm volatile(MFMA_DRAIN : "+v"(zcs[0][0]), "+v"(zcs[1][0]));
-#pragma unroll
-      for (int un = 0; un < 2; ++un) {
-        double* zr = &zred[(q >> 1) & 1][wave][un][0];
-        const double zm = q - 1 + un < qlim_z ? 1.0 : 0.0;
-#pragma unroll
-        for (int bcb = 0; bcb < NB; ++bcb) {
-          const f64x4 z = zcs[un][bcb] * zm;
-          *reinterpret_cast<f64x2*>(zr + 256 * bcb + 2 * lane) = f64x2{z[0], z[1]};
-          *reinterpret_cast<f64x2*>(zr + 256 * bcb + 128 + 2 * lane) = f64x2{z[2], z[3]};
-        }
-      }
-    }
     ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn;
 #ifdef DAV_SYMW_STAMPS
     unsigned long long t4;
@@ -450,19 +453,28 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     st_unit += t4 - t0;
 #endif
   };
-  // nunits is a multiple of 16: two units per trip, the X_J operand sets alternate
-  for (unsigned q = 0; q < nunits; q += 2) {
-    unit(q, std::integral_constant<int, 0>{});
-    unit(q + 1, std::integral_constant<int, 1>{});
+  // nunits is a multiple of 16: two pairs per trip (the transposed partials alternate between two register sets)
+  for (unsigned q = 0; q < nunits; q += 4) {
+    unit(q, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    unit(q + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    unit(q + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    unit(q + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
   }
   // every load and LDS read of the loop has landed before anything else (the compiler does not know about them)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  // the last pair's sums, then the last strip
+  // the last pair's partials, its sums, then the last strip
+  if constexpr (NB == 2) asm volatile(MFMA_DRAIN : "+v"(zcs[1][0][0]), "+v"(zcs[1][0][1]), "+v"(zcs[1][1][0]), "+v"(zcs[1][1][1]));
+  else asm volatile(MFMA_DRAIN : "+v"(zcs[1][0][0]), "+v"(zcs[1][1][0]));
+#pragma unroll
+  for (int w = 0; w < 4 * NB; ++w) z_write(zcs[1], (nunits >> 1) - 1, w);
   __syncthreads();
-  sum_issue(nunits - 2);
-  sum_finish(nunits - 2);
-  sum_issue(nunits - 1);
-  sum_finish(nunits - 1);
+#pragma unroll
+  for (int un = 2; un >= 1; --un) {
+#pragma unroll
+    for (int sl = 0; sl < NRS; ++sl) sum_issue(nunits - un, sl);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) sum_finish(nunits - un, t);
+  }
   __syncthreads();
   flush_strip(nunits / UPS - 1);
 #ifdef DAV_SYMW_STAMPS
