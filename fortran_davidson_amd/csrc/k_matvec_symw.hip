@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     const unsigned bcb = e >> 8, half = (e >> 7) & 1, ln = (e & 127) >> 1, jj = e & 1;
     zoff[t] = (16 * bcb + (ln & 15)) * ZS + (ln >> 4) + 4 * (2 * half + jj);
   }
-  unsigned long long st_hs = 0, st_bar = 0, st_sum = 0, st_unit = 0, st_vm = 0;   // (diagnostic build; st_vm: cycles in the waits that open the half-steps)
-  (void)st_hs; (void)st_bar; (void)st_sum; (void)st_unit; (void)st_vm;
+  unsigned long long st_hs = 0, st_bar = 0, st_sum = 0, st_unit = 0, st_vm = 0, st_mf = 0;   // (diagnostic build; st_vm: cycles in the waits that open the half-steps, st_mf: in their MFMAs + slots)
+  (void)st_hs; (void)st_bar; (void)st_sum; (void)st_unit; (void)st_vm; (void)st_mf;
 #ifdef DAV_SYMW_STAMPS
   unsigned long long tk0, tr0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk0), "=s"(tr0) :: "memory");
@@ -413,6 +413,10 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
           if constexpr (hs == 2 && k == 6) sum_finish(q - 2, 0);
         }
       };
+#if DAV_SYMW_STAMPS > 1
+      unsigned long long fa, fb;
+      STAMP(fa);
+#endif
       // direct: D[row 2 (g + 4 reg) + par, block column c] += sum_k A[row, tile column 4 u + k] X_J[tile column, c]
       // transposed: Z[tile column g + 4 reg, block column c] += sum_k P[row 16 ib + 4 k + 2 j + xy, tile column] X_I[row, c]
       symw_static_for<4>([&](auto uc) {
@@ -444,6 +448,10 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
           mem_slot(std::integral_constant<int, 2 * gi + 1>{});
         });
       });
+#if DAV_SYMW_STAMPS > 1
+      STAMP(fb);
+      st_mf += fb - fa;
+#endif
     });
     ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn;
 #ifdef DAV_SYMW_STAMPS
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk1), "=s"(tr1) :: "memory");
     atomicAdd(&symw_stamp[0], st_hs); atomicAdd(&symw_stamp[1], st_bar); atomicAdd(&symw_stamp[2], st_sum);
     atomicAdd(&symw_stamp[3], (unsigned long long)nunits);
-    atomicAdd(&symw_stamp[4], tk1 - tk0); atomicAdd(&symw_stamp[5], tr1 - tr0); atomicAdd(&symw_stamp[6], st_vm);
+    atomicAdd(&symw_stamp[4], tk1 - tk0); atomicAdd(&symw_stamp[5], tr1 - tr0); atomicAdd(&symw_stamp[6], st_vm); atomicAdd(&symw_stamp[9], st_mf);
     atomicAdd(&symw_stamp[10], st_unit); atomicAdd(&symw_stamp[11], 1ull);
   }
 #endif

@@ -16,7 +16,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   "v_mfma_f64_16x16x4_f64 %4, " A0 ", " B0 ", %4\n\tv_mfma_f64_16x16x4_f64 %5, " A0 ", " B1 ", %5\n\t"                   \
   "v_mfma_f64_16x16x4_f64 %6, " A1 ", " B0 ", %6\n\tv_mfma_f64_16x16x4_f64 %7, " A1 ", " B1 ", %7\n\t"
 
-enum { NONE = 0, BUF_OFFEN = 1, BUF_TID = 2, GLOBAL_SADDR = 3, BUF_LDS = 4, BUF_OFFEN_SPREAD = 5, BUF_TID_SPREAD = 6, BUF_OFFEN_X2 = 7, BUF_TID_X2 = 8, DS_BURST = 9, DS_SPREAD = 10, MIX_BURST = 11, MIX_SPREAD = 12, MIX_SPREAD2 = 13 };
+enum { NONE = 0, BUF_OFFEN = 1, BUF_TID = 2, GLOBAL_SADDR = 3, BUF_LDS = 4, BUF_OFFEN_SPREAD = 5, BUF_TID_SPREAD = 6, BUF_OFFEN_X2 = 7, BUF_TID_X2 = 8, DS_BURST = 9, DS_SPREAD = 10, MIX_BURST = 11, MIX_SPREAD = 12, MIX_SPREAD2 = 13, DEP_NONE = 14, DEP_SPREAD = 15, DEP_SPREAD_SALU = 16, DEP_SPREAD_NOP = 17 };
 
 // the destination registers of the loads are fixed (a[0:15] / a[16:31]) so that no variant pays for a copy
 template <int MODE>
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 1) void k(const double* __restrict__ src, doub
     unsigned so = __builtin_amdgcn_readfirstlane((it & 3) * 1024);
 #define OPS : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]) \
             : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(voff), "s"(d_raw), "s"(d_tid), "s"(so), "s"(base), "v"(ldsa)                   \
-            : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"
+            : "memory", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "s90", "scc"
 #define M32 MF8("%8", "%9", "%10", "%11") MF8("%8", "%9", "%10", "%11") MF8("%8", "%9", "%10", "%11") MF8("%8", "%9", "%10", "%11")
     if (MODE == NONE) {
       asm volatile(M32 OPS);
@@ -125,6 +125,29 @@ __global__ __launch_bounds__(256, 1) void k(const double* __restrict__ src, doub
                    "buffer_load_dwordx4 a[24:27], %12, %13, %15 offen offset:384\n\tbuffer_load_dwordx4 a[28:31], %12, %13, %15 offen offset:448\n\t" M4
                    "ds_read_b128 v[200:203], %17\n\tds_read_b128 v[204:207], %17 offset:16\n\t" M4 "ds_read_b128 v[208:211], %17 offset:128\n\t"
                    "ds_read_b128 v[212:215], %17 offset:144\n\t" M4 OPS);
+    } else if (MODE >= DEP_NONE) {
+      // the kernel's dependency pattern: per group two direct accumulators and ONE transposed accumulator used by every second MFMA
+#define D2(d, z) "v_mfma_f64_16x16x4_f64 " d ", %8, %10, " d "\n\tv_mfma_f64_16x16x4_f64 " z ", %9, %11, " z "\n\t"
+#define SL(op) op
+#define GRP(o1, o2, o3, o4) D2("%0", "%4") o1 D2("%1", "%4") o2 D2("%2", "%5") o3 D2("%3", "%5") o4
+      if (MODE == DEP_NONE)
+        asm volatile(GRP("", "", "", "") GRP("", "", "", "") GRP("", "", "", "") GRP("", "", "", "") OPS);
+      else if (MODE == DEP_SPREAD)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                     GRP("ds_write_b128 %17, a[0:3]\n\t", "ds_write_b128 %17, a[4:7] offset:1088\n\t", "ds_write_b128 %17, a[8:11] offset:2176\n\t", "ds_write_b128 %17, a[12:15] offset:3264\n\t")
+                     GRP("ds_read_b128 v[200:203], %17\n\t", "ds_read_b128 v[204:207], %17 offset:16\n\t", "ds_read_b128 v[208:211], %17 offset:128\n\t", "ds_read_b128 v[212:215], %17 offset:144\n\t")
+                     GRP("buffer_load_dwordx4 a[0:3], %12, %13, %15 offen\n\t", "buffer_load_dwordx4 a[4:7], %12, %13, %15 offen offset:64\n\t", "buffer_load_dwordx4 a[8:11], %12, %13, %15 offen offset:128\n\t", "buffer_load_dwordx4 a[12:15], %12, %13, %15 offen offset:192\n\t")
+                     GRP("buffer_load_dwordx2 a[16:17], %12, %13, %15 offen offset:256\n\t", "buffer_load_dwordx2 a[20:21], %12, %13, %15 offen offset:320\n\t", "buffer_load_dwordx2 a[24:25], %12, %13, %15 offen offset:384\n\t", "buffer_load_dwordx2 a[28:29], %12, %13, %15 offen offset:448\n\t") OPS);
+      else if (MODE == DEP_SPREAD_SALU)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                     GRP("ds_write_b128 %17, a[0:3]\n\ts_add_u32 s90, s90, 1\n\t", "ds_write_b128 %17, a[4:7] offset:1088\n\t", "ds_write_b128 %17, a[8:11] offset:2176\n\ts_add_u32 s90, s90, 1\n\t", "ds_write_b128 %17, a[12:15] offset:3264\n\t")
+                     GRP("ds_read_b128 v[200:203], %17\n\ts_add_u32 s90, s90, 1\n\t", "ds_read_b128 v[204:207], %17 offset:16\n\t", "ds_read_b128 v[208:211], %17 offset:128\n\ts_add_u32 s90, s90, 1\n\t", "ds_read_b128 v[212:215], %17 offset:144\n\t")
+                     GRP("buffer_load_dwordx4 a[0:3], %12, %13, %15 offen\n\ts_add_u32 s90, s90, 1\n\t", "buffer_load_dwordx4 a[4:7], %12, %13, %15 offen offset:64\n\t", "buffer_load_dwordx4 a[8:11], %12, %13, %15 offen offset:128\n\ts_add_u32 s90, s90, 1\n\t", "buffer_load_dwordx4 a[12:15], %12, %13, %15 offen offset:192\n\t")
+                     GRP("buffer_load_dwordx2 a[16:17], %12, %13, %15 offen offset:256\n\ts_add_u32 s90, s90, 1\n\t", "buffer_load_dwordx2 a[20:21], %12, %13, %15 offen offset:320\n\t", "buffer_load_dwordx2 a[24:25], %12, %13, %15 offen offset:384\n\ts_add_u32 s90, s90, 1\n\t", "buffer_load_dwordx2 a[28:29], %12, %13, %15 offen offset:448\n\t") OPS);
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+                     GRP("s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t") GRP("s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t")
+                     GRP("s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t") GRP("s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t", "s_nop 0\n\t") OPS);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
@@ -193,5 +216,9 @@ int main() {
   run<MIX_BURST>("+ 8 loads + 4 ds_write + 4 ds_read in a burst", src, out, cyc, base, 16);
   run<MIX_SPREAD>("+ the same 16, one per 2 MFMAs", src, out, cyc, base, 16);
   run<MIX_SPREAD2>("+ the same 16, two per 4 MFMAs", src, out, cyc, base, 16);
+  run<DEP_NONE>("32 MFMAs, the kernel's accumulator pattern", src, out, cyc, base, 0);
+  run<DEP_SPREAD>("+ 16 memory operations, one per 2 MFMAs", src, out, cyc, base, 16);
+  run<DEP_SPREAD_SALU>("+ 16 memory + 8 scalar operations", src, out, cyc, base, 24);
+  run<DEP_SPREAD_NOP>("+ 16 s_nop 0, one per 2 MFMAs", src, out, cyc, base, 16);
   return 0;
 }
