@@ -1,17 +1,23 @@
 // K1s, wide blocks - the symmetric-tiled sweep with ONE wave per SIMD and 16 NB block columns per workgroup (NB = 1, 2).
 //
-// Why.  v_mfma_f64_16x16x4_f64 holds the SIMD's vector issue for its whole 64 cycles (profiles/ubench/r01_mfma_f64_overlap.log:
-// a wave with one in flight issues nothing else, a second wave on the SIMD one instruction per ~21 cycles), so in the
-// MFMA-bound launches of a solve (32 / 64 columns) every instruction that is not an MFMA is paid for in matrix-pipe time.
+// Why.  v_mfma_f64_16x16x4_f64 runs on the SIMD's fp64 vector units for 64 cycles (profiles/ubench/r01_mfma_f64_overlap.log: a
+// second wave on the SIMD gets one VALU instruction per ~21 cycles), so in the MFMA-bound launches of a solve (32 / 64
+// columns) the instructions that are not MFMAs - how many, and where they stand - decide how busy the matrix pipe is.
 // matvec_sym9_kernel<2> (16 columns per workgroup, two waves per SIMD, 216 VGPRs) issues 2.6 vector instructions besides
 // each MFMA - tile loads, the LDS transposition of the tile, the X_I operand reads, 64-bit address arithmetic - and
 // repeats the transposition of every tile in each of the 2 / 4 column groups of a launch: pipe 73 % busy (round 2).
 // Here a workgroup is 4 waves x 512 registers.  Wave v keeps, for the whole work item,
 //   - its 128-row slice of the super row (R = 2 block rows x 2 halves) x 16 NB block columns of direct partials,
 //   - the X_I operand of the transposed product for those rows (it never changes within an item: no LDS, no re-reads),
-// so one tile load and one LDS transposition feed 16 NB MFMAs per 32 x 16 sub-block instead of 16, the transposition of
-// half-step s + 1 is issued before the MFMAs of half-step s (its latency hides behind them - the registers for that are
-// what the two-wave kernel did not have), and addresses are a scalar descriptor plus constant per-lane offsets.
+// so one tile load and one LDS transposition feed 16 NB MFMAs per 32 x 16 sub-block instead of 16, and addresses are a scalar
+// descriptor plus constant per-lane offsets.
+// Where the other instructions stand matters as much as how many there are (profiles/ubench/loadcost.hip): a memory
+// instruction that follows an MFMA issues in the shadow of that MFMA's 16 passes (~1-4 cycles), a burst of them queues in
+// front of the next MFMA (8 cycles per buffer load, 29 per DS operation).  So a half-step is 16 NB asm statements of two
+// MFMAs with ONE memory operation behind each: the transposition of the NEXT half-step (its LDS reads are 16 NB MFMAs old when
+// their registers are used), the tile loads three half-steps ahead, the next unit's X_J, and - as second operations - the
+// pieces of the exchange of the transposed partials.  Matrix pipe 93-94 % busy (PMC), 0.78 / 0.87 of the fp64 peak at 32 / 64
+// columns at the clock the chip holds under this load.
 // Same work items, slab layout, masking rules and fixed-order sums as matvec_sym9_kernel<2> (k_matvec_sym9.hip), so the
 // same reduction kernel follows; results are bitwise reproducible run to run.
 //
@@ -20,16 +26,16 @@
 // distance between two MFMAs of one chain, back to back included - but only every 83.1 cycles with C / D in
 // accumulation registers; A and B operands cost nothing in either half.  So: accumulators (direct partials, transposed
 // partial) in VGPRs; what an MFMA only READS in accumulation registers - X_I (128), the load ring of tile entries (64),
-// the X_J operand (16 NB).  The compiler's allocator does not keep such values there reliably (it prefers VGPRs for a
+// the X_J operand (16 NB), the Gram-layout operands (32).  The compiler's allocator does not keep such values there reliably (it prefers VGPRs for a
 // value that may live in either half, runs out, and copies - a VALU write right in front of an MFMA it does not know to
-// be one), so the ring and X_J live in FIXED accumulation registers a[160:255] that only inline assembly names: buffer
-// loads straight into them, DS writes and MFMAs straight out of them, vmcnt counted by hand (every vector-memory load of
+// be one), so the ring, X_J and the Gram-layout operands live in FIXED accumulation registers a[128:255] that only inline
+// assembly names: buffer loads and DS reads straight into them, DS writes and MFMAs straight out of them, vmcnt counted by hand (every vector-memory load of
 // the loop is one of these; the compiler's own operations - prologue, strip stores - only make the counts conservative).
 // What the compiler does not know about an asm MFMA is handled structurally: every MFMA operand is produced by a
 // load, never by a VALU instruction (the B operand of a tile that is not there is loaded from a page of zeros instead
 // of multiplied by zero; a chain starts with the literal-zero form; no branches around MFMAs), and MFMA results are read
-// by other instructions only behind the 18 wait states a 16-pass MFMA needs (MFMA_DRAIN).  tests/test_isa_lint.py checks
-// the emitted code: no compiler instruction touches a[160:255], no VALU write within two instructions of an MFMA that reads it.
+// by other instructions only behind the 18 wait states a 16-pass MFMA needs (MFMA_DRAIN) or many MFMAs later.
+// tests/test_isa_lint.py checks the emitted code: no compiler instruction touches a[128:255], no VALU write within two instructions of an MFMA that reads it.
 #include "kernels.h"
 #include <cstdlib>
 #include <type_traits>
