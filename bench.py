@@ -42,6 +42,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+# Generated (matrix-free) sweeps: fp64 MFMA and VALU instructions of a wave do not overlap (profiles/ubench/valucost.hip,
+# r03_valucost.log: n VALU instructions behind an MFMA cost 12.5 + 4 n cycles, v_mul_lo_u32 and v_mad_u64_u32 included - none of
+# them is quarter rate on gfx950), so one wave-evaluation (64 entries) costs the generator's ~34 VALU instructions x 4 cycles
+# (splitmix64: two 64-bit multiplies = 2 v_mad_u64_u32 + 4 v_mul_lo_u32, three 64-bit shift-xor rounds, key, conversion, scaling,
+# diagonal select) PLUS the two 64-cycle MFMAs that consume it in a 16-column sweep (direct + transposed product).
+GEN_CYCLES_PER_WAVE_EVALUATION = 34 * 4 + 2 * 64
+GEN_MODEL = ("1024 SIMDs x 2.4 GHz x 64 lanes / 264 cycles per wave-evaluation: ~34 VALU instructions x 4 cycles (splitmix64 + key + "
+             "conversion; no quarter-rate instruction among them, profiles/ubench/r03_valucost.log) + 2 fp64 MFMAs x 64 cycles (16 columns, "
+             "direct + transposed product) - the two kinds of instruction do not overlap within a SIMD (same log: n VALU instructions "
+             "behind an MFMA cost 12.5 + 4 n cycles)")
 FP64_MFMA_PEAK_TFLOPS = 78.6    # 256 CUs x 4 SIMDs x (16x16x4 MACs / 64 cycles) x 2 x 2.4 GHz (measured: 64.0 cycles per
                                 # v_mfma_f64_16x16x4_f64, 16.3 per v_mfma_f64_4x4x4_4b_f64 - profiles/ubench)
 
@@ -419,13 +429,13 @@ def main():
                 groups = max(int(sg.apply_cols) // 16, 1)
                 ms_b_group = max(dev_other - 0.0, 0.0) / groups
                 evals_b = 0.5 * float(gn) * float(gn)
-                peak_evals = 1024 * 2.4e9 * 64 / 208.0
+                peak_evals = 1024 * 2.4e9 * 64 / GEN_CYCLES_PER_WAVE_EVALUATION
                 extras["configs3_gjd"]["roofline"] = {
                     "A_sweeps": {"bound": "hbm (16 columns) / mfma (32, 64)", "ms_per_sweep_end_to_end": round(sg.apply_ms / max(sg.applies, 1), 3),
                                  "GBps_end_to_end": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9, 1) if sg.apply_ms > 0 else None,
                                  "frac_of_8TBps": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sg.apply_ms > 0 else None,
                                  "TFLOPs_kernel_only": round(sg.apply_flops / (sg.apply_kernel_ms * 1e-3) / 1e12, 2) if sg.apply_kernel_ms > 0 else None},
-                    "B_sweeps": {"bound": "valu-int (generator)", "sixteen_column_groups": groups, "ms_per_group_upper_bound": round(ms_b_group, 2),
+                    "B_sweeps": {"bound": "valu-int + mfma on one issue port (generator)", "sixteen_column_groups": groups, "ms_per_group_upper_bound": round(ms_b_group, 2),
                                  "hash_evaluations_per_s_lower_bound": round(evals_b / (ms_b_group * 1e-3), 0) if ms_b_group > 0 else None,
                                  "peak": round(peak_evals, 0),
                                  "frac_lower_bound": round(evals_b / (ms_b_group * 1e-3) / peak_evals, 4) if ms_b_group > 0 else None,
@@ -473,18 +483,14 @@ def main():
                     "sweeps": int(sf.applies), "launches": int(sf.apply_launches), "ms_per_launch": round(per_launch_ms, 2),
                     "entries_of_A_per_s_per_rank": round(entries / (per_launch_ms * 1e-3), 0) if per_launch_ms > 0 else None,
                     "eigenvalues": [float(x) for x in lam_f[:3]]}
-                # VALU roofline of the generator: one splitmix64 per generated entry = two 64-bit multiplies = 2 v_mad_u64_u32 +
-                # 4 v_mul_lo_u32 (quarter rate: 16 cycles per wave64 each) + ~28 full-rate integer / convert / fp64 instructions
-                # (4 cycles each) = ~208 cycles per 64 evaluations per SIMD
+                # issue-port roofline of the generated sweep (GEN_CYCLES_PER_WAVE_EVALUATION above)
                 evals = entries * (0.5 if fstorage == "symmetric" else 1.0)
-                peak_evals = 1024 * 2.4e9 * 64 / 208.0
+                peak_evals = 1024 * 2.4e9 * 64 / GEN_CYCLES_PER_WAVE_EVALUATION
                 if per_launch_ms > 0:
                     extras["configs4_free"]["roofline"] = {
-                        "bound": "valu-int", "unit": "hash evaluations/s", "achieved": round(evals / (per_launch_ms * 1e-3), 0),
+                        "bound": "valu-int + mfma on one issue port", "unit": "hash evaluations/s", "achieved": round(evals / (per_launch_ms * 1e-3), 0),
                         "peak": round(peak_evals, 0), "frac": round(evals / (per_launch_ms * 1e-3) / peak_evals, 4),
-                        "model": "1024 SIMDs x 2.4 GHz x 64 lanes / 208 cycles per wave-evaluation (6 quarter-rate 32-bit multiplies of the two "
-                                 "64-bit multiplies of splitmix64 = 96 cycles, ~28 full-rate instructions = 112 cycles); the MFMAs and the "
-                                 "LDS transposition of the sweep share the issue slots"}
+                        "model": GEN_MODEL}
                 f.close()
             except Exception as exc:       # noqa: BLE001
                 extras["configs4_free"] = {"error": repr(exc)[:300]}
