@@ -251,7 +251,7 @@ int coll_allreduce(E* e, double* buf, size_t count);
 int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count);
 // ---- engine_operators.hip --------------------------------------------------------------------------------
 int refresh_diag_host(E* e, int which);
-int sym_schedule(const E* e, int kk);
+int sym_schedule(const E* e, int kk, bool stored_fp64);
 std::vector<int> sym_group_owners(int nb, int nranks);
 int sym_setup(E* e);
 int sym_diag(E* e, OpDesc& o);

@@ -20,17 +20,20 @@ int refresh_diag_host(E* e, int which) {
   return 0;
 }
 
-// Block rows per workgroup of the symmetric sweep for a block of kk <= 16 columns: 4 (k <= 8), 2, or 1 (the
-// one-block-row kernel of k_matvec_sym.hip: below 200 block rows, where super rows leave too few work items and too much
-// of the matrix in the masked diagonal super blocks).  DAV_SYM_R = 1 | 2 | 4 forces a schedule (4 only if k <= 8).
-int sym_schedule(const E* e, int kk) {
+// Block rows per workgroup of the symmetric sweep for a block of kk <= 16 columns: 4 (k <= 8, from 200 block rows on), 2 (more
+// than 8 columns, from 64 block rows on: the one-wave-per-SIMD kernel of k_matvec_symw.hip), or 1 (the one-block-row kernel of
+// k_matvec_sym.hip: small matrices, where super rows leave too few work items and too much of the matrix in the masked
+// diagonal super blocks).  DAV_SYM_R = 1 | 2 | 4 forces a schedule (4 only if k <= 8).
+int sym_schedule(const E* e, int kk, bool stored_fp64) {
   const char* ev = getenv("DAV_SYM_R");                 // read per call: A/B runs flip it inside one process
   const int forced = ev ? atoi(ev) : 0;
   const int nb = (int)(e->ncols_pad / SYM_TB);          // block rows of the whole matrix
-  // crossover measured end to end on one box (k = 8 / 32; ms for R = 1 | 2 | 4): N=40000 (157 block rows) 1.33 | 1.38 | 1.39
-  // and 2.30 | 2.45 | 2.42; N=60000 (235) 2.78 | 2.78 | 2.67 and 5.04 | 5.00 | 5.01; N=100000 7.28 | 7.39 | 6.84 and
-  // 13.78 | 13.61 | 13.57; N=140000 14.98 | 14.85 | 13.99 and 26.81 | 26.31 | 26.30
-  int R = nb >= 200 ? (kk <= 8 ? 4 : 2) : 1;
+  // k <= 8, crossover measured end to end on one box (ms for R = 1 | 2 | 4): N=40000 (157 block rows) 1.33 | 1.38 | 1.39; N=60000
+  // (235) 2.78 | 2.78 | 2.67; N=100000 7.28 | 7.39 | 6.84; N=140000 14.98 | 14.85 | 13.99.
+  // More than 8 columns (R = 1 | 2, k = 16 / 32 / 64, profiles/experiments/r03_small_n_schedule.log): N=20000 (79 block rows)
+  // 0.455 | 0.427, 0.665 | 0.647, 1.26 | 1.12 ms; N=40000 1.51 | 1.50, 2.31 | 2.05, 4.58 | 3.67; N=60000 3.04 | 2.79, 5.09 | 4.18,
+  // 10.1 | 7.54.
+  int R = kk <= 8 ? (nb >= 200 ? 4 : 1) : (nb >= (stored_fp64 ? 64 : 200) ? 2 : 1);   // generated / fp32 tiles: the two-wave kernels, as before
   if (forced == 1 || forced == 2 || forced == 4) R = forced;
   if (R == 4 && kk > 8) R = 2;
   if (R > 1 && !matvec_sym_can_pair()) R = 1;          // DAV_SYM_V8=0: the one-wave-per-SIMD kernel, A/B runs only
