@@ -44,14 +44,15 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 # Generated (matrix-free) sweeps: fp64 MFMA and VALU instructions of a wave do not overlap (profiles/ubench/valucost.hip,
 # r03_valucost.log: n VALU instructions behind an MFMA cost 12.5 + 4 n cycles, v_mul_lo_u32 and v_mad_u64_u32 included - none of
-# them is quarter rate on gfx950), so one wave-evaluation (64 entries) costs the generator's ~34 VALU instructions x 4 cycles
-# (splitmix64: two 64-bit multiplies = 2 v_mad_u64_u32 + 4 v_mul_lo_u32, three 64-bit shift-xor rounds, key, conversion, scaling,
-# diagonal select) PLUS the two 64-cycle MFMAs that consume it in a 16-column sweep (direct + transposed product).
-GEN_CYCLES_PER_WAVE_EVALUATION = 34 * 4 + 2 * 64
-GEN_MODEL = ("1024 SIMDs x 2.4 GHz x 64 lanes / 264 cycles per wave-evaluation: ~34 VALU instructions x 4 cycles (splitmix64 + key + "
+# them is quarter rate on gfx950), so one wave-evaluation (64 entries) costs the generator's 26 VALU instructions x 4 cycles
+# (the interior-tile path of k_matvec_sym9.hip compiled on its own: per entry 5 v_xor, 4 v_mul_lo_u32, 2 v_mad_u64_u32, 2
+# v_lshrrev_b64, 2 v_add3, 2 v_lshrrev_b32, 2 v_cvt_f64_u32, 1 each v_alignbit / v_add_f64 / v_fmac_f64 / v_mul_f64, ~1.3
+# 64-bit adds) PLUS the two 64-cycle MFMAs that consume it in a 16-column sweep (direct + transposed product).
+GEN_CYCLES_PER_WAVE_EVALUATION = 26 * 4 + 2 * 64
+GEN_MODEL = ("1024 SIMDs x 2.4 GHz x 64 lanes / 232 cycles per wave-evaluation: 26 VALU instructions x 4 cycles (splitmix64 + key + "
              "conversion; no quarter-rate instruction among them, profiles/ubench/r03_valucost.log) + 2 fp64 MFMAs x 64 cycles (16 columns, "
              "direct + transposed product) - the two kinds of instruction do not overlap within a SIMD (same log: n VALU instructions "
-             "behind an MFMA cost 12.5 + 4 n cycles)")
+             "behind an MFMA cost 12.5 + 4 n cycles); the LDS transposition, X_I reads and the exchange of the sweep are not in the model")
 FP64_MFMA_PEAK_TFLOPS = 78.6    # 256 CUs x 4 SIMDs x (16x16x4 MACs / 64 cycles) x 2 x 2.4 GHz (measured: 64.0 cycles per
                                 # v_mfma_f64_16x16x4_f64, 16.3 per v_mfma_f64_4x4x4_4b_f64 - profiles/ubench)
 
