@@ -382,12 +382,13 @@ def test_hashed_operator_symmetric_generation_equals_the_dense_generator(n, k):
         assert np.abs(e.panel_get(PANEL_W, 0, k) - A @ X).max() <= 1e-12 * np.abs(A @ X).max()
 
 
-@pytest.mark.parametrize("k", [8, 16, 40, 64])
-def test_symmetric_super_row_schedules_at_a_size_that_selects_them(k):
+@pytest.mark.parametrize("n,k", [(51700, 8), (51700, 16), (51700, 40), (51700, 64), (16700, 16), (16700, 40), (16700, 8)])
+def test_symmetric_super_row_schedules_at_a_size_that_selects_them(n, k):
     """From 200 block rows on the sweep runs the super-row schedules (4 block rows per workgroup for k <= 8, else 2)
     by itself: N=51700 (202 block rows, a ragged last super row), the same generated matrix in full storage
-    as the reference, stored tiles and the hashed operator generated in the sweep."""
-    n = 51700
+    as the reference, stored tiles and the hashed operator generated in the sweep.  Stored fp64 tiles and more than 8
+    columns: two block rows per workgroup (the wide kernel) from 64 block rows on - N=16700 has 66, an odd last super row
+    (k = 8 and the generated operator stay on the one-block-row kernel there)."""
     X = np.random.default_rng(k).standard_normal((n, k))
     with fd.CEngine(n=n, max_cols=64) as e:
         e.set_dense_generated(OP_A, 5, 1e-3)
