@@ -160,3 +160,33 @@ def test_config3_n200000_restart_forcing_variant():
         verify_on_device(eng, lam, False, n, sp)
         st = eng.c.stats()
         assert st.restarts >= 1 and st.applies + st.restarts >= iters    # one sweep per growing iteration, none after a restart (W and B*V are contracted with V)
+
+
+def test_sweep_kernels_at_full_size_agree_with_each_other():
+    """The block sweep at N=200000 (160 GB of symmetric tiles), properties that need no reference product: the 64-column launch
+    (two workgroups per work item) is bit for bit the two 32-column launches of its halves; 16 columns (one column group per
+    workgroup) and 8 columns (the four-block-row kernel on the 4x4x4 MFMA - another kernel, another schedule, other sums)
+    agree with it to rounding; X^T (A Y) = (A X)^T Y."""
+    from fortran_davidson_amd.engine_c import PANEL_V, PANEL_W
+    n = 200000
+    rng = np.random.default_rng(5)
+    with fd.CEngine(n=n, max_cols=64) as e:
+        e.set_storage(1)
+        e.set_dense_generated(OP_A, 1, 1e-3)
+        X = rng.standard_normal((n, 64))
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, 64, PANEL_W, 0)
+        W = e.panel_get(PANEL_W, 0, 64)
+        assert np.isfinite(W).all()
+        for c0 in (0, 32):
+            e.apply(OP_A, PANEL_V, c0, 32, PANEL_S, 0)
+            assert np.array_equal(e.panel_get(PANEL_S, 0, 32), W[:, c0:c0 + 32])
+        scale = np.abs(W).max()
+        e.apply(OP_A, PANEL_V, 16, 16, PANEL_S, 0)
+        assert np.abs(e.panel_get(PANEL_S, 0, 16) - W[:, 16:32]).max() < 1e-12 * scale
+        e.apply(OP_A, PANEL_V, 40, 8, PANEL_S, 0)
+        assert np.abs(e.panel_get(PANEL_S, 0, 8) - W[:, 40:48]).max() < 1e-12 * scale
+        G = e.gram(PANEL_V, 0, 64, PANEL_W, 0, 64)                 # X^T A X: symmetric to rounding
+        assert np.abs(G - G.T).max() < 1e-11 * np.abs(G).max()
+        # the diagonal dominates: (A X)_ij = (i + 1) X_ij + O(n * sparsity) - a coarse check of the values themselves
+        assert np.abs(W - np.arange(1, n + 1)[:, None] * X).max() < 1e-3 * n * 6 * 0.05 + 50
