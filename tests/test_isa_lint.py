@@ -8,7 +8,8 @@ test checks the EMITTED code for them:
   2. no VALU instruction writes a register that an MFMA reads within the next two instructions (2 wait states);
   3. a register written by an MFMA is read by a non-MFMA instruction only after an `s_nop 15` (+ `s_nop 3`): 18+ wait states -
      or after three later MFMAs of the wave (each holds the matrix pipe for 16 passes: the result is two MFMAs old at least);
-  4. no register moves between the halves (v_accvgpr_*) and no scratch in the kernel at all.
+  4. no register moves between the halves (v_accvgpr_*) and no scratch in the kernel at all;
+  5. no buffer load reads a scalar register that a VALU instruction wrote fewer than 5 wait states before.
 """
 import os
 import re
@@ -142,3 +143,30 @@ def test_mfma_hazards(kernels):
                     mfma_written[dfile].pop(r, None)
             recent.append((is_valu, dfile, dregs))
         assert n_mfma in (256, 512), (name, n_mfma)
+
+
+def test_buffer_descriptors_are_not_fresh_from_the_valu(kernels):
+    """A buffer instruction that reads a scalar register written by a VALU instruction (v_readfirstlane, v_readlane, v_cmp)
+    needs 5 wait states in between.  The loads of the prologue open with `s_nop 4`; those of the loop do not (their descriptors
+    are scalar-ALU results) - checked here: no VALU instruction among the five in front of a buffer load writes a scalar register
+    that the load reads, unless an `s_nop 4` stands in between."""
+    def sregs(tok):
+        m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"s(\d+)", tok)
+        return {int(m.group(1))} if m else ({-1} if tok == "vcc" else set())
+    for name, lines in kernels.items():
+        code = [ln.split(";")[0].strip() for ln in lines]
+        code = [c for c in code if c and not c.startswith(".") and not c.endswith(":")]
+        for i, c in enumerate(code):
+            if not c.startswith("buffer_load"):
+                continue
+            _, ops = _operands(c)
+            read = set().union(*[sregs(t.split()[0]) for t in ops[1:] if t]) if len(ops) > 1 else set()
+            for b in reversed(code[max(0, i - 5):i]):
+                if b == "s_nop 4":
+                    break
+                if b.startswith(("v_readfirstlane", "v_readlane", "v_cmp")):
+                    _, bops = _operands(b)
+                    assert not (sregs(bops[0]) & read), (name, b, c)
