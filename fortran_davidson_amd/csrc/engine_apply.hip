@@ -25,13 +25,19 @@ bool inner_f32_tiles(E* e, OpDesc& o) {
 // one-wave-per-SIMD kernel (k_matvec_symw.hip: 32 columns per workgroup, or 16 for a block of <= 16); generated operators,
 // the fp32 copy and the k <= 8 schedule (R = 4, 4x4x4 MFMA) stay on matvec_sym9_kernel.
 // DAV_SYM_WIDE = 0: never (A/B runs), 1: blocks wider than 16 columns only, 2 (default): from 9 columns on.  Read per call.
+// DAV_SYM_WIDE: 2 (default) the one-wave-per-SIMD kernel for more than 8 columns, 1 for more than 16 only, 0 never (A/B runs)
+static int sym_wide_level() {
+  const char* ev = getenv("DAV_SYM_WIDE");                // read per call: A/B runs flip it inside one process
+  return ev ? atoi(ev) : 2;
+}
+bool sym_wide_enabled() { return sym_wide_level() > 1; }   // ... for 9-16 columns too
+
 void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
                        int npair, int64_t dstride, int64_t tstride) {
-  const char* ev = getenv("DAV_SYM_WIDE");
-  const int wide = ev ? atoi(ev) : 2;
-  if (R == 2 && o.kind == DAV_KIND_DENSE && !use32 && wide > 0 && (kk > 16 || wide > 1)) {
+  const int wide = sym_wide_level();
+  if (o.kind == DAV_KIND_DENSE && !use32 && wide > 0 && ((R == 2 && (kk > 16 || wide > 1)) || (R == 4 && kk > 8 && kk <= 16))) {
     const int nbw = kk > 16 ? 2 : 1;
-    launch_matvec_symw(e->stream, nbw, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+    launch_matvec_symw(e->stream, nbw, R == 4, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
                        (npair + nbw - 1) / nbw, e->xt_group_stride, dstride, tstride);
     return;
   }
@@ -168,7 +174,7 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     // the super-row kernels: the four workgroups of a work item share every tile read through their XCD's L2.  Same box,
     // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  DAV_SYM_QUAD=0: off.
     static const int quad_env = [] { const char* ev = getenv("DAV_SYM_QUAD"); return ev ? atoi(ev) : 1; }();
-    if (quad_env && step == 32 && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 16, true) == 2 && !has_comm(e)) step = 64;
+    if (quad_env && step == 32 && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2 && !has_comm(e)) step = 64;
     // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
     // reduce-scatter of this path through RCCL on a one-GPU box)
     const bool multi = e->nranks > 1 || has_comm(e);
@@ -183,7 +189,7 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
       // communicator only, and a second stream on one communicator is exactly the kind of thing that must be seen on real
       // links before it becomes the default of a run nobody can watch
       static const int overlap_env = [] { const char* ev = getenv("DAV_SYM_OVERLAP"); return ev ? atoi(ev) : 0; }();
-      if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 16, true) == 2) {
+      if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
         const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
         if (rc != 2) return rc;                        // 2: its streams / buffers / slabs could not be set up - serial path below
       }
@@ -192,7 +198,7 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;
       const bool use32 = inner && inner_f32_tiles(e, o);
-      int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, std::min(kk, 16), o.kind == DAV_KIND_DENSE && !use32);
+      int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, kk, o.kind == DAV_KIND_DENSE && !use32);
       if (use32 && R == 1) R = 2;            // the fp32 tiles are read by the super-row kernels only
       const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
       const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)e->sym_nitems * 16 * SYM_TB;

@@ -265,6 +265,7 @@ void ingest_wanted(E* e, int64_t* first, int64_t* count);
 OpParams op_params(const OpDesc& o);
 // ---- engine_apply.hip ------------------------------------------------------------------------------------
 bool inner_f32_tiles(E* e, OpDesc& o);
+bool sym_wide_enabled();
 void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
                        int npair, int64_t dstride, int64_t tstride);
 int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner);

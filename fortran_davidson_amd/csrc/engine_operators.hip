@@ -20,8 +20,8 @@ int refresh_diag_host(E* e, int which) {
   return 0;
 }
 
-// Block rows per workgroup of the symmetric sweep for a block of kk <= 16 columns: 4 (k <= 8, from 200 block rows on), 2 (more
-// than 8 columns, from 64 block rows on: the one-wave-per-SIMD kernel of k_matvec_symw.hip), or 1 (the one-block-row kernel of
+// Block rows per workgroup of the symmetric sweep for a launch of kk columns: 4 (k <= 8 - and 9-16 columns of stored fp64 tiles -
+// from 200 block rows on), 2 (more than 8 columns, from 64 block rows on: the one-wave-per-SIMD kernel of k_matvec_symw.hip), or 1 (the one-block-row kernel of
 // k_matvec_sym.hip: small matrices, where super rows leave too few work items and too much of the matrix in the masked
 // diagonal super blocks).  DAV_SYM_R = 1 | 2 | 4 forces a schedule (4 only if k <= 8).
 int sym_schedule(const E* e, int kk, bool stored_fp64) {
@@ -34,8 +34,13 @@ int sym_schedule(const E* e, int kk, bool stored_fp64) {
   // 0.455 | 0.427, 0.665 | 0.647, 1.26 | 1.12 ms; N=40000 1.51 | 1.50, 2.31 | 2.05, 4.58 | 3.67; N=60000 3.04 | 2.79, 5.09 | 4.18,
   // 10.1 | 7.54.
   int R = kk <= 8 ? (nb >= 200 ? 4 : 1) : (nb >= (stored_fp64 ? 64 : 200) ? 2 : 1);   // generated / fp32 tiles: the two-wave kernels, as before
+  // 9-16 columns of stored fp64 tiles: the wide kernel on FOUR block rows per workgroup (half as many transposed partials written
+  // by a sweep that is HBM-bound there); DAV_SYM_TALL=0: two (A/B runs)
+  const char* tv = getenv("DAV_SYM_TALL");
+  const bool tall = stored_fp64 && kk > 8 && kk <= 16 && nb >= 200 && sym_wide_enabled() && (tv ? atoi(tv) != 0 : true);
+  if (R == 2 && tall) R = 4;
   if (forced == 1 || forced == 2 || forced == 4) R = forced;
-  if (R == 4 && kk > 8) R = 2;
+  if (R == 4 && kk > 8 && !(stored_fp64 && kk <= 16 && sym_wide_enabled())) R = 2;
   if (R > 1 && !matvec_sym_can_pair()) R = 1;          // DAV_SYM_V8=0: the one-wave-per-SIMD kernel, A/B runs only
   return R;
 }

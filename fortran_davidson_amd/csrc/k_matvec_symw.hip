@@ -91,13 +91,21 @@ __device__ __forceinline__ i32x4 symw_desc(const void* p, int bytes) {
   return i32x4{(int)symw_uniform((unsigned)a), (int)symw_uniform((unsigned)(a >> 32) & 0xffffu), bytes, 0x00020000};
 }
 
-template <int NB>
+// TALL (NB = 1 only; what 9-16 columns run): FOUR block rows per workgroup - every wave works through two 128-row slices of a unit
+// one after the other (slice s: block row I0 + 2 s + wave / 2), so that the cross-wave sum of a unit's transposed partials covers
+// four block rows and half as many of them are written (at 16 columns the sweep is HBM-bound and those writes are what
+// separates it from the 8-column path).  The sequence the loop walks is (unit 0, slice 0), (unit 0, slice 1), (unit 1, slice 0)
+// ...: a "pair" is then the two slices of ONE unit, everything else - ring, Gram operands, X_J sets (one per slice: a slice
+// without a tile reads zeros), slots, exchange - is the two-block-row kernel's.
+template <int NB, bool TALL>
 __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items, const int* __restrict__ zslot_begin,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
                                                              double* __restrict__ slabT, int kcols, int nwg, int64_t xt_gstride,
                                                              int64_t slabD_gstride, int64_t slabT_gstride, int nb) {
-  constexpr int R = 2;                  // block rows per workgroup
+  static_assert(!TALL || NB == 1, "two slices per wave: 16 columns per workgroup");
+  constexpr int R = TALL ? 4 : 2;       // block rows per workgroup
+  constexpr int NSL = TALL ? 2 : 1;     // 128-row slices per wave
   constexpr int NRS = 4;                // 128-row slices = waves
   constexpr unsigned UPJ = SYM_TB / 16; // units (16 tile columns) per tile column
   constexpr unsigned UPS = 4;           // units per 64-column strip of the stage
@@ -140,16 +148,19 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   const int S = items[4 * item], J0 = items[4 * item + 1], J1 = items[4 * item + 2];
   const int I0 = S * R;
   const int Imax = I0 + R - 1 < nb - 1 ? I0 + R - 1 : nb - 1;     // last block row of the super row that exists
-  const int I = I0 + (wave >> 1);                                 // this wave's block row (may lie past the end)
   const int rhalf = wave & 1;
-  const bool have_row = I <= Imax;
+  int Is[NSL];                                                    // this wave's block rows (may lie past the end)
+  bool have_row[NSL];
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) { Is[sl] = I0 + 2 * sl + (wave >> 1); have_row[sl] = Is[sl] <= Imax; }
 
   // X_I of this wave's 128 rows, in the lane layout of the transposed product's B operand: for half-step hs, 16-row block
   // ib, row pair j and parity xy the lane (k = g, column c) holds X[row 32 hs + 16 ib + 4 g + 2 j + xy, block column c].
   // A wave without a block row reads the rows of block row Imax; its partial is multiplied by zero.
-  double xI[4][2][2][2][NB];
-  {
-    const double* xr = xt + ((int64_t)(have_row ? I : Imax) * SYM_TB + 128 * rhalf) * 16;
+  double xI[NSL][4][2][2][2][NB];
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) {
+    const double* xr = xt + ((int64_t)(have_row[sl] ? Is[sl] : Imax) * SYM_TB + 128 * rhalf) * 16;
     const unsigned xo = (4 * g) * 16 + c;
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs)
@@ -161,18 +172,21 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
           for (int xy = 0; xy < 2; ++xy)
 #pragma unroll
             for (int bcb = 0; bcb < NB; ++bcb)
-              xI[hs][ib][j][xy][bcb] = xr[bcb * xt_gstride + xo + (32 * hs + 16 * ib + 2 * j + xy) * 16];
+              xI[sl][hs][ib][j][xy][bcb] = xr[bcb * xt_gstride + xo + (32 * hs + 16 * ib + 2 * j + xy) * 16];
   }
 
-  f64x4 acc[4][2][NB];              // direct partials: [half-step][row parity][group] x (4 row groups in the f64x4)
+  f64x4 acc[NSL][4][2][NB];         // direct partials: [slice][half-step][row parity][group] x (4 row groups in the f64x4)
 #pragma unroll
-  for (int hs = 0; hs < 4; ++hs)
+  for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
-    for (int par = 0; par < 2; ++par)
+    for (int hs = 0; hs < 4; ++hs)
 #pragma unroll
-      for (int bcb = 0; bcb < NB; ++bcb) acc[hs][par][bcb] = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int bcb = 0; bcb < NB; ++bcb) acc[sl][hs][par][bcb] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   const unsigned nunits = symw_uniform((unsigned)(J1 - J0) * UPJ);
+  const unsigned nseq = NSL * nunits;                             // length of the sequence the loop walks: (unit, slice) pairs
   double* tw = tr + wave * TRW;
   // LDS byte addresses (the low 32 bits of a generic pointer into LDS are the LDS offset)
   const unsigned tw_wr = (unsigned)reinterpret_cast<uintptr_t>(tw + g * TRS + 2 * c);    // + 4 u rows of TRS: the direct layout
@@ -188,14 +202,19 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   // (a scalar instruction costs ~5 cycles of matrix-pipe time here, profiles/ubench/r03_fatwave_vgpr_acc.log).
   constexpr int64_t UNIT_BYTES = 16 * SYM_TB * (int64_t)sizeof(double);
   const int64_t unit0 = (int64_t)J0 * UPJ * UNIT_BYTES;
-  const char* const trow_own = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[have_row ? I : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
   const char* const trow_max = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
-  // units whose tile is stored for this wave (J <= I) / lies below the diagonal (J < I): q < qlim_*
-  const unsigned qlim_d = symw_uniform(have_row ? (I >= J0 ? (unsigned)(I - J0 + 1) * UPJ : 0u) : 0u);
-  const unsigned qlim_z = symw_uniform(have_row ? (I > J0 ? (unsigned)(I - J0) * UPJ : 0u) : 0u);
-  auto unit_desc = [&](unsigned q) {
-    q = q < nunits ? q : nunits - 1;
-    return symw_desc((q < qlim_d ? trow_own : trow_max) + (int64_t)q * UNIT_BYTES, (int)UNIT_BYTES);
+  const char* trow_own[NSL];
+  unsigned qlim_d[NSL];              // units whose tile is stored for this wave's slice (J <= I): q < qlim_d
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) {
+    trow_own[sl] = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[have_row[sl] ? Is[sl] : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
+    qlim_d[sl] = symw_uniform(have_row[sl] ? (Is[sl] >= J0 ? (unsigned)(Is[sl] - J0 + 1) * UPJ : 0u) : 0u);
+  }
+  // position i of the sequence: unit i / NSL, slice i % NSL
+  auto unit_desc = [&](unsigned i) {
+    i = i < nseq ? i : nseq - 1;
+    const unsigned q = i / NSL, sl = i % NSL;
+    return symw_desc((q < qlim_d[sl] ? trow_own[sl] : trow_max) + (int64_t)q * UNIT_BYTES, (int)UNIT_BYTES);
   };
   // One vector-memory / LDS operation per call, each its own asm statement.  In the loop they are placed BETWEEN the MFMAs, one
   // behind every second MFMA, never in bursts: next to 64-cycle MFMAs a lone wave pays 1-2 cycles for a memory instruction
@@ -227,9 +246,10 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   int xso[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) xso[u] = (4 * u) * 16 * (int)sizeof(double);
-  auto x_desc = [&](unsigned q, int bcb) {
-    q = q < nunits ? q : nunits - 1;
-    return symw_desc(q < qlim_d ? xjg[bcb] + (int64_t)q * (16 * 16 * (int64_t)sizeof(double)) : zpage, 16 * 16 * (int)sizeof(double));
+  auto x_desc = [&](unsigned i, int bcb) {
+    i = i < nseq ? i : nseq - 1;
+    const unsigned q = i / NSL, sl = i % NSL;
+    return symw_desc(q < qlim_d[sl] ? xjg[bcb] + (int64_t)q * (16 * 16 * (int64_t)sizeof(double)) : zpage, 16 * 16 * (int)sizeof(double));
   };
   // column quad U of group B of the unit behind `d` -> X_J operand set SET
   auto x_load = [&](auto set, auto uc, auto bc, const i32x4& d, auto fresh) {
@@ -269,9 +289,9 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   // (half-step 1), the sum in fixed slice order, masked, -> stage (half-step 2).  zred alternates with the pair parity: a wave
   // that runs ahead cannot overwrite what a slower one still sums, because to get there it has to pass the next barrier.
   // Mask: the slices of block row r feed the transposed product of unit q only where its tile lies below the diagonal.
-  unsigned qz[2];
+  unsigned qz[R];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) qz[r] = symw_uniform(I0 + r <= Imax && I0 + r > J0 ? (unsigned)(I0 + r - J0) * UPJ : 0u);
+  for (int r = 0; r < R; ++r) qz[r] = symw_uniform(I0 + r <= Imax && I0 + r > J0 ? (unsigned)(I0 + r - J0) * UPJ : 0u);
   unsigned zoff[NB];                 // stage offsets of the entries this lane sums (constant; + 16 (q & 3) + strip parity)
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
@@ -290,10 +310,16 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 #pragma unroll
     for (int t = 0; t < NB; ++t) sreg[sl][t] = zred[(qp >> 1) & 1][sl][qp & 1][wave * (NB * 64) + 64 * t + lane];
   };
-  auto sum_finish = [&](unsigned qp, int t) {  // slices in fixed order, times 1 or 0 -> stage
+  double zkeep[NB];                  // (TALL) the first slice's sum, until the second slice's joins it
+  auto sum_finish = [&](unsigned ip, int t) {  // position ip of the sequence: wave slices in fixed order, times 1 or 0 -> stage
+    const unsigned qp = ip / NSL;               // the unit
+    const int sl = (int)(ip % NSL);
     double* zs = zst[(qp / UPS) & 1] + (qp & 3) * 16;
-    const double m0 = qp < qz[0] ? 1.0 : 0.0, m1 = qp < qz[1] ? 1.0 : 0.0;
-    zs[zoff[t]] = __builtin_fma(m1, sreg[3][t], __builtin_fma(m1, sreg[2][t], __builtin_fma(m0, sreg[1][t], m0 * sreg[0][t])));
+    const double m0 = qp < qz[2 * sl] ? 1.0 : 0.0, m1 = qp < qz[2 * sl + 1] ? 1.0 : 0.0;
+    const double v = __builtin_fma(m1, sreg[3][t], __builtin_fma(m1, sreg[2][t], __builtin_fma(m0, sreg[1][t], m0 * sreg[0][t])));
+    if constexpr (!TALL) zs[zoff[t]] = v;
+    else if (sl == 0) zkeep[t] = v;
+    else zs[zoff[t]] = zkeep[t] + v;
   };
   // both partials of a pair (un = unit of the pair) -> zred[parity of the pair]: z[reg] = tile column col + g + 4 reg, block
   // column c of group bcb, summed over this wave's 128 rows
@@ -356,8 +382,10 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 #pragma unroll
     for (int bcb = 0; bcb < NB; ++bcb) xd[bcb] = x_desc(q + 1, bcb);
     const i32x4 udn = unit_desc(q + 3);
-    // the sums of strip st were staged by unit 4 st + 5; the barrier of unit 4 st + 6 publishes them
-    const bool flush_due = SET == 0 && (q & 3) == 2 && q >= 6;
+    // the sums of strip st (units 4 st .. 4 st + 3) were staged by position NSL (4 st + 3) + NSL + 1 of the sequence; the barrier
+    // of the next even position publishes them: 4 st + 6 (TALL: 8 st + 10)
+    constexpr unsigned FP = 4 * NSL, F0 = TALL ? 10 : 6;
+    const bool flush_due = SET == 0 && (q % FP) == 2 && q >= F0;
     f64x4(&zc)[NB] = zcs[PP][SET];             // transposed partials of the unit
     symw_static_for<4>([&](auto hsc) {
       constexpr int hs = decltype(hsc)::value;
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
         STAMP(t1);
         if constexpr (SET == 0) __syncthreads();
         STAMP(t2);
-        if (flush_due) flush_strip((q - 6) / 4);       // once per four units: not worth registers across MFMAs
+        if (flush_due) flush_strip((q - F0) / FP);     // once per four units: not worth registers across MFMAs
       }
       if (hs == 2) STAMP(t3);
       // this half-step's Gram operands (read from LDS during the previous half-step) and the tile entries its transposition
@@ -430,8 +458,9 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
         symw_static_for<NB>([&](auto bc) {
           constexpr int bcb = decltype(bc)::value, gi = u * NB + bcb;
           // (named here: operands of an asm statement inside a generic lambda are not captured by themselves)
-          f64x4 &d0 = acc[hs][0][bcb], &d1 = acc[hs][1][bcb], &zz = zc[bcb];
-          const double x0 = xI[hs][ib][j][0][bcb], x1 = xI[hs][ib][j][1][bcb];
+          constexpr int SL = TALL ? SET : 0;     // the slice this position of the sequence works on
+          f64x4 &d0 = acc[SL][hs][0][bcb], &d1 = acc[SL][hs][1][bcb], &zz = zc[bcb];
+          const double x0 = xI[SL][hs][ib][j][0][bcb], x1 = xI[SL][hs][ib][j][1][bcb];
           // two MFMAs per statement: direct (rows of parity 0 / 1), transposed (the row pair's first / second row)
           if constexpr (hs == 0 && u == 0)
             asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c3:%c4], a[%c5:%c6], %0\n\t"
@@ -468,7 +497,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
 #endif
   };
   // nunits is a multiple of 16: two pairs per trip (the transposed partials alternate between two register sets)
-  for (unsigned q = 0; q < nunits; q += 4) {
+  for (unsigned q = 0; q < nseq; q += 4) {
     unit(q, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     unit(q + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
     unit(q + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -480,14 +509,14 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   if constexpr (NB == 2) asm volatile(MFMA_DRAIN : "+v"(zcs[1][0][0]), "+v"(zcs[1][0][1]), "+v"(zcs[1][1][0]), "+v"(zcs[1][1][1]));
   else asm volatile(MFMA_DRAIN : "+v"(zcs[1][0][0]), "+v"(zcs[1][1][0]));
 #pragma unroll
-  for (int w = 0; w < 4 * NB; ++w) z_write(zcs[1], (nunits >> 1) - 1, w);
+  for (int w = 0; w < 4 * NB; ++w) z_write(zcs[1], (nseq >> 1) - 1, w);
   __syncthreads();
 #pragma unroll
   for (int un = 2; un >= 1; --un) {
 #pragma unroll
-    for (int sl = 0; sl < NRS; ++sl) sum_issue(nunits - un, sl);
+    for (int sl = 0; sl < NRS; ++sl) sum_issue(nseq - un, sl);
 #pragma unroll
-    for (int t = 0; t < NB; ++t) sum_finish(nunits - un, t);
+    for (int t = 0; t < NB; ++t) sum_finish(nseq - un, t);
   }
   __syncthreads();
   flush_strip(nunits / UPS - 1);
@@ -506,23 +535,26 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   // half-step and one group at a time through the transposition scratch so that they leave as 256-byte rows
   double* outD = slabD + (int64_t)items[4 * item + 3] * R * 16 * SYM_TB;
 #pragma unroll
-  for (int bcb = 0; bcb < NB; ++bcb) {
-    const int kc = kcols - 16 * bcb < 16 ? kcols - 16 * bcb : 16;
+  for (int sl = 0; sl < NSL; ++sl) {
 #pragma unroll
-    for (int hs = 0; hs < 4; ++hs) {
-      asm volatile(MFMA_DRAIN : "+v"(acc[hs][0][bcb]), "+v"(acc[hs][1][bcb]));
+    for (int bcb = 0; bcb < NB; ++bcb) {
+      const int kc = kcols - 16 * bcb < 16 ? kcols - 16 * bcb : 16;
 #pragma unroll
-      for (int par = 0; par < 2; ++par)
+      for (int hs = 0; hs < 4; ++hs) {
+        asm volatile(MFMA_DRAIN : "+v"(acc[sl][hs][0][bcb]), "+v"(acc[sl][hs][1][bcb]));
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) tw[c * RS + 2 * (g + 4 * reg) + par] = acc[hs][par][bcb][reg];
-      // wave-private scratch, in-order DS: the reads below see the writes above
+        for (int par = 0; par < 2; ++par)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int e = lane + 64 * t;                      // (block column, row of the half-step)
-        const int bc = e >> 5, r = e & 31;
-        const double v = tw[bc * RS + r];
-        if (bc < kc && have_row)
-          outD[bcb * slabD_gstride + ((int64_t)(wave >> 1) * 16 + bc) * SYM_TB + 128 * rhalf + 32 * hs + r] = v;
+          for (int reg = 0; reg < 4; ++reg) tw[c * RS + 2 * (g + 4 * reg) + par] = acc[sl][hs][par][bcb][reg];
+        // wave-private scratch, in-order DS: the reads below see the writes above
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int e = lane + 64 * t;                      // (block column, row of the half-step)
+          const int bc = e >> 5, r = e & 31;
+          const double v = tw[bc * RS + r];
+          if (bc < kc && have_row[sl])
+            outD[bcb * slabD_gstride + ((int64_t)(2 * sl + (wave >> 1)) * 16 + bc) * SYM_TB + 128 * rhalf + 32 * hs + r] = v;
+        }
       }
     }
   }
@@ -531,14 +563,15 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   asm volatile("" ::: "a128", "a255");
 }
 
-void launch_matvec_symw(hipStream_t st, int nbw, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,
+void launch_matvec_symw(hipStream_t st, int nbw, bool tall, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,
                         const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
                         int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   dim3 grid(nitems * nwg), block(256);
-  if (nbw == 2)
-    hipLaunchKernelGGL((matvec_symw_kernel<2>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, nwg,
-                       xt_gstride, slabD_gstride, slabT_gstride, nb);
-  else
-    hipLaunchKernelGGL((matvec_symw_kernel<1>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, nwg,
-                       xt_gstride, slabD_gstride, slabT_gstride, nb);
+#define SYMW_LAUNCH(NBW, T)                                                                                                          \
+  hipLaunchKernelGGL((matvec_symw_kernel<NBW, T>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
+                     nwg, xt_gstride, slabD_gstride, slabT_gstride, nb)
+  if (nbw == 2) SYMW_LAUNCH(2, false);
+  else if (tall) SYMW_LAUNCH(1, true);
+  else SYMW_LAUNCH(1, false);
+#undef SYMW_LAUNCH
 }

@@ -107,9 +107,10 @@ void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT,
 void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool tiles_f32, const int64_t* row_off, OpParams op, int64_t n,
                         int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
                         double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
-// the same sweep (stored fp64 tiles, R = 2) with one wave per SIMD and 16 nbw block columns per workgroup (k_matvec_symw.hip);
-// nwg workgroups per work item cover the 16-column groups [0, nbw nwg) of the block
-void launch_matvec_symw(hipStream_t st, int nbw, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,
+// the same sweep (stored fp64 tiles) with one wave per SIMD and 16 nbw block columns per workgroup (k_matvec_symw.hip): R = 2 block
+// rows per workgroup, or (tall, nbw = 1: the work items of the R = 4 schedule) four; nwg workgroups per work item cover the
+// 16-column groups [0, nbw nwg) of the block
+void launch_matvec_symw(hipStream_t st, int nbw, bool tall, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,
                         const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
                         int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
 // fp32 copy of `count` stored tile entries (count a multiple of 4)

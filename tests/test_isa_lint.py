@@ -70,7 +70,7 @@ def kernels(tmp_path_factory):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-c",
                     "-o", str(out) + ".o", SRC], check=True, capture_output=True, timeout=600)
     ks = _kernels(out.read_text())
-    assert len(ks) == 2, list(ks)
+    assert len(ks) == 3, list(ks)
     return ks
 
 
