@@ -33,7 +33,9 @@ int sym_schedule(const E* e, int kk, bool stored_fp64) {
   // More than 8 columns (R = 1 | 2, k = 16 / 32 / 64, profiles/experiments/r03_small_n_schedule.log): N=20000 (79 block rows)
   // 0.455 | 0.427, 0.665 | 0.647, 1.26 | 1.12 ms; N=40000 1.51 | 1.50, 2.31 | 2.05, 4.58 | 3.67; N=60000 3.04 | 2.79, 5.09 | 4.18,
   // 10.1 | 7.54.
-  int R = kk <= 8 ? (nb >= 200 ? 4 : 1) : (nb >= (stored_fp64 ? 64 : 200) ? 2 : 1);   // generated / fp32 tiles: the two-wave kernels, as before
+  // (k <= 8 between 64 and 200 block rows, stored fp64 tiles: the wide kernel is 2-4 % ahead of the one-block-row kernel end to end:
+  // N=20000 0.431 | 0.415, N=30000 0.863 | 0.847, N=50000 2.06 | 2.03 ms, profiles/experiments/r03_small_n_schedule.log)
+  int R = nb >= 200 ? (kk <= 8 ? 4 : 2) : (nb >= 64 && stored_fp64 ? 2 : 1);   // generated / fp32 tiles: the two-wave kernels from 200 on, as before
   // 9-16 columns of stored fp64 tiles: the wide kernel on FOUR block rows per workgroup (half as many transposed partials written
   // by a sweep that is HBM-bound there); DAV_SYM_TALL=0: two (A/B runs)
   const char* tv = getenv("DAV_SYM_TALL");
