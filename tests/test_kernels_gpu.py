@@ -387,8 +387,8 @@ def test_symmetric_super_row_schedules_at_a_size_that_selects_them(n, k):
     """From 200 block rows on the sweep runs the super-row schedules (4 block rows per workgroup for k <= 8, else 2)
     by itself: N=51700 (202 block rows, a ragged last super row), the same generated matrix in full storage
     as the reference, stored tiles and the hashed operator generated in the sweep.  Stored fp64 tiles and more than 8
-    columns: two block rows per workgroup (the wide kernel) from 64 block rows on - N=16700 has 66, an odd last super row
-    (k = 8 and the generated operator stay on the one-block-row kernel there)."""
+    columns: two block rows per workgroup (the wide kernel; 9-16 columns from 200 block rows on: four) from 64 block rows on -
+    N=16700 has 66, an odd last super row (the generated operator stays on the one-block-row kernel there)."""
     X = np.random.default_rng(k).standard_normal((n, k))
     with fd.CEngine(n=n, max_cols=64) as e:
         e.set_dense_generated(OP_A, 5, 1e-3)
