@@ -86,7 +86,7 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     e->ov_ready = true;
   }
   const int64_t total_rows = (int64_t)e->nranks * e->nslab;
-  const bool use32 = inner && inner_f32_tiles(e, o);
+  const bool use32 = false;                            // chunks of 32 columns: the fp64 tiles on the wide kernel (see apply_ptr)
   const int R = 2;                                     // 32-column chunks: the paired two-block-row schedule
   const E::SymPlan* pl = &e->sym_plan[0];
   const int64_t dstride = (int64_t)pl->nitems * R * 16 * SYM_TB, tstride = pl->zslots * 16 * SYM_TB;
@@ -197,7 +197,9 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;
-      const bool use32 = inner && inner_f32_tiles(e, o);
+      // fp32 tiles (inner sweeps of the GJD correction, opt-in) where the sweep is bound by bytes: up to 16 columns.  Wider ones
+      // are bound by the fp64 matrix pipe either way, and the one-wave-per-SIMD kernel on the fp64 tiles is the faster of the two
+      const bool use32 = inner && kk <= 16 && inner_f32_tiles(e, o);
       int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, kk, o.kind == DAV_KIND_DENSE && !use32);
       if (use32 && R == 1) R = 2;            // the fp32 tiles are read by the super-row kernels only
       const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
