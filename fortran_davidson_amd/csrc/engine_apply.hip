@@ -37,8 +37,15 @@ void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, 
   const int wide = sym_wide_level();
   if (o.kind == DAV_KIND_DENSE && !use32 && wide > 0 && ((R == 2 && (kk > 16 || wide > 1)) || (R == 4 && kk > 8 && kk <= 16))) {
     const int nbw = kk > 16 ? 2 : 1;
-    launch_matvec_symw(e->stream, nbw, R == 4, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+    launch_matvec_symw(e->stream, nbw, R == 4, false, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
                        (npair + nbw - 1) / nbw, e->xt_group_stride, dstride, tstride);
+    return;
+  }
+  // fp32 tiles (mixed-precision inner sweeps, up to 16 columns): the wide kernel's fp32 variant; DAV_SYM_WIDE32=0: the two-wave kernel
+  static const int wide32 = [] { const char* ev = getenv("DAV_SYM_WIDE32"); return ev ? atoi(ev) : 1; }();
+  if (o.kind == DAV_KIND_DENSE && use32 && wide > 1 && wide32 && R == 2 && kk <= 16) {
+    launch_matvec_symw(e->stream, 1, false, true, o.a32, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+                       npair, e->xt_group_stride, dstride, tstride);
     return;
   }
   launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,

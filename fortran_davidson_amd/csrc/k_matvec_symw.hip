@@ -56,6 +56,8 @@ __device__ __forceinline__ void symw_static_for(F&& f) { symw_static_for_impl(f,
 #define SYMW_RING(k, u) (224 - 16 * NSLOT + 16 * (k) + 4 * (u))
 #define SYMW_XJ(s, u, bcb) (224 + 16 * (s) + 4 * (u) + 2 * (bcb))
 #define SYMW_P(par, ib, j) (128 + 16 * (par) + 8 * (ib) + 4 * (j))
+// fp32 tiles: raw ring slot k, load u in FIXED VGPRs v[224 + 8 k + 2 u .. + 1] (tests/test_isa_lint.py: the compiler stays below v224)
+#define SYMW_RAW(k, u) (224 + 8 * (k) + 2 * (u))
 constexpr int symw_fixed_lo() { return 128; }   // first fixed register (tests/test_isa_lint.py)
 
 __device__ double symw_zero_page[16 * 16];     // B operand of a tile that is not there
@@ -97,13 +99,21 @@ __device__ __forceinline__ i32x4 symw_desc(const void* p, int bytes) {
 // separates it from the 8-column path).  The sequence the loop walks is (unit 0, slice 0), (unit 0, slice 1), (unit 1, slice 0)
 // ...: a "pair" is then the two slices of ONE unit, everything else - ring, Gram operands, X_J sets (one per slice: a slice
 // without a tile reads zeros), slots, exchange - is the two-block-row kernel's.
-template <int NB, bool TALL>
-__global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
+// F32 (NB = 1, two block rows; the opt-in mixed-precision inner sweeps of the GJD correction): the tiles are an fp32 copy of the
+// stored operator - half the bytes of a sweep that is byte-bound at 16 columns.  The loads land in FIXED VGPRs v[224:255] (a
+// 4-slot ring of raw fp32 pairs), a burst of 8 v_cvt_f64_f32 in front of a half-step's MFMAs widens the NEXT half-step's
+// sub-block into ordinary registers, and from there on everything is fp64: the direct product's A operand and the LDS
+// transposition take those registers instead of the ring, products and sums are the fp64 kernel's.
+template <int NB, bool TALL, bool F32>
+__global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restrict__ tiles_any, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items, const int* __restrict__ zslot_begin,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
                                                              double* __restrict__ slabT, int kcols, int nwg, int64_t xt_gstride,
                                                              int64_t slabD_gstride, int64_t slabT_gstride, int nb) {
   static_assert(!TALL || NB == 1, "two slices per wave: 16 columns per workgroup");
+  static_assert(!F32 || (NB == 1 && !TALL), "fp32 tiles: 16 columns, two block rows per workgroup");
+  using TileT = std::conditional_t<F32, float, double>;
+  const TileT* __restrict__ tiles = static_cast<const TileT*>(tiles_any);
   constexpr int R = TALL ? 4 : 2;       // block rows per workgroup
   constexpr int NSL = TALL ? 2 : 1;     // 128-row slices per wave
   constexpr int NRS = 4;                // 128-row slices = waves
@@ -195,12 +205,12 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   // 4u + g), the half-step as a scalar offset: no vector address arithmetic in the loop
   unsigned voff[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) voff[u] = ((4 * u + g) * SYM_TB + 2 * c) * (unsigned)sizeof(double);
+  for (int u = 0; u < 4; ++u) voff[u] = ((4 * u + g) * SYM_TB + 2 * c) * (unsigned)sizeof(TileT);
   // Tile this wave works on in tile column J: its own if it is stored, else the (stored) tile of block row Imax (masked).
   // The tiles of a block row are contiguous in J and a unit is 16 tile columns = 32 KiB of a tile: the sub-block of unit q
   // starts (J0 16 + q) 32 KiB behind the block row's first tile - linear in q, no division, no per-unit table look-up
   // (a scalar instruction costs ~5 cycles of matrix-pipe time here, profiles/ubench/r03_fatwave_vgpr_acc.log).
-  constexpr int64_t UNIT_BYTES = 16 * SYM_TB * (int64_t)sizeof(double);
+  constexpr int64_t UNIT_BYTES = 16 * SYM_TB * (int64_t)sizeof(TileT);
   const int64_t unit0 = (int64_t)J0 * UPJ * UNIT_BYTES;
   const char* const trow_max = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
   const char* trow_own[NSL];
@@ -225,8 +235,16 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     constexpr int SLOT = decltype(slot)::value, U = decltype(uc)::value;
     const unsigned vo = voff[U];           // (operands of an asm statement inside a generic lambda are not captured by themselves)
     const i32x4 dd = d;
-    const int soo = hs * 32 * (int)sizeof(double);
-    if constexpr (U == 0 && decltype(fresh)::value)
+    const int soo = hs * 32 * (int)sizeof(TileT);
+    if constexpr (F32) {
+      // raw fp32 pair (rows 2c, 2c + 1 of tile column 4u + g) -> v[SYMW_RAW(SLOT, U) .. + 1]
+      if constexpr (U == 0 && decltype(fresh)::value)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx2 v[%c0:%c1], %2, %3, %4 offen"
+                     :: "i"(SYMW_RAW(SLOT, U)), "i"(SYMW_RAW(SLOT, U) + 1), "v"(vo), "s"(dd), "s"(soo) : "memory");
+      else
+        asm volatile("buffer_load_dwordx2 v[%c0:%c1], %2, %3, %4 offen"
+                     :: "i"(SYMW_RAW(SLOT, U)), "i"(SYMW_RAW(SLOT, U) + 1), "v"(vo), "s"(dd), "s"(soo) : "memory");
+    } else if constexpr (U == 0 && decltype(fresh)::value)
       asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[%c0:%c1], %2, %3, %4 offen"
                    :: "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "v"(vo), "s"(dd), "s"(soo) : "memory");
     else
@@ -273,6 +291,23 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     const unsigned wa = tw_wr;
     asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3"
                  :: "v"(wa), "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "i"(4 * U * TRS * (int)sizeof(double)) : "memory");
+  };
+  // F32: the widened sub-blocks, [half-step parity][column quad] = rows 2c, 2c + 1 of tile column 4u + g
+  f64x2 wide[F32 ? 2 : 1][4];
+  auto ds_w_reg = [&](auto uc, const f64x2& v) {
+    constexpr int U = decltype(uc)::value;
+    const unsigned wa = tw_wr;
+    const f64x2 vv = v;
+    asm volatile("ds_write_b128 %0, %1 offset:%c2" :: "v"(wa), "v"(vv), "i"(4 * U * TRS * (int)sizeof(double)) : "memory");
+  };
+  auto widen = [&](auto slot, f64x2 (&w)[4]) {      // raw ring slot -> fp64
+    constexpr int SLOT = decltype(slot)::value;
+    symw_static_for<4>([&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      double x, y;
+      asm volatile("v_cvt_f64_f32 %0, v%c2\n\tv_cvt_f64_f32 %1, v%c3" : "=&v"(x), "=&v"(y) : "i"(SYMW_RAW(SLOT, U)), "i"(SYMW_RAW(SLOT, U) + 1));
+      w[U] = f64x2{x, y};
+    });
   };
   auto ds_r = [&](auto parc, auto tc) {
     constexpr int PAR = decltype(parc)::value, IB = decltype(tc)::value >> 1, JJ = decltype(tc)::value & 1;
@@ -362,7 +397,12 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
     symw_static_for<4>([&](auto uc) { t_load(std::integral_constant<int, st % NSLOT>{}, uc, ud[st / 4], st % 4, std::true_type{}); });
   });
   asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
-  symw_static_for<4>([&](auto uc) { ds_w(std::integral_constant<int, 0>{}, uc); });
+  if constexpr (F32) {
+    widen(std::integral_constant<int, 0>{}, wide[0]);
+    symw_static_for<4>([&](auto uc) { ds_w_reg(uc, wide[0][decltype(uc)::value]); });
+  } else {
+    symw_static_for<4>([&](auto uc) { ds_w(std::integral_constant<int, 0>{}, uc); });
+  }
   symw_static_for<4>([&](auto tc) { ds_r(std::integral_constant<int, 0>{}, tc); });
 
   f64x4 zcs[2][2][NB];               // transposed partials: [pair parity][unit of the pair][group]
@@ -409,6 +449,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
       STAMP(w1);
       st_vm += w1 - w0;
 #endif
+      if constexpr (F32) widen(std::integral_constant<int, (hs + 1) % NSLOT>{}, wide[(hs + 1) & 1]);   // ONE VALU burst per half-step
       // The memory operations of the half-step, one slot behind every second MFMA: the transposition of step s + 1 (ring slot
       // -> LDS -> Gram operands of the other parity; its reads are 16 NB MFMAs old when the next half-step starts), the tile
       // loads of step s + DEPTH (their ring slot held step s - 1, whose MFMAs and DS reads have been issued), X_J of unit q + 1
@@ -431,8 +472,13 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
           if constexpr (hs == 2 && (k == 12 || k == 14)) sum_finish(q - 2, (k - 12) / 2);
         } else {
           if constexpr (k < 2) {
-            ds_w(WS{}, std::integral_constant<int, 2 * k>{});
-            ds_w(WS{}, std::integral_constant<int, 2 * k + 1>{});
+            if constexpr (F32) {
+              ds_w_reg(std::integral_constant<int, 2 * k>{}, wide[(hs + 1) & 1][2 * k]);
+              ds_w_reg(std::integral_constant<int, 2 * k + 1>{}, wide[(hs + 1) & 1][2 * k + 1]);
+            } else {
+              ds_w(WS{}, std::integral_constant<int, 2 * k>{});
+              ds_w(WS{}, std::integral_constant<int, 2 * k + 1>{});
+            }
           } else if constexpr (k < 4) {
             ds_r(NP{}, std::integral_constant<int, 2 * (k - 2)>{});
             ds_r(NP{}, std::integral_constant<int, 2 * (k - 2) + 1>{});
@@ -462,6 +508,25 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
           f64x4 &d0 = acc[SL][hs][0][bcb], &d1 = acc[SL][hs][1][bcb], &zz = zc[bcb];
           const double x0 = xI[SL][hs][ib][j][0][bcb], x1 = xI[SL][hs][ib][j][1][bcb];
           // two MFMAs per statement: direct (rows of parity 0 / 1), transposed (the row pair's first / second row)
+          if constexpr (F32) {
+            // the direct product's A operand is the widened sub-block (ordinary registers) instead of the ring
+            const double a0 = wide[hs & 1][u].x, a1 = wide[hs & 1][u].y;
+            if constexpr (hs == 0 && u == 0)
+              asm volatile("v_mfma_f64_16x16x4_f64 %0, %3, a[%c4:%c5], %0\n\t"
+                           "v_mfma_f64_16x16x4_f64 %1, a[%c6:%c7], %2, 0"
+                           : "+v"(d0), "=&v"(zz)
+                           : "a"(x0), "v"(a0), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1), "i"(SYMW_P(hs & 1, ib, j)), "i"(SYMW_P(hs & 1, ib, j) + 1));
+            else
+              asm volatile("v_mfma_f64_16x16x4_f64 %0, %3, a[%c4:%c5], %0\n\t"
+                           "v_mfma_f64_16x16x4_f64 %1, a[%c6:%c7], %2, %1"
+                           : "+v"(d0), "+v"(zz)
+                           : "a"(x0), "v"(a0), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1), "i"(SYMW_P(hs & 1, ib, j)), "i"(SYMW_P(hs & 1, ib, j) + 1));
+            mem_slot(std::integral_constant<int, 2 * gi>{});
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %3, a[%c4:%c5], %0\n\t"
+                         "v_mfma_f64_16x16x4_f64 %1, a[%c6:%c7], %2, %1"
+                         : "+v"(d1), "+v"(zz)
+                         : "a"(x1), "v"(a1), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1), "i"(SYMW_P(hs & 1, ib, j) + 2), "i"(SYMW_P(hs & 1, ib, j) + 3));
+          } else {
           if constexpr (hs == 0 && u == 0)
             asm volatile("v_mfma_f64_16x16x4_f64 %0, a[%c3:%c4], a[%c5:%c6], %0\n\t"
                          "v_mfma_f64_16x16x4_f64 %1, a[%c7:%c8], %2, 0"
@@ -480,6 +545,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
                        : "+v"(d1), "+v"(zz)
                        : "a"(x1), "i"(SYMW_RING(hs, u) + 2), "i"(SYMW_RING(hs, u) + 3), "i"(SYMW_XJ(SET, u, bcb)), "i"(SYMW_XJ(SET, u, bcb) + 1),
                          "i"(SYMW_P(hs & 1, ib, j) + 2), "i"(SYMW_P(hs & 1, ib, j) + 3));
+          }
           mem_slot(std::integral_constant<int, 2 * gi + 1>{});
         });
       });
@@ -561,17 +627,19 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const double* __res
   // block rows of the super row past the end of the matrix: their slab rows are read by nobody
   // the fixed registers belong to this kernel: the descriptor must allocate all 256 accumulation registers
   asm volatile("" ::: "a128", "a255");
+  if constexpr (F32) asm volatile("" ::: "v224", "v255");
 }
 
-void launch_matvec_symw(hipStream_t st, int nbw, bool tall, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,
-                        const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
+void launch_matvec_symw(hipStream_t st, int nbw, bool tall, bool tiles_f32, const void* tiles, const int64_t* row_off, int nb, const int* items_dev,
+                        int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
                         int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   dim3 grid(nitems * nwg), block(256);
-#define SYMW_LAUNCH(NBW, T)                                                                                                          \
-  hipLaunchKernelGGL((matvec_symw_kernel<NBW, T>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
+#define SYMW_LAUNCH(NBW, T, F)                                                                                                          \
+  hipLaunchKernelGGL((matvec_symw_kernel<NBW, T, F>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
                      nwg, xt_gstride, slabD_gstride, slabT_gstride, nb)
-  if (nbw == 2) SYMW_LAUNCH(2, false);
-  else if (tall) SYMW_LAUNCH(1, true);
-  else SYMW_LAUNCH(1, false);
+  if (tiles_f32) SYMW_LAUNCH(1, false, true);
+  else if (nbw == 2) SYMW_LAUNCH(2, false, false);
+  else if (tall) SYMW_LAUNCH(1, true, false);
+  else SYMW_LAUNCH(1, false, false);
 #undef SYMW_LAUNCH
 }

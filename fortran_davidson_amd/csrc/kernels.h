@@ -110,8 +110,9 @@ void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool
 // the same sweep (stored fp64 tiles) with one wave per SIMD and 16 nbw block columns per workgroup (k_matvec_symw.hip): R = 2 block
 // rows per workgroup, or (tall, nbw = 1: the work items of the R = 4 schedule) four; nwg workgroups per work item cover the
 // 16-column groups [0, nbw nwg) of the block
-void launch_matvec_symw(hipStream_t st, int nbw, bool tall, const double* tiles, const int64_t* row_off, int nb, const int* items_dev, int nitems,
-                        const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
+// tiles_f32 (nbw = 1, R = 2): `tiles` is the fp32 copy of the stored tiles (mixed-precision inner sweeps)
+void launch_matvec_symw(hipStream_t st, int nbw, bool tall, bool tiles_f32, const void* tiles, const int64_t* row_off, int nb, const int* items_dev,
+                        int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
                         int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
 // fp32 copy of `count` stored tile entries (count a multiple of 4)
 void launch_tiles_to_f32(hipStream_t st, const double* src, float* dst, int64_t count);

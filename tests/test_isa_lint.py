@@ -4,7 +4,7 @@ The kernel's MFMAs are inline assembly (the compiler does not know them as such,
 out of the accumulation registers the kernel names literally).  The kernel header states the rules that make that safe; this
 test checks the EMITTED code for them:
   1. no compiler-generated instruction (outside ;;#ASMSTART / ;;#ASMEND) names the kernel's fixed registers (a[128:255]: Gram-layout operands,
-     load ring, X_J operand);
+     load ring, X_J operand; the fp32-tile variant: v[224:255] too, its raw load ring);
   2. no VALU instruction writes a register that an MFMA reads within the next two instructions (2 wait states);
   3. a register written by an MFMA is read by a non-MFMA instruction only after an `s_nop 15` (+ `s_nop 3`): 18+ wait states -
      or after three later MFMAs of the wave (each holds the matrix pipe for 16 passes: the result is two MFMAs old at least);
@@ -70,7 +70,7 @@ def kernels(tmp_path_factory):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-c",
                     "-o", str(out) + ".o", SRC], check=True, capture_output=True, timeout=600)
     ks = _kernels(out.read_text())
-    assert len(ks) == 3, list(ks)
+    assert len(ks) == 4, list(ks)
     return ks
 
 
@@ -98,6 +98,8 @@ def test_compiler_code_stays_out_of_the_fixed_registers(kernels):
             for t in ops:
                 f, r = _regs(t)
                 assert not (f == "a" and r and max(r) >= lo), (name, ln)
+                # the fp32-tile variant keeps its raw load ring in fixed VGPRs v[224:255] (SYMW_RAW in the kernel file)
+                assert not ("ELb0ELb1E" in name and f == "v" and r and max(r) >= 224), (name, ln)
 
 
 def test_mfma_hazards(kernels):
