@@ -38,13 +38,18 @@ int collect_events(E* e) {
       e->st.panel_ms += ms;
     } else {
       e->st.comm_ms += ms;
+      if (e->ev_kind[i] == 5) { e->st.allgather_ms += ms; e->st.allgather_bytes += e->ev_bytes[i]; }
+      else if (e->ev_kind[i] == 6) { e->st.reduce_scatter_ms += ms; e->st.reduce_scatter_bytes += e->ev_bytes[i]; }
+      else if (e->ev_kind[i] == 7) { e->st.allreduce_ms += ms; e->st.allreduce_bytes += e->ev_bytes[i]; }
     }
   }
   e->ev_used = 0;
   return 0;
 }
 // begin/end record an event pair on the stream; collect_events() turns pairs into milliseconds
-int timed_begin(E* e, int kind, double bytes, int* slot) {
+int timed_begin(E* e, int kind, double bytes, int* slot) { return timed_begin_on(e, kind, bytes, slot, e->stream); }
+int timed_end(E* e, int slot) { return timed_end_on(e, slot, e->stream); }
+int timed_begin_on(E* e, int kind, double bytes, int* slot, hipStream_t stream) {
   // an event pair costs ~5 us of host time: by default only the block apply is timed - kind 0 = end to end
   // (pack + all-gather + kernel + reduction), kind 4 = the block-matvec kernel alone (the roofline kernel);
   // dav_set_timing(h, 2) adds the Gram / panel / collective phases
@@ -57,13 +62,13 @@ int timed_begin(E* e, int kind, double bytes, int* slot) {
   e->ev_done[*slot] = false;
   e->ev_kind[*slot] = kind;
   e->ev_bytes[*slot] = bytes;
-  HIPCHK(hipEventRecord(e->ev[*slot][0], e->stream));
+  HIPCHK(hipEventRecord(e->ev[*slot][0], stream));
   return 0;
 }
-int timed_end(E* e, int slot) {
+int timed_end_on(E* e, int slot, hipStream_t stream) {
   if (slot < 0) return 0;
   if (e->ev_open > 0) --e->ev_open;
-  HIPCHK(hipEventRecord(e->ev[slot][1], e->stream));
+  HIPCHK(hipEventRecord(e->ev[slot][1], stream));
   e->ev_done[slot] = true;
   return 0;
 }
@@ -125,7 +130,7 @@ int check_panel(E* e, int panel, int c0, int k) {
 
 // ------------------------------------------------------------------------------------------------
 extern "C" const char* dav_last_error(void) { return g_err.c_str(); }
-extern "C" int dav_version(void) { return 100; }
+extern "C" int dav_version(void) { return DAV_HIP_ABI_VERSION; }
 
 
 extern "C" int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, int gev, int rank, int nranks) {
@@ -147,7 +152,29 @@ extern "C" int dav_create(dav_handle_t* h, int device, int64_t n, int max_cols, 
   return 0;
 }
 
+// every tuning / A-B knob of the engine, read here and nowhere else
+Tune tune_from_env() {
+  Tune t;
+  auto geti = [](const char* name, int dflt) { const char* ev = getenv(name); return ev && *ev ? atoi(ev) : dflt; };
+  t.sym_wide = geti("DAV_SYM_WIDE", t.sym_wide);
+  t.sym_wide32 = geti("DAV_SYM_WIDE32", t.sym_wide32);
+  t.sym_pair = geti("DAV_SYM_PAIR", t.sym_pair);
+  t.sym_quad = geti("DAV_SYM_QUAD", t.sym_quad);
+  t.sym_overlap = geti("DAV_SYM_OVERLAP", t.sym_overlap);
+  t.sym_r = geti("DAV_SYM_R", t.sym_r);
+  t.sym_tall = geti("DAV_SYM_TALL", t.sym_tall);
+  t.sym_run = std::max(0, geti("DAV_SYM_RUN", 0));
+  t.sym_run9 = std::max(0, geti("DAV_SYM_RUN9", 0));
+  t.sym_mfma4 = geti("DAV_SYM_MFMA4", t.sym_mfma4);
+  t.mv_target = std::max(0, geti("DAV_MV_TARGET", 0));
+  t.mv_nsplit = std::max(0, geti("DAV_MV_NSPLIT", 0));
+  t.b_resident = geti("DAV_B_RESIDENT", t.b_resident);
+  t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
+  return t;
+}
+
 int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, int nranks) {
+  e->tune = tune_from_env();
   e->device = device;
   e->n = n;
   e->rank = rank;
@@ -177,7 +204,7 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   HIPCHK(hipMalloc(&e->xt, sizeof(double) * e->xt_group_stride * 4));
   HIPCHK(hipMemsetAsync(e->xt, 0, sizeof(double) * e->xt_group_stride * 4, e->stream));
   int nsplit, jc;
-  matvec_plan(e->nloc_pad, e->ncols_pad, 4, &nsplit, &jc);
+  matvec_plan(e->nloc_pad, e->ncols_pad, 4, &nsplit, &jc, e->tune.mv_target, e->tune.mv_nsplit);
   size_t s1 = matvec_slab_doubles(e->nloc_pad, 4, nsplit);
   size_t s2 = gram_scratch_doubles(e->cols_alloc, e->cols_alloc, e->nloc_pad);
   e->scratch_doubles = std::max(s1, s2);
@@ -242,7 +269,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
     { std::lock_guard<std::mutex> lk(e->wd->mu); e->wd->stop = true; }
     e->wd->cv.notify_all();
     e->wd->th.join();
-    for (Watchdog::Item& x : e->wd->it) if (x.ev) hipEventDestroy(x.ev);
+    for (Watchdog::Lane& l : e->wd->lane) { if (l.check.ev) hipEventDestroy(l.check.ev); if (l.latest.ev) hipEventDestroy(l.latest.ev); }
     delete e->wd;
     e->wd = nullptr;
   }
@@ -276,11 +303,17 @@ extern "C" int dav_synchronize(dav_handle_t e) {
   return 0;
 }
 
-extern "C" int dav_get_stats(dav_handle_t e, dav_stats* out) {
+extern "C" int dav_get_stats(dav_handle_t e, dav_stats* out) { return dav_get_stats_n(e, out, sizeof(dav_stats)); }
+
+// at most `bytes` bytes of the structure: a caller built against an older, shorter layout passes its own sizeof
+extern "C" int dav_get_stats_n(dav_handle_t e, void* out, size_t bytes) {
+  if (!out) return fail("dav_get_stats: null output");
   CHK(bind(e));
   CHK(collect_events(e));
   e->st.m = e->m;
-  *out = e->st;
+  e->st.comm_ranks = e->comm_ranks;
+  e->st.comm_overlap = (e->comm && (e->tune.sym_overlap < 0 ? e->nranks > 1 : e->tune.sym_overlap != 0)) ? 1 : 0;
+  std::memcpy(out, &e->st, std::min(bytes, sizeof(dav_stats)));
   return 0;
 }
 

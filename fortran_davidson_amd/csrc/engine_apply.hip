@@ -24,33 +24,28 @@ bool inner_f32_tiles(E* e, OpDesc& o) {
 // The super-row sweep of one launch: stored fp64 tiles, two block rows per workgroup and more than 8 columns run the
 // one-wave-per-SIMD kernel (k_matvec_symw.hip: 32 columns per workgroup, or 16 for a block of <= 16); generated operators,
 // the fp32 copy and the k <= 8 schedule (R = 4, 4x4x4 MFMA) stay on matvec_sym9_kernel.
-// DAV_SYM_WIDE = 0: never (A/B runs), 1: blocks wider than 16 columns only, 2 (default): from 9 columns on.  Read per call.
-// DAV_SYM_WIDE: 2 (default) the one-wave-per-SIMD kernel for more than 8 columns, 1 for more than 16 only, 0 never (A/B runs)
-static int sym_wide_level() {
-  const char* ev = getenv("DAV_SYM_WIDE");                // read per call: A/B runs flip it inside one process
-  return ev ? atoi(ev) : 2;
-}
-bool sym_wide_enabled() { return sym_wide_level() > 1; }   // ... for 9-16 columns too
+// Tune::sym_wide (DAV_SYM_WIDE at dav_create) = 2 (default): the one-wave-per-SIMD kernel for more than 8 columns, 1: for more
+// than 16 only, 0: never (A/B runs)
+bool sym_wide_enabled(const E* e) { return e->tune.sym_wide > 1; }   // ... for 9-16 columns too
 
 void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
                        int npair, int64_t dstride, int64_t tstride) {
-  const int wide = sym_wide_level();
+  const int wide = e->tune.sym_wide;
   if (o.kind == DAV_KIND_DENSE && !use32 && wide > 0 && ((R == 2 && (kk > 16 || wide > 1)) || (R == 4 && kk > 8 && kk <= 16))) {
     const int nbw = kk > 16 ? 2 : 1;
     launch_matvec_symw(e->stream, nbw, R == 4, false, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
                        (npair + nbw - 1) / nbw, e->xt_group_stride, dstride, tstride);
     return;
   }
-  // fp32 tiles (mixed-precision inner sweeps, up to 16 columns): the wide kernel's fp32 variant; DAV_SYM_WIDE32=0: the two-wave kernel
-  static const int wide32 = [] { const char* ev = getenv("DAV_SYM_WIDE32"); return ev ? atoi(ev) : 1; }();
-  if (o.kind == DAV_KIND_DENSE && use32 && wide > 1 && wide32 && R == 2 && kk <= 16) {
+  // fp32 tiles (mixed-precision inner sweeps, up to 16 columns): the wide kernel's fp32 variant; Tune::sym_wide32 = 0: the two-wave kernel
+  if (o.kind == DAV_KIND_DENSE && use32 && wide > 1 && e->tune.sym_wide32 && R == 2 && kk <= 16) {
     launch_matvec_symw(e->stream, 1, false, true, o.a32, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
                        npair, e->xt_group_stride, dstride, tstride);
     return;
   }
   launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
                      o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk,
-                     slabD, slabT, npair, e->xt_group_stride, dstride, tstride);
+                     slabD, slabT, npair, e->xt_group_stride, dstride, tstride, e->tune.sym_mfma4 != 0);
 }
 
 
@@ -108,12 +103,13 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     launch_pack_xt(e->stream, src + (int64_t)i * step * e->ldp, e->ldp, e->nloc, e->nslab, kk, xt_of(i), e->xt_group_stride, e->row0);
     HIPCHK(hipEventRecord(e->ov_packed[p], e->stream));
     HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_packed[p], 0));
-    CHK(coll_group_begin(e));
+    CollGroup grp(e);
+    CHK(grp.begin(5, 8.0 * (double)e->nslab * 16 * ng * e->nranks, e->comm_stream));
     for (int g = 0; g < ng; ++g) {
       double* base = xt_of(i) + (size_t)g * e->xt_group_stride;
       NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, e->comm_stream));
     }
-    CHK(coll_group_end(e, "all-gather of a column chunk (second stream)", e->comm_stream));
+    CHK(grp.end("all-gather of a column chunk (second stream)", e->comm_stream));
     HIPCHK(hipEventRecord(e->ov_gathered[p], e->comm_stream));
     return 0;
   };
@@ -144,11 +140,14 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
                          e->nslab, total_rows);
     HIPCHK(hipEventRecord(e->ov_reduced[p], e->stream));
     HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_reduced[p], 0));
-    CHK(coll_group_begin(e));
-    for (int g = 0; g < npair; ++g)
-      NCCLCHK(g_rccl.ReduceScatter(e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16,
-                                   (size_t)e->nslab * std::min(16, kk - 16 * g), ncclDouble, ncclSum, e->comm, e->comm_stream));
-    CHK(coll_group_end(e, "reduce-scatter of a column chunk (second stream)", e->comm_stream));
+    {
+      CollGroup grp(e);
+      CHK(grp.begin(6, 8.0 * (double)e->nslab * kk * e->nranks, e->comm_stream));
+      for (int g = 0; g < npair; ++g)
+        NCCLCHK(g_rccl.ReduceScatter(e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16,
+                                     (size_t)e->nslab * std::min(16, kk - 16 * g), ncclDouble, ncclSum, e->comm, e->comm_stream));
+      CHK(grp.end("reduce-scatter of a column chunk (second stream)", e->comm_stream));
+    }
     HIPCHK(hipEventRecord(e->ov_scattered[p], e->comm_stream));
     if (i >= 1) CHK(to_panel(i - 1));                      // the previous chunk's rows of W, while this chunk's reduce-scatter runs
     if (which == DAV_OP_A) { e->st.applies += 1; e->st.apply_cols += kk; }
@@ -174,14 +173,12 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     // columns per launch as paired workgroups that share their tile reads through the memory-side cache.
     // Several ranks: each sweeps the block rows it stores against the all-gathered block and holds a partial of the
     // WHOLE product; one reduce-scatter per 16 columns sums the partials and leaves every rank its row slab.
-    static const int pair_env = [] { const char* ev = getenv("DAV_SYM_PAIR"); return ev ? atoi(ev) : 1; }();
     // pairing shares the READS of stored tiles: nothing to share when the entries are generated
-    int step = (pair_env && matvec_sym_can_pair() && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
+    int step = (e->tune.sym_pair && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
     // 64 columns (the widest expansion of the doubling policy below a basis of 128) as FOUR column groups in one launch on
     // the super-row kernels: the four workgroups of a work item share every tile read through their XCD's L2.  Same box,
-    // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  DAV_SYM_QUAD=0: off.
-    static const int quad_env = [] { const char* ev = getenv("DAV_SYM_QUAD"); return ev ? atoi(ev) : 1; }();
-    if (quad_env && step == 32 && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2 && !has_comm(e)) step = 64;
+    // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  Tune::sym_quad = 0: off.
+    if (e->tune.sym_quad && step == 32 && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2 && !has_comm(e)) step = 64;
     // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
     // reduce-scatter of this path through RCCL on a one-GPU box)
     const bool multi = e->nranks > 1 || has_comm(e);
@@ -192,11 +189,12 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     const int64_t* owned = multi ? e->sym_row_off : nullptr;
     const int64_t total_rows = (int64_t)e->nranks * e->nslab;
     {
-      // Opt-in (DAV_SYM_OVERLAP=1) until it has run on a multi-GPU node: the pipeline is exercised through a 1-rank RCCL
-      // communicator only, and a second stream on one communicator is exactly the kind of thing that must be seen on real
-      // links before it becomes the default of a run nobody can watch
-      static const int overlap_env = [] { const char* ev = getenv("DAV_SYM_OVERLAP"); return ev ? atoi(ev) : 0; }();
-      if (overlap_env && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
+      // Default over a real multi-rank communicator (Tune::sym_overlap = -1; DAV_SYM_OVERLAP=0 / 1 at dav_create forces it off / on,
+      // 1 also over the 1-rank communicator of the GPU tests): the collectives of a block wider than 32 columns run on a second
+      // stream under the sweeps.  All collectives of the pipeline are issued on that ONE stream in the same order on every rank,
+      // ordered against the engine's stream by events, so no two collectives of the communicator are ever in flight together.
+      const bool overlap = e->tune.sym_overlap < 0 ? e->nranks > 1 : e->tune.sym_overlap != 0;
+      if (overlap && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
         const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
         if (rc != 2) return rc;                        // 2: its streams / buffers / slabs could not be set up - serial path below
       }
@@ -218,21 +216,20 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
         if (npair > 2) { e->sym_no_quad = true; step = 32; kk = 32; npair = 2; }
         else { e->sym_no_pair = true; step = 16; kk = 16; npair = 1; }
       }
-      int slot = -1, kslot = -1, cslot = -1;
+      int slot = -1, kslot = -1;
       const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
       double bytes = stored + 16.0 * (double)e->n * kk;
       // end to end: everything that turns the source columns into W - packing, (all-gather,) the sweep, the fixed-order sum(, reduce-scatter)
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
       launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
       if (multi) {
-        CHK(timed_begin(e, 3, 0, &cslot));
-        CHK(coll_group_begin(e));
+        CollGroup grp(e);
+        CHK(grp.begin(5, 8.0 * (double)e->nslab * 16 * npair * e->nranks));
         for (int g = 0; g < npair; ++g) {
           double* base = e->xt + g * e->xt_group_stride;
           CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
         }
-        CHK(coll_group_end(e, "all-gather of the new block", e->stream));
-        CHK(timed_end(e, cslot));
+        CHK(grp.end("all-gather of the new block", e->stream));
       }
       if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
       double* slabT = e->sym_slab + (int64_t)npair * dstride;
@@ -259,15 +256,14 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
                             out, e->ldp, multi ? e->nslab : 0, total_rows);
       }
       if (multi) {
-        CHK(timed_begin(e, 3, 0, &cslot));
-        CHK(coll_group_begin(e));
+        CollGroup grp(e);
+        CHK(grp.begin(6, 8.0 * (double)e->nslab * kk * e->nranks));
         for (int g = 0; g < npair; ++g) {
           const int kg = std::min(16, kk - 16 * g);
           CHK(coll_reduce_scatter(e, e->sym_wpart + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16,
                                   (size_t)e->nslab * kg));
         }
-        CHK(coll_group_end(e, "reduce-scatter of the partial products", e->stream));
-        CHK(timed_end(e, cslot));
+        CHK(grp.end("reduce-scatter of the partial products", e->stream));
         for (int g = 0; g < npair; ++g)
           launch_chunk_to_panel(e->stream, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad,
                                 std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
@@ -290,18 +286,16 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
     launch_pack_xt(e->stream, src + (int64_t)c * e->ldp, e->ldp, e->nloc, e->nslab, kk, e->xt, e->xt_group_stride, e->row0);
     if (has_comm(e)) {
-      int cslot;
-      CHK(timed_begin(e, 3, 0, &cslot));
-      CHK(coll_group_begin(e));
+      CollGroup grp(e);
+      CHK(grp.begin(5, 8.0 * (double)e->nslab * 16 * groups * e->nranks));
       for (int g = 0; g < groups; ++g) {
         double* base = e->xt + g * e->xt_group_stride;
         CHK(coll_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
       }
-      CHK(coll_group_end(e, "all-gather of the new block", e->stream));
-      CHK(timed_end(e, cslot));
+      CHK(grp.end("all-gather of the new block", e->stream));
     }
     int nsplit, jc;
-    matvec_plan(e->nloc_pad, e->ncols_pad, ngroups, &nsplit, &jc);
+    matvec_plan(e->nloc_pad, e->ncols_pad, ngroups, &nsplit, &jc, e->tune.mv_target, e->tune.mv_nsplit);
     if (matvec_slab_doubles(e->nloc_pad, ngroups, nsplit) > e->scratch_doubles) return fail("matvec scratch too small");
     if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->nloc * (double)e->n * kk, &kslot));
     if (o.kind == DAV_KIND_DENSE)
@@ -332,6 +326,15 @@ extern "C" int dav_apply(dav_handle_t e, int which, int src_panel, int c0, int k
   if (which < 0 || which > 1) return fail("dav_apply: bad operator id");
   CHK(bind(e));
   return apply_impl(e, which, src_panel, c0, k, dst_panel, d0, true);
+}
+
+// dav_apply as the GJD correction solve issues it (csrc/davidson_hip_private.h): an inner sweep may read the fp32 copy of the tiles
+extern "C" int dav_apply_inner(dav_handle_t e, int which, int src_panel, int c0, int k, int dst_panel, int d0) {
+  if (which < 0 || which > 1) return fail("dav_apply_inner: bad operator id");
+  CHK(bind(e));
+  CHK(check_panel(e, src_panel, c0, k));
+  CHK(check_panel(e, dst_panel, d0, k));
+  return apply_ptr(e, which, panel_ptr(e, src_panel, c0), k, panel_ptr(e, dst_panel, d0), false, true);
 }
 
 // ---- measurement --------------------------------------------------------------------------------

@@ -22,6 +22,7 @@ int rccl_load() {
   SYM(GroupStart, "ncclGroupStart")
   SYM(GroupEnd, "ncclGroupEnd")
   SYM(GetErrorString, "ncclGetErrorString")
+  SYM(CommCount, "ncclCommCount")
 #undef SYM
   g_rccl.lib = lib;
   return 0;
@@ -38,15 +39,20 @@ void watchdog_loop(Watchdog* w) {
   while (!w->stop) {
     w->cv.wait_for(lk, std::chrono::milliseconds(200));
     const double now = wall_seconds();
-    for (Watchdog::Item& x : w->it) {
-      if (!x.active) continue;
-      const hipError_t q = hipEventQuery(x.ev);
-      if (q == hipSuccess) { x.active = false; continue; }
+    for (Watchdog::Lane& l : w->lane) {
+      if (!l.used || !l.check_active) continue;
+      const hipError_t q = hipEventQuery(l.check.ev);
+      if (q == hipSuccess) {
+        // everything up to `check` is done; what was enqueued behind it is covered by `latest`: watch that one next
+        if (l.latest_valid) { std::swap(l.check, l.latest); l.latest_valid = false; }
+        else l.check_active = false;
+        continue;
+      }
       (void)hipGetLastError();
-      if (q == hipErrorNotReady && now - x.t0 > w->timeout_s) {
+      if (q == hipErrorNotReady && now - l.check.t0 > w->timeout_s) {
         std::fprintf(stderr, "davidson engine: rank %d of %d: collective \"%s\" (number %llu, outer iteration %ld) has not completed after %.0f s "
                              "- a peer is gone or stuck; ending this process (DAVIDSON_COLLECTIVE_TIMEOUT sets the bound)\n",
-                     w->rank, w->nranks, x.what, (unsigned long long)x.seq, x.iter, now - x.t0);
+                     w->rank, w->nranks, l.check.what, (unsigned long long)l.check.seq, l.check.iter, now - l.check.t0);
         std::fflush(stderr);
         _exit(124);
       }
@@ -75,18 +81,26 @@ extern "C" int dav_comm_init(dav_handle_t e, const void* id128) {
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   NCCLCHK(g_rccl.CommInitRank(&e->comm, e->nranks, id, e->rank));
+  int count = 0;
+  NCCLCHK(g_rccl.CommCount(e->comm, &count));          // what RCCL itself reports: goes into dav_stats.comm_ranks (bench.py prints it)
+  if (count != e->nranks) return fail("dav_comm_init: the communicator has " + std::to_string(count) + " ranks, the engine was created for " + std::to_string(e->nranks));
+  e->comm_ranks = count;
   // the watchdog of this communicator's collectives (DAVIDSON_COLLECTIVE_TIMEOUT seconds; default 600, 0 = none)
   double timeout = 600.0;
   if (const char* ev = getenv("DAVIDSON_COLLECTIVE_TIMEOUT")) timeout = atof(ev);
   if (timeout > 0.0 && !e->wd) {
     Watchdog* w = new Watchdog;
     w->timeout_s = timeout; w->device = e->device; w->rank = e->rank; w->nranks = e->nranks;
-    for (Watchdog::Item& x : w->it)
-      if (hipEventCreateWithFlags(&x.ev, hipEventDisableTiming) != hipSuccess) {
-        for (Watchdog::Item& y : w->it) if (y.ev) (void)hipEventDestroy(y.ev);
-        delete w;
-        return fail("dav_comm_init: could not create the watchdog's events");
-      }
+    bool ok = true;
+    for (Watchdog::Lane& l : w->lane)
+      ok = ok && hipEventCreateWithFlags(&l.check.ev, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&l.latest.ev, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      for (Watchdog::Lane& l : w->lane) { if (l.check.ev) (void)hipEventDestroy(l.check.ev); if (l.latest.ev) (void)hipEventDestroy(l.latest.ev); }
+      delete w;
+      return fail("dav_comm_init: could not create the watchdog's events");
+    }
     w->th = std::thread(watchdog_loop, w);
     e->wd = w;
   }
@@ -315,8 +329,6 @@ int test_allgather(E*, const double*, double*, size_t) { return fail("built with
 int test_allreduce(E*, double*, size_t) { return fail("built without test transports"); }
 int test_reduce_scatter(E*, const double*, double*, size_t) { return fail("built without test transports"); }
 void shm_release(E*) {}
-extern "C" int dav_comm_init_shm(dav_handle_t, const char*) { return fail("dav_comm_init_shm: built without DAV_TEST_TRANSPORTS"); }
-extern "C" int dav_local_group_join(dav_handle_t*, int) { return fail("dav_local_group_join: built without DAV_TEST_TRANSPORTS"); }
 #endif
 
 // recv[p*count .. (p+1)*count) = send of rank p, for every rank (send may alias recv + rank*count)
@@ -333,42 +345,77 @@ int watch_mark(E* e, const char* what, hipStream_t stream) {
   Watchdog* w = e->wd;
   if (!w || e->group_depth > 0) return 0;
 #if DAV_TEST_TRANSPORTS
-  if (const char* ev = getenv("DAV_TEST_STALL_MS"))
-    hipLaunchKernelGGL(watchdog_stall_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long)atoll(ev) * 100000ull);   // 100 MHz counter
+  // DAV_TEST_STALL_MS (with DAV_TEST_STALL_FROM = n: only from the n-th collective of this engine on)
+  static const long stall_ms = [] { const char* ev = getenv("DAV_TEST_STALL_MS"); return ev ? atol(ev) : 0L; }();
+  static const long stall_from = [] { const char* ev = getenv("DAV_TEST_STALL_FROM"); return ev ? atol(ev) : 0L; }();
+  if (stall_ms > 0 && (long)w->seq >= stall_from)
+    hipLaunchKernelGGL(watchdog_stall_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long)stall_ms * 100000ull);   // 100 MHz counter
 #endif
   std::lock_guard<std::mutex> lk(w->mu);
-  Watchdog::Item& x = w->it[w->seq % Watchdog::NW];
-  if (x.active) return 0;                       // the ring is full of unfinished collectives: the oldest of them is being watched
-  HIPCHK(hipEventRecord(x.ev, stream));
-  x.what = what; x.seq = w->seq++; x.t0 = wall_seconds(); x.iter = e->iter_hint; x.active = true;
+  Watchdog::Lane* l = nullptr;
+  for (Watchdog::Lane& c : w->lane)
+    if (c.used && c.stream == stream) { l = &c; break; }
+  if (!l)
+    for (Watchdog::Lane& c : w->lane)
+      if (!c.used) { c.used = true; c.stream = stream; l = &c; break; }
+  if (!l) return fail("collective watchdog: more streams than lanes");
+  Watchdog::Mark& m = l->check_active ? l->latest : l->check;
+  HIPCHK(hipEventRecord(m.ev, stream));          // `latest` is re-recorded: it then stands behind the newest collective
+  m.what = what; m.seq = w->seq++; m.t0 = wall_seconds(); m.iter = e->iter_hint;
+  if (l->check_active) l->latest_valid = true;
+  else l->check_active = true;
   return 0;
 }
+// ncclGroupStart ... ncclGroupEnd around several collectives; the group is marked for the watchdog once, at its end.  A failure
+// between begin and end must go through coll_group_abort (CollGroup below does), or the open group would silently switch the
+// watchdog off for the rest of the engine's life.
 int coll_group_begin(E* e) {
   if (e->comm) { NCCLCHK(g_rccl.GroupStart()); ++e->group_depth; }
   return 0;
 }
 int coll_group_end(E* e, const char* what, hipStream_t stream) {
-  if (e->comm) { NCCLCHK(g_rccl.GroupEnd()); --e->group_depth; CHK(watch_mark(e, what, stream)); }
+  if (e->comm) {
+    if (e->group_depth > 0) --e->group_depth;
+    NCCLCHK(g_rccl.GroupEnd());
+    CHK(watch_mark(e, what, stream));
+  }
   return 0;
 }
+void coll_group_abort(E* e) {
+  if (e->comm && e->group_depth > 0) {
+    --e->group_depth;
+    (void)g_rccl.GroupEnd();
+  }
+}
 
+// Timing (dav_set_timing level 2): an event pair around the collective on the stream it runs on - kinds 5 / 6 / 7 =
+// all-gather / reduce-scatter / all-reduce, with the payload per rank; inside a group the group is timed as a whole.
 int coll_allgather(E* e, const double* send, double* recv, size_t count) {
   if (has_test_transport(e)) return test_allgather(e, send, recv, count);
+  int slot = -1;
+  if (e->group_depth == 0) { CHK(timed_begin(e, 5, 8.0 * (double)count * e->nranks, &slot)); e->st.collectives += 1; }
   NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
+  CHK(timed_end(e, slot));
   return watch_mark(e, "all-gather", e->stream);
 }
 
 // buf <- sum over ranks of buf (same bits on every rank)
 int coll_allreduce(E* e, double* buf, size_t count) {
   if (has_test_transport(e)) return test_allreduce(e, buf, count);
+  int slot = -1;
+  if (e->group_depth == 0) { CHK(timed_begin(e, 7, 8.0 * (double)count, &slot)); e->st.collectives += 1; }
   NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, e->comm, e->stream));
+  CHK(timed_end(e, slot));
   return watch_mark(e, "all-reduce", e->stream);
 }
 
 // recv[0 .. count) = sum over ranks p of send_p[rank*count .. (rank+1)*count)  (send holds nranks chunks)
 int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
   if (has_test_transport(e)) return test_reduce_scatter(e, send, recv, count);
+  int slot = -1;
+  if (e->group_depth == 0) { CHK(timed_begin(e, 6, 8.0 * (double)count * e->nranks, &slot)); e->st.collectives += 1; }
   NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
+  CHK(timed_end(e, slot));
   return watch_mark(e, "reduce-scatter", e->stream);
 }
 

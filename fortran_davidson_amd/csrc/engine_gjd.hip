@@ -149,7 +149,7 @@ extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const dou
       CHK(apply_ptr(e, DAV_OP_B, v + (size_t)c_lo * e->ldp, c_hi - c_lo, ub + (size_t)c_lo * e->ldp, true, true));
       ubp = ub;
     }
-    if (getenv("DAV_GJD_TRACE")) {
+    if (e->tune.gjd_trace) {
       int na = 0;
       for (int j = 0; j < m; ++j) na += active[j] != 0.0;
       fprintf(stderr, "gjd inner %d: active %d of %d, columns [%d, %d)\n", itn, na, m, c_lo, c_hi);

@@ -2,7 +2,7 @@
 // points, and the functions the parts share.  Nothing here is part of the C ABI (include/davidson_hip.h); internal functions
 // have hidden visibility.
 #pragma once
-#include "../../include/davidson_hip.h"
+#include "davidson_hip_private.h"
 #include "kernels.h"
 #include "ingest.h"
 
@@ -58,6 +58,7 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 extern Rccl g_rccl;
 int rccl_load();
@@ -84,6 +85,12 @@ struct OpDesc {
   int storage = 0;           // dense: 0 = full, 1 = symmetric-tiled (lower block triangle)
   float* a32 = nullptr;      // fp32 copy of the symmetric tiles: operand of the mixed-precision inner sweeps (lazy)
   bool a32_valid = false, a32_refused = false;
+  // generated symmetric operator (hashed, storage 1) kept PARTLY resident: the tiles of its longest block rows (I >= res_first)
+  // are stored like a dense operator's (res_tiles of them at res_a, addressed through res_row_off), the others are generated in the sweep
+  double* res_a = nullptr;
+  int64_t* res_row_off = nullptr;   // device, per block row: first tile inside res_a, -1 = generated
+  int64_t res_tiles = 0;
+  int res_first = 0;                // first resident block row (resident rows form the tail: the longest ones)
 };
 
 struct SmallBuf {            // device small matrix + pinned staging
@@ -96,8 +103,29 @@ struct SmallBuf {            // device small matrix + pinned staging
 constexpr int N_SMALL = 4;
 constexpr int N_EVPAIRS = 64;
 
+// Tuning / A-B knobs of the sweeps.  Read from the environment ONCE, when the engine is created (tune_from_env in
+// engine.hip, called by dav_create): nothing on the apply path calls getenv.  A/B runs set the variables and create a new engine.
+struct Tune {
+  int sym_wide = 2;       // DAV_SYM_WIDE: 2 = the one-wave-per-SIMD kernel (k_matvec_symw.hip) from 9 columns on, 1 = for more than 16 only, 0 = never
+  int sym_wide32 = 1;     // DAV_SYM_WIDE32: its fp32-tile variant for the mixed-precision inner sweeps of up to 16 columns
+  int sym_pair = 1;       // DAV_SYM_PAIR: 32 columns per launch (two 16-column groups share their tile reads)
+  int sym_quad = 1;       // DAV_SYM_QUAD: 64 columns per launch
+  int sym_overlap = -1;   // DAV_SYM_OVERLAP: collectives of wide blocks on a second stream; -1 = default (on over a real multi-rank communicator)
+  int sym_r = 0;          // DAV_SYM_R: 1 | 2 | 4 forces the block rows per workgroup
+  int sym_tall = 1;       // DAV_SYM_TALL: four block rows per workgroup at 9-16 columns
+  int sym_run = 0;        // DAV_SYM_RUN / DAV_SYM_RUN9: run length of the work items (0 = by the tile count)
+  int sym_run9 = 0;
+  int sym_mfma4 = 1;      // DAV_SYM_MFMA4: the 4x4x4 MFMA at k <= 8
+  int64_t mv_target = 0;  // DAV_MV_TARGET / DAV_MV_NSPLIT: grid of the row-slab kernel (0 = by the shape)
+  int64_t mv_nsplit = 0;
+  int b_resident = 1;     // DAV_B_RESIDENT: keep what fits of a generated second operator resident as stored tiles (dav_set_operator_hashed, storage 1)
+  bool gjd_trace = false; // DAV_GJD_TRACE
+};
+Tune tune_from_env();
+
 struct Watchdog;
 struct dav_engine {
+  Tune tune;
   int device = 0;
   hipStream_t stream = nullptr;
   int64_t n = 0, nslab = 0, nloc = 0, row0 = 0, nloc_pad = 0, ncols_pad = 0;
@@ -162,6 +190,7 @@ struct dav_engine {
   SmallBuf sm[N_SMALL];
   size_t small_doubles = 0;
   ncclComm_t comm = nullptr;
+  int comm_ranks = 0;             // ncclCommCount of `comm`
   LocalGroup* lg = nullptr;       // loopback transport (tests); owned by rank 0
   ShmGroup* shm = nullptr;        // shared-memory transport (tests of the multi-process launch flow)
   OpDesc op[2];
@@ -192,10 +221,16 @@ typedef dav_engine E;
 // followed by an event, and one thread per engine checks that events complete: one that has not after
 // DAVIDSON_COLLECTIVE_TIMEOUT seconds (default 600; 0 = no watchdog) prints rank / collective / outer iteration and ends
 // the process with exit code 124 - the launcher then tears the group down.  No re-exec, nothing is retried.
+// Per stream ("lane": the engine's stream, the communication stream) two events cover the whole tail of the stream however many
+// collectives are enqueued between two polls: `check` is the one being watched (with the time it was recorded), `latest` is
+// re-recorded behind every further collective.  When `check` completes the watchdog moves on to `latest` (its record time becomes
+// the new reference), so the newest collective is always behind a watched event, and a stream that stays busy for longer than
+// the timeout with collectives that DO complete is never mistaken for a hang.
 struct Watchdog {
-  static constexpr int NW = 32;
-  struct Item { hipEvent_t ev = nullptr; const char* what = ""; uint64_t seq = 0; double t0 = 0.0; long iter = -1; bool active = false; };
-  Item it[NW];
+  static constexpr int NL = 2;
+  struct Mark { hipEvent_t ev = nullptr; const char* what = ""; uint64_t seq = 0; double t0 = 0.0; long iter = -1; };
+  struct Lane { hipStream_t stream = nullptr; bool used = false, check_active = false, latest_valid = false; Mark check, latest; };
+  Lane lane[NL];
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
@@ -220,6 +255,8 @@ int bind(E* e);
 int collect_events(E* e);
 int timed_begin(E* e, int kind, double bytes, int* slot);
 int timed_end(E* e, int slot);
+int timed_begin_on(E* e, int kind, double bytes, int* slot, hipStream_t stream);   // the pair is recorded on `stream`
+int timed_end_on(E* e, int slot, hipStream_t stream);
 int small_upload(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* ldm_out);
 int small_upload_multi(E* e, int i, SmallMat* mats, int n);
 double* panel_ptr(E* e, int panel, int col);
@@ -246,6 +283,25 @@ void shm_release(E*);
 int watch_mark(E* e, const char* what, hipStream_t stream);
 int coll_group_begin(E* e);
 int coll_group_end(E* e, const char* what, hipStream_t stream);
+void coll_group_abort(E* e);
+// RAII around a group of collectives: begin() ... end(); leaving the scope without end() (an early return on an error) closes
+// the NCCL group and restores the depth counter
+struct CollGroup {
+  E* e; bool open = false; int slot = -1;
+  explicit CollGroup(E* e_) : e(e_) {}
+  // kind 5 / 6: the group is an all-gather / a reduce-scatter of `bytes` payload per rank, timed as a whole on `stream`
+  int begin(int kind = 0, double bytes = 0.0, hipStream_t stream = nullptr) {
+    if (kind != 0 && e->comm) { int rc = timed_begin_on(e, kind, bytes, &slot, stream ? stream : e->stream); if (rc != 0) return rc; e->st.collectives += 1; }
+    int rc = coll_group_begin(e); open = rc == 0; return rc;
+  }
+  int end(const char* what, hipStream_t stream) {
+    open = false;
+    int rc = coll_group_end(e, what, stream);
+    if (rc != 0) return rc;
+    return timed_end_on(e, slot, stream);
+  }
+  ~CollGroup() { if (open) coll_group_abort(e); }
+};
 int coll_allgather(E* e, const double* send, double* recv, size_t count);
 int coll_allreduce(E* e, double* buf, size_t count);
 int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count);
@@ -265,7 +321,7 @@ void ingest_wanted(E* e, int64_t* first, int64_t* count);
 OpParams op_params(const OpDesc& o);
 // ---- engine_apply.hip ------------------------------------------------------------------------------------
 bool inner_f32_tiles(E* e, OpDesc& o);
-bool sym_wide_enabled();
+bool sym_wide_enabled(const E* e);
 void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
                        int npair, int64_t dstride, int64_t tstride);
 int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner);

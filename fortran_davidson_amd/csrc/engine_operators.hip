@@ -23,10 +23,9 @@ int refresh_diag_host(E* e, int which) {
 // Block rows per workgroup of the symmetric sweep for a launch of kk columns: 4 (k <= 8 - and 9-16 columns of stored fp64 tiles -
 // from 200 block rows on), 2 (more than 8 columns, from 64 block rows on: the one-wave-per-SIMD kernel of k_matvec_symw.hip), or 1 (the one-block-row kernel of
 // k_matvec_sym.hip: small matrices, where super rows leave too few work items and too much of the matrix in the masked
-// diagonal super blocks).  DAV_SYM_R = 1 | 2 | 4 forces a schedule (4 only if k <= 8).
+// diagonal super blocks).  Tune::sym_r (DAV_SYM_R at dav_create) = 1 | 2 | 4 forces a schedule (4 only if k <= 16).
 int sym_schedule(const E* e, int kk, bool stored_fp64) {
-  const char* ev = getenv("DAV_SYM_R");                 // read per call: A/B runs flip it inside one process
-  const int forced = ev ? atoi(ev) : 0;
+  const int forced = e->tune.sym_r;                     // DAV_SYM_R at dav_create
   const int nb = (int)(e->ncols_pad / SYM_TB);          // block rows of the whole matrix
   // k <= 8, crossover measured end to end on one box (ms for R = 1 | 2 | 4): N=40000 (157 block rows) 1.33 | 1.38 | 1.39; N=60000
   // (235) 2.78 | 2.78 | 2.67; N=100000 7.28 | 7.39 | 6.84; N=140000 14.98 | 14.85 | 13.99.
@@ -37,13 +36,11 @@ int sym_schedule(const E* e, int kk, bool stored_fp64) {
   // N=20000 0.431 | 0.415, N=30000 0.863 | 0.847, N=50000 2.06 | 2.03 ms, profiles/experiments/r03_small_n_schedule.log)
   int R = nb >= 200 ? (kk <= 8 ? 4 : 2) : (nb >= 64 && stored_fp64 ? 2 : 1);   // generated / fp32 tiles: the two-wave kernels from 200 on, as before
   // 9-16 columns of stored fp64 tiles: the wide kernel on FOUR block rows per workgroup (half as many transposed partials written
-  // by a sweep that is HBM-bound there); DAV_SYM_TALL=0: two (A/B runs)
-  const char* tv = getenv("DAV_SYM_TALL");
-  const bool tall = stored_fp64 && kk > 8 && kk <= 16 && nb >= 200 && sym_wide_enabled() && (tv ? atoi(tv) != 0 : true);
+  // by a sweep that is HBM-bound there); Tune::sym_tall = 0: two (A/B runs)
+  const bool tall = stored_fp64 && kk > 8 && kk <= 16 && nb >= 200 && sym_wide_enabled(e) && e->tune.sym_tall != 0;
   if (R == 2 && tall) R = 4;
   if (forced == 1 || forced == 2 || forced == 4) R = forced;
-  if (R == 4 && kk > 8 && !(stored_fp64 && kk <= 16 && sym_wide_enabled())) R = 2;
-  if (R > 1 && !matvec_sym_can_pair()) R = 1;          // DAV_SYM_V8=0: the one-wave-per-SIMD kernel, A/B runs only
+  if (R == 4 && kk > 8 && !(stored_fp64 && kk <= 16 && sym_wide_enabled(e))) R = 2;
   return R;
 }
 
@@ -87,7 +84,7 @@ int sym_setup(E* e) {
   // short remainder runs of every block row fill the tail (same box, N=60000: 2.95-3.04 ms against 3.16-3.37 ms
   // in block-row order for run lengths 6..24; N=200000: flat within 1 % for 16..64).
   int64_t C = std::min<int64_t>(32, std::max<int64_t>(4, (ntiles + 3071) / 3072));
-  if (const char* ev = getenv("DAV_SYM_RUN")) C = std::max(1, atoi(ev));
+  if (e->tune.sym_run > 0) C = e->tune.sym_run;
   struct Item { int I, J0, J1, slot; };
   std::vector<Item> list;
   std::vector<int> row_begin(nb + 1, 0);
@@ -117,7 +114,7 @@ int sym_setup(E* e) {
     pl.R = p == 0 ? 2 : 4;
     pl.nsuper = (nb + pl.R - 1) / pl.R;
     int64_t Cp = std::min<int64_t>(64 / pl.R, std::max<int64_t>(1, (ntiles + 3071) / (3072 * pl.R)));
-    if (const char* ev = getenv("DAV_SYM_RUN9")) Cp = std::max(1, atoi(ev));
+    if (e->tune.sym_run9 > 0) Cp = e->tune.sym_run9;
     std::vector<Item> plist;
     std::vector<int> prow(pl.nsuper + 1, 0), zbeg(pl.nsuper + 1, 0);
     for (int S = 0; S < pl.nsuper; ++S) {
@@ -511,5 +508,13 @@ extern "C" int dav_set_operator_host(dav_handle_t e, int which, const double* di
 extern "C" int dav_get_diagonal(dav_handle_t e, int which, double* out) {
   if (which < 0 || which > 1 || e->diag_host[which].empty()) return fail("dav_get_diagonal: operator not set");
   std::memcpy(out, e->diag_host[which].data(), sizeof(double) * e->n);
+  return 0;
+}
+
+// fraction of the block rows (by tiles) of operator `which` that a generated symmetric operator keeps resident as stored tiles
+extern "C" int dav_resident_fraction(dav_handle_t e, int which, double* fraction) {
+  if (which < 0 || which > 1 || !fraction) return fail("dav_resident_fraction: bad arguments");
+  const OpDesc& o = e->op[which];
+  *fraction = (o.res_tiles > 0 && e->sym_ntiles_local > 0) ? (double)o.res_tiles / (double)e->sym_ntiles_local : 0.0;
   return 0;
 }

@@ -202,14 +202,9 @@ __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t r
   }
 }
 
-void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc) {
+// target > 0: aim at that many workgroups; forced_nsplit > 0: exact split count (Tune::mv_target / mv_nsplit, tuning runs)
+void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc, int64_t target, int64_t forced_nsplit) {
   int64_t rowblocks = nrows_pad / MV_ROWS;
-  static int64_t target = 0;                   // ~8 workgroups per CU (DAV_MV_TARGET overrides, for tuning)
-  if (target == 0) {
-    const char* env = getenv("DAV_MV_TARGET");
-    target = env ? atoll(env) : -1;
-    if (target == 0) target = -1;
-  }
   // Measured on MI355X (N=20000, 79 row blocks, split count swept 12..64): the sweep is fastest when the
   // grid just fills the resident capacity once (256 CUs x 5 workgroups = 1280): 16 splits = 1264
   // workgroups gives 5.6 TB/s, 17 splits (1343, a second sparsely filled round) 5.37, 26 splits 5.35.
@@ -222,14 +217,7 @@ void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit,
     s = 1280 / rowblocks;
     if (s < 1 || rowblocks * s < 900) s = (1024 + rowblocks - 1) / rowblocks;
   }
-  {
-    static int64_t forced = -1;                // DAV_MV_NSPLIT: exact split count (tuning)
-    if (forced < 0) {
-      const char* env = getenv("DAV_MV_NSPLIT");
-      forced = env ? atoll(env) : 0;
-    }
-    if (forced > 0) s = forced;
-  }
+  if (forced_nsplit > 0) s = forced_nsplit;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
   int64_t chunk = (ncols_pad + s - 1) / s;

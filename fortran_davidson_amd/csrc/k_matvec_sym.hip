@@ -3,41 +3,27 @@
 // entries, which is what makes N = 200000 (160 GB) fit one MI355X - and every off-diagonal tile is
 // used twice per sweep:   W_I += A_IJ X_J   (direct)   and   W_J += A_IJ^T X_I   (transposed).
 //
-// Two kernels, same slabs and same reduction: matvec_sym8_kernel (default: 8 waves, two per SIMD, further
-// down) and matvec_sym_kernel (4 waves, one per SIMD, described first; DAV_SYM_V8=0 selects it for A/B runs).
+// One-block-row kernel matvec_sym8_kernel (8 waves, two per SIMD; small matrices and the harness operator - larger ones run the
+// super-row schedules of k_matvec_sym9.hip / k_matvec_symw.hip, same slabs, same kind of reduction): workgroup = one run of
+// tiles (I, J0..J1) of block row I.  Per half-step the 32 x 16 sub-block sits in registers in the "direct" lane layout (16 B =
+// 2 rows of one column per lane; MFMA contraction over columns); the "Gram" lane layout the transposed product needs (4
+// consecutive rows of one column per lane; MFMA contraction over rows) is made through a wave-private LDS scratch (no barrier:
+// a wave's DS operations complete in order).  A second kernel adds, in fixed order, the slabs that belong to each output block
+// (bitwise reproducible, no fp64 atomics).
 //
-// Workgroup = 4 waves, one run of tiles (I, J0..J1) of block row I.  Inside every 64-column batch of a
-// tile wave w owns the 16 tile columns 16w..16w+15 over ALL 256 rows ("unit" = 256 x 16, processed as four
-// 64-row steps).  That choice makes the transposed partial Z (16 tile columns x 16 block columns, summed
-// over the 256 rows) complete inside one wave - it goes from the accumulators straight to the per-tile
-// slab, with no cross-wave exchange and no barrier anywhere in the main loop - while the direct partials
-// (256 rows x 16 block columns = 128 accumulator registers per wave) stay in registers for the whole run
-// and are summed over the four waves once, at the end of the run.  Per step the 64 x 16 sub-block sits in
-// registers in the "direct" lane layout (16 B = 2 rows of one column per lane; MFMA contraction over
-// columns); the "Gram" lane layout the transposed product needs (4 consecutive rows of one column per
-// lane; MFMA contraction over rows) is made through a wave-private LDS scratch (8 x ds_write_b128 +
-// 8 x ds_read_b128, no barrier: a wave's DS operations complete in order).  A second kernel adds, in fixed
-// order, the slabs that belong to each output block (bitwise reproducible, no fp64 atomics).
-//
-// Load pipeline: a 4-slot register ring indexed by the (compile-time) 64-row group of the step; the loads
-// of step s+3 are issued before the MFMAs of step s, with no register moves (a rotating buffer with moves
-// makes the compiler wait for the newest loads at the end of every step, which is what the first versions
-// of this kernel did).  One wave per SIMD, up to 24 KB in flight per wave.
-//
-// History, so that measured dead ends are not retried blindly.  v5 gave each wave 64 rows of every
-// 16-column step and summed the transposed partials of the four waves through LDS once per 64 columns
-// (two barriers each); same box, N=60000 / N=200000, k=16: v5 3.38 / 34.6 ms, the same with a branch-free
-// body and X_I kept in registers 3.36 ms, this version 3.34 / 32.9 ms.  Also tried on v5: re-reading the
-// sub-block from global memory in the Gram layout (late: misses L2 and doubles HBM traffic; early: as many
-// registers as the LDS scheme and twice the TA work); interleaving the dependent transposed MFMAs with the
-// direct ones (9 % slower); two 16-column groups per pass (slower than two passes); producing the Gram
-// operand one step ahead with sched_group_barrier (same speed); summing the waves once per 128 columns
-// (1 %); runs of 4..14 tiles per workgroup (within 2 %; a workgroup costs ~7 us to start and drain); on the
-// 8-wave kernel: fp64 atomics into W instead of the slabs and the reduction kernel (not reproducible; N=60000,
-// k=16: 3.07 -> 2.80 ms, but N=200000, k=8: 29.9 -> 29.5 ms and the paired 32-column launches 4 % slower).
-// Counters (profiles/r01_pmc_mfma_clock_n40000.json, v5, N=40000): matrix pipe 43 % busy at 2.34 GHz, HBM
-// fetch = tile bytes.  Traffic per sweep: the stored half matrix once, plus 1/16 of it written as per-tile
-// Z slabs and read back by the reduction kernel (8 % of the sweep time) - the price of a deterministic sum.
+// History, so that measured dead ends are not retried blindly.  The first version ran ONE wave per SIMD (4 waves, each owning 16
+// tile columns over all 256 rows, transposed partials complete inside a wave, a 4-slot load ring three steps ahead): its ~100
+// non-MFMA instructions per step are serialised with the 32 MFMAs (N=60000 / N=200000, k=16: 3.34 / 32.9 ms); it was kept behind
+// an A/B knob until round 4 and then deleted - the two-waves-per-SIMD kernel below replaced it everywhere in round 1, and the
+// one-wave-per-SIMD idea came back in round 3 as k_matvec_symw.hip with the memory operations placed between the MFMAs.  Also
+// tried on that version: re-reading the sub-block from global memory in the Gram layout (late: misses L2 and doubles HBM
+// traffic; early: as many registers as the LDS scheme and twice the TA work); interleaving the dependent transposed MFMAs with
+// the direct ones (9 % slower); two 16-column groups per pass (slower than two passes); producing the Gram operand one step
+// ahead with sched_group_barrier (same speed); summing the waves once per 128 columns (1 %); runs of 4..14 tiles per workgroup
+// (within 2 %; a workgroup costs ~7 us to start and drain); on the 8-wave kernel: fp64 atomics into W instead of the slabs and
+// the reduction kernel (not reproducible; N=60000, k=16: 3.07 -> 2.80 ms, but N=200000, k=8: 29.9 -> 29.5 ms and the paired
+// 32-column launches 4 % slower).  Traffic per sweep: the stored half matrix once, plus 1/16 of it written as per-tile Z slabs
+// and read back by the reduction kernel (8 % of the sweep time) - the price of a deterministic sum.
 #include "kernels.h"
 #include <cstdlib>
 #include <type_traits>
@@ -49,171 +35,11 @@ __device__ __forceinline__ const double* sym_tile(const double* tiles, const int
   return tiles + (row_off[I] + J) * (int64_t)(SYM_TB * SYM_TB);
 }
 
-constexpr int SYM_DEPTH = 3;      // steps of load lookahead (ring of 4 slots)
-
-__global__ __launch_bounds__(256, 1) void matvec_sym_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off,
-                                                            const int* __restrict__ items, const double* __restrict__ xt,
-                                                            double* __restrict__ slabD, double* __restrict__ slabT, int kcols) {
-  constexpr int RS = 65;          // padded stride of the end-of-run exchange of the direct partials
-  constexpr int TRS = 66;         // padded column stride of the transposition scratch (528 B)
-  constexpr int XT = 258;         // padded column stride of the transposed X_I copy (b128 reads conflict free)
-  __shared__ __attribute__((aligned(16))) double tr[4][16 * TRS];
-  __shared__ __attribute__((aligned(16))) double xsT[16 * XT];
-  static_assert(16 * TRS >= 16 * RS, "the end-of-run exchange reuses the transposition scratch");
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  // work item: (block row, first tile, end tile, slab slot); items are dispatched longest first
-  const int I = items[4 * blockIdx.x], J0 = items[4 * blockIdx.x + 1], J1 = items[4 * blockIdx.x + 2];
-
-  // B operand of the transposed product: X_I, stored transposed ([block column][row]) so that the four
-  // consecutive rows a lane needs are one 32-byte run
-  for (int e = threadIdx.x; e < SYM_TB * 16; e += 256)
-    xsT[(e & 15) * XT + (e >> 4)] = xt[((int64_t)I * SYM_TB + (e >> 4)) * 16 + (e & 15)];
-  __syncthreads();
-
-  // direct partials: all 256 rows of the block row x 16 block columns, for the tile columns this wave owns
-  f64x4 acc[4][4];
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rg][rt] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-  const int nunits = (J1 - J0) * 4;                 // 16-column units of this wave (one per 64-column batch)
-  const int nsteps = nunits * 4;                    // (unit, 64-row group) steps
-  const int64_t dlane = 2 * c + (int64_t)g * SYM_TB;
-  double* tw = tr[wave];
-
-  // ring slot of step s is s & 3 (= the row group): the 64 x 16 sub-block in the direct layout
-  f64x2 ra[4][4][2];
-  auto load_step = [&](int s, f64x2 (&a)[4][2]) {
-    s = s < nsteps ? s : nsteps - 1;                // clamped at the end of the run: a harmless re-read
-    const int q = s >> 2, rg = s & 3;
-    const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
-    const double* ad = sym_tile(tiles, row_off, I, J) + (int64_t)col * SYM_TB + rg * 64 + dlane;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      a[u][0] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB);
-      a[u][1] = *reinterpret_cast<const f64x2*>(ad + (int64_t)(4 * u) * SYM_TB + 32);
-    }
-  };
-  // B operand of the direct product for unit q: X_J rows (tile columns) of the unit
-  auto load_b = [&](int q, double (&b)[4]) {
-    q = q < nunits ? q : nunits - 1;
-    const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
-    const double* xj = xt + ((int64_t)J * SYM_TB + col + g) * 16 + c;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = xj[(4 * u) * 16];
-  };
-  double b[4], bn[4];
-  load_b(0, b);
-#pragma unroll
-  for (int d = 0; d < SYM_DEPTH; ++d) load_step(d, ra[d]);
-
-  // One unit = 256 rows x 16 columns of tile (I, J).  OFF = off-diagonal tile (direct + transposed product);
-  // the diagonal tile, always the last of a run, only has the direct product.  Two instantiations instead
-  // of a run-time test keep the body one basic block.
-  auto unit = [&](auto off_tag, int q) {
-    constexpr bool OFF = decltype(off_tag)::value;
-    load_b(q + 1, bn);
-    // X_I is read from LDS again for every unit: as registers its 128 values would not fit.  The opaque
-    // zero keeps the compiler from hoisting the (loop invariant) reads out of the unit loop.
-    int xoff = c * XT + 4 * g;
-    asm volatile("" : "+v"(xoff));
-    const double* xw = xsT + xoff;
-    f64x4 zc[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) zc[s4] = f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      f64x2 (&a)[4][2] = ra[rg];
-      load_step(q * 4 + rg + SYM_DEPTH, ra[(rg + SYM_DEPTH) & 3]);
-      f64x2 p[4][2], xb[4][2];
-      if constexpr (OFF) {
-        // direct layout -> LDS: lane (c, g) owns rows 2c, 2c+1 (+32) of column 4u + g
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c) = a[u][0];
-          *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c + 32) = a[u][1];
-        }
-        // LDS -> Gram layout: lane (c, g) owns rows 16 ib + 4g .. +3 of column c; same rows of X_I
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) {
-          p[ib][0] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g);
-          p[ib][1] = *reinterpret_cast<const f64x2*>(tw + c * TRS + 16 * ib + 4 * g + 2);
-          xb[ib][0] = *reinterpret_cast<const f64x2*>(xw + rg * 64 + 16 * ib);
-          xb[ib][1] = *reinterpret_cast<const f64x2*>(xw + rg * 64 + 16 * ib + 2);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc[rg][0] = mfma_f64(a[u][0].x, b[u], acc[rg][0]);
-        acc[rg][1] = mfma_f64(a[u][0].y, b[u], acc[rg][1]);
-        acc[rg][2] = mfma_f64(a[u][1].x, b[u], acc[rg][2]);
-        acc[rg][3] = mfma_f64(a[u][1].y, b[u], acc[rg][3]);
-      }
-      if constexpr (OFF) {
-        // four independent accumulator chains: a dependent f64 MFMA issued fewer than ~4 slots behind its
-        // producer stalls the pipe
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) {
-          zc[0] = mfma_f64(p[ib][0].x, xb[ib][0].x, zc[0]);
-          zc[1] = mfma_f64(p[ib][0].y, xb[ib][0].y, zc[1]);
-          zc[2] = mfma_f64(p[ib][1].x, xb[ib][1].x, zc[2]);
-          zc[3] = mfma_f64(p[ib][1].y, xb[ib][1].y, zc[3]);
-        }
-      }
-    }
-    if constexpr (OFF) {
-      // z[reg]: tile column col + g + 4 reg, block column c; complete (all 256 rows) - no cross-wave sum.
-      // slabT tile (I, J): [16 block columns][256 tile columns]
-      const f64x4 z = (zc[0] + zc[1]) + (zc[2] + zc[3]);
-      const int J = J0 + (q >> 2), col = (q & 3) * 64 + wave * 16;
-      double* outT = slabT + (((int64_t)I * (I - 1) / 2 + J) * 16 + c) * SYM_TB + col + g;
-      if (c < kcols) {            // block columns beyond the k in use carry zeros nobody reads
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) outT[4 * reg] = z[reg];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = bn[u];
-  };
-  const int nq_off = ((J1 - 1 == I ? J1 - 1 : J1) - J0) * 4;
-  int q = 0;
-  for (; q < nq_off; ++q) unit(std::true_type{}, q);
-  for (; q < nunits; ++q) unit(std::false_type{}, q);
-
-  // end of the run: sum the direct partials of the four waves (they own different tile columns), one
-  // 64-row group at a time, through the scratch the transposition used
-  double* red = &tr[0][0];
-  double* outD = slabD + (int64_t)items[4 * blockIdx.x + 3] * 16 * SYM_TB;
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
-    __syncthreads();
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int half = rt >> 1, par = rt & 1;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        red[wave * 16 * TRS + c * RS + 32 * half + 2 * (g + 4 * reg) + par] = acc[rg][rt][reg];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-      const int le = (e >> 6) * RS + (e & 63);
-      if ((e >> 6) < kcols)
-        outD[(int64_t)(e >> 6) * SYM_TB + rg * 64 + (e & 63)] =
-            red[le] + red[16 * TRS + le] + red[2 * 16 * TRS + le] + red[3 * 16 * TRS + le];
-    }
-  }
-}
-
-// ---- v8: two waves per SIMD -----------------------------------------------------------------------------
+// ---- two waves per SIMD -----------------------------------------------------------------------------------
 // Measured on gfx950 (scratch microbenchmarks): while a wave has a v_mfma_f64_16x16x4 in
 // flight it issues nothing else - every VALU / DS / VMEM instruction of that wave adds its own issue time
 // (4-5 cycles, 18+ for a 16-byte global load) on top of the 64 cycles per MFMA; a SECOND wave on the same
-// SIMD, however, issues in the shadow of those MFMAs at full MFMA rate for the first.  The kernel above
-// runs one wave per SIMD (128 accumulator + 128 ring registers), so its ~100 non-MFMA instructions per
-// step are serialised with the 32 MFMAs.  Here a workgroup has 8 waves: wave (w, h) owns tile columns
+// SIMD, however, issues in the shadow of those MFMAs at full MFMA rate for the first.  A workgroup has 8 waves: wave (w, h) owns tile columns
 // 16w..16w+15 of every 64-column batch over the row half h (128 rows, four 32-row half-steps), which fits
 // 256 registers.  The transposed partial of a unit is now split over the two waves of a pair: wave h=1
 // hands its 16 x 16 partial to wave h=0 through LDS (one workgroup barrier per unit, double buffered).
@@ -466,23 +292,14 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
 void launch_matvec_sym(hipStream_t st, const double* tiles, const int64_t* row_off, const int* items_dev, int nitems, const double* xt, int kcols,
                        double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   // kcols <= 16 * npair block columns are in use; npair = 2 runs two 16-column groups as paired workgroups
-  // DAV_SYM_V8=0 selects the one-wave-per-SIMD kernel (kept for A/B measurements; one group per launch)
-  static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
-  if (v8)
-    hipLaunchKernelGGL(matvec_sym8_kernel<false>, dim3(nitems * npair), dim3(512), 0, st, tiles, row_off, items_dev, xt, slabD, slabT, kcols,
-                       npair, xt_gstride, slabD_gstride, slabT_gstride, OpParams{}, (int64_t)0);
-  else
-    hipLaunchKernelGGL(matvec_sym_kernel, dim3(nitems), dim3(256), 0, st, tiles, row_off, items_dev, xt, slabD, slabT, kcols);
+  hipLaunchKernelGGL(matvec_sym8_kernel<false>, dim3(nitems * npair), dim3(512), 0, st, tiles, row_off, items_dev, xt, slabD, slabT, kcols,
+                     npair, xt_gstride, slabD_gstride, slabT_gstride, OpParams{}, (int64_t)0);
 }
 void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const int* items_dev, int nitems, const double* xt, int kcols,
                                  double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride,
                                  int64_t slabT_gstride) {
   hipLaunchKernelGGL(matvec_sym8_kernel<true>, dim3(nitems * npair), dim3(512), 0, st, (const double*)nullptr, (const int64_t*)nullptr, items_dev, xt, slabD,
                      slabT, kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, op, n);
-}
-bool matvec_sym_can_pair() {
-  static const int v8 = [] { const char* ev = getenv("DAV_SYM_V8"); return ev ? atoi(ev) : 1; }();
-  return v8 != 0;
 }
 
 // W[J*256 + r, col] = sum over runs of block row J of slabD + sum over I > J of slabT(I, J), fixed order.  With several

@@ -352,13 +352,12 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
 
 void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool tiles_f32, const int64_t* row_off, OpParams op, int64_t n,
                         int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
-                        double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
+                        double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride, bool m4) {
   dim3 grid(nitems * npair), block(512);
 #define DAV_SYM9_LAUNCH(RR, GG, FF, MM)                                                                                          \
   hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG, FF, MM>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, \
                      kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
-  // DAV_SYM_MFMA4=0: the k <= 8 sweep of a stored fp64 matrix on the 16-wide MFMA (A/B runs)
-  static const bool m4 = [] { const char* ev = getenv("DAV_SYM_MFMA4"); return !ev || atoi(ev) != 0; }();
+  // m4 = false (Tune::sym_mfma4 = 0): the k <= 8 sweep of a stored fp64 matrix on the 16-wide MFMA (A/B runs)
   if (R == 4) {
     if (gen) DAV_SYM9_LAUNCH(4, true, false, true);
     else if (tiles_f32) DAV_SYM9_LAUNCH(4, false, true, true);

@@ -22,7 +22,7 @@ void launch_slab_reduce(hipStream_t st, const double* slab, int nsplit, int64_t 
                         int64_t nloc, int k, double* dst, int64_t ldd);
 // scratch (in doubles) one matvec launch needs
 size_t matvec_slab_doubles(int64_t nrows_pad, int ngroups, int nsplit);
-void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc);
+void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc, int64_t target = 0, int64_t forced_nsplit = 0);
 
 // ---- K2: tall-skinny Gram ------------------------------------------------------------------------
 constexpr int GRAM_ROWS = 1024;   // rows per workgroup at most (4 waves x 256) ...
@@ -98,7 +98,6 @@ void launch_matvec_sym(hipStream_t st, const double* tiles, const int64_t* row_o
 void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const int* items_dev, int nitems, const double* xt, int kcols,
                                  double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride,
                                  int64_t slabT_gstride);
-bool matvec_sym_can_pair();
 // chunk_rows = 0: dst = panel columns (ldd), rows >= nloc zeroed.  chunk_rows = nslab (several ranks): dst = this rank's
 // partial product in reduce-scatter layout [rank][column][row of the rank's slab], rows < total_rows
 void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, const int64_t* owned,
@@ -106,7 +105,7 @@ void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT,
 // super-row schedules (k_matvec_sym9.hip): R = 2 or 4 block rows per workgroup, transposed partials summed on chip
 void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool tiles_f32, const int64_t* row_off, OpParams op, int64_t n,
                         int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
-                        double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
+                        double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride, bool mfma4 = true);
 // the same sweep (stored fp64 tiles) with one wave per SIMD and 16 nbw block columns per workgroup (k_matvec_symw.hip): R = 2 block
 // rows per workgroup, or (tall, nbw = 1: the work items of the R = 4 schedule) four; nwg workgroups per work item cover the
 // 16-column groups [0, nbw nwg) of the block

@@ -23,7 +23,13 @@ class Stats(C.Structure):
                 ("apply_ms", C.c_double), ("apply_bytes", C.c_double), ("last_apply_ms", C.c_double),
                 ("last_apply_bytes", C.c_double), ("gram_ms", C.c_double), ("panel_ms", C.c_double),
                 ("comm_ms", C.c_double), ("apply_kernel_ms", C.c_double), ("apply_flops", C.c_double),
-                ("apply_launches", C.c_int64), ("restarts", C.c_int64)]
+                ("apply_launches", C.c_int64), ("restarts", C.c_int64),
+                ("allgather_ms", C.c_double), ("reduce_scatter_ms", C.c_double), ("allreduce_ms", C.c_double),
+                ("allgather_bytes", C.c_double), ("reduce_scatter_bytes", C.c_double), ("allreduce_bytes", C.c_double),
+                ("collectives", C.c_int64), ("comm_ranks", C.c_int32), ("comm_overlap", C.c_int32)]
+
+
+ABI_VERSION = 102      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
 
 
 def _dp(a):
@@ -39,6 +45,8 @@ class CEngine:
 
     def __init__(self, n=None, max_cols=None, gev=False, device=0, rank=0, nranks=1, handle=None):
         self.lib = hip_lib()
+        if self.lib.dav_version() != ABI_VERSION:
+            raise DavidsonHipError(f"libdavidson_hip.so reports ABI version {self.lib.dav_version()}, engine_c.py mirrors {ABI_VERSION}")
         self.owned = handle is None
         if handle is None:
             h = C.c_void_p()
@@ -68,7 +76,7 @@ class CEngine:
     # -- bookkeeping
     def stats(self) -> Stats:
         st = Stats()
-        self._chk(self.lib.dav_get_stats(self.h, C.byref(st)))
+        self._chk(self.lib.dav_get_stats_n(self.h, C.byref(st), C.c_size_t(C.sizeof(st))))
         return st
 
     def reset_stats(self):
@@ -168,6 +176,16 @@ class CEngine:
     def apply(self, which, src_panel, c0, k, dst_panel, d0):
         self._chk(self.lib.dav_apply(self.h, C.c_int(which), C.c_int(src_panel), C.c_int(c0), C.c_int(k),
                                      C.c_int(dst_panel), C.c_int(d0)))
+
+    def apply_inner(self, which, src_panel, c0, k, dst_panel, d0):
+        """dav_apply as the GJD correction solve issues it (may read the fp32 copy of the tiles; csrc/davidson_hip_private.h)"""
+        self._chk(self.lib.dav_apply_inner(self.h, C.c_int(which), C.c_int(src_panel), C.c_int(c0), C.c_int(k),
+                                           C.c_int(dst_panel), C.c_int(d0)))
+
+    def resident_fraction(self, which):
+        f = C.c_double()
+        self._chk(self.lib.dav_resident_fraction(self.h, C.c_int(which), C.byref(f)))
+        return f.value
 
     def gram(self, panel_p, p0, p, panel_q, q0, q):
         out = np.zeros((p, q), order="F")

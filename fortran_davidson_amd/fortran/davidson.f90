@@ -24,7 +24,7 @@ module davidson_device
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
-       engine_set_identity, engine_comm_unique_id, engine_comm_init, engine_comm_init_shm, &
+       engine_set_identity, engine_comm_unique_id, engine_comm_init, &
        generalized_eigensolver_device, davidson_device_loop, basis_capacity
 
   !> Handle of a device-resident problem: operators A (and B) plus all work panels in HBM.
@@ -41,13 +41,12 @@ module davidson_device
      !> opt-in (engine_set_device_rr / DAVIDSON_DEVICE_RR=1): the Rayleigh-Ritz problem is solved on the device
      !> (one-workgroup Jacobi, order <= 128) and the projected matrices, Ritz values and vectors never leave HBM
      logical :: device_rr = .false.
+     !> Wall time of the last solve on this engine by phase (seconds): 1 setup (init basis + first projection),
+     !> 2 host Rayleigh-Ritz (DSYEV/DSYGV), 3 Ritz/residue/correction phase, 4 orthonormalisation,
+     !> 5 operator apply (expand), 6 projection, 7 restart, 8 GJD inner solves.  Printed when the
+     !> environment variable DAVIDSON_VERBOSE is set; never printed otherwise (drop-in silence).
+     real(dp) :: phase_seconds(8) = 0.0_dp
   end type davidson_engine
-
-  !> Wall time of the last solve by phase (seconds): 1 setup (init basis + first projection),
-  !> 2 host Rayleigh-Ritz (DSYEV/DSYGV), 3 Ritz/residue/correction phase, 4 orthonormalisation,
-  !> 5 operator apply (expand), 6 projection, 7 restart, 8 GJD inner solves.  Printed when the
-  !> environment variable DAVIDSON_VERBOSE is set; never printed otherwise (drop-in silence).
-  real(dp), save, public :: last_phase_seconds(8) = 0.0_dp
 
   !> Correction policies of the outer loop (see davidson_device_loop)
   integer, parameter, public :: POLICY_ALL = 0, POLICY_UNCONVERGED = 1
@@ -111,6 +110,11 @@ contains
     eng%gev = .false.
     if (present(gev)) eng%gev = gev
     eng%max_cols = basis_capacity(lowest, max_dim)
+    if (dav_version() /= DAV_HIP_ABI_VERSION) then
+       print *, "engine_create: libdavidson_hip.so reports ABI version ", dav_version(), ", these modules were built for ", &
+            DAV_HIP_ABI_VERSION
+       error stop
+    end if
     call check_dav(dav_create(eng%h, int(dev, c_int), int(n, c_int64_t), int(eng%max_cols, c_int), &
          merge(1_c_int, 0_c_int, eng%gev), int(rk, c_int), int(nr, c_int)), "dav_create")
     ! engine knob that does not touch the reference's argument lists (reaches the dense and matrix-free
@@ -176,14 +180,6 @@ contains
     character(kind=c_char), intent(out) :: id(128)
     call check_dav(dav_comm_unique_id(id), "dav_comm_unique_id")
   end subroutine engine_comm_unique_id
-
-  !> Test transport for ranks that are PROCESSES sharing one GPU: collectives through the POSIX shared-memory
-  !> segment `name` ("/something"; rank 0 creates it).  The multi-GPU data path is engine_comm_init (RCCL).
-  subroutine engine_comm_init_shm(eng, name)
-    type(davidson_engine), intent(inout) :: eng
-    character(len=*), intent(in) :: name
-    call check_dav(dav_comm_init_shm(eng%h, trim(name) // c_null_char), "dav_comm_init_shm")
-  end subroutine engine_comm_init_shm
 
   subroutine engine_comm_init(eng, id)
     type(davidson_engine), intent(inout) :: eng
@@ -363,7 +359,8 @@ contains
     ! stored matrix: the dense driver's sticky convergence flags (src/davidson.f90:176); matrix-free operator A:
     ! the matrix-free driver's all-at-once test (:416)
     call davidson_device_loop(eng%h, eng%n, lowest, method, max_iterations, tolerance, iters, max_dim, &
-         eng%gev, .not. eng%free_semantics, eigenvalues, policy=eng%policy, device_rr=eng%device_rr)
+         eng%gev, .not. eng%free_semantics, eigenvalues, policy=eng%policy, device_rr=eng%device_rr, &
+         phase_seconds=eng%phase_seconds)
     if (present(eigenvectors)) then
        call check_dav(dav_panel_get(eng%h, DAV_PANEL_X, 0_c_int, int(lowest, c_int), eigenvectors, &
             int(size(eigenvectors, 1), c_int64_t)), "dav_panel_get")
@@ -375,7 +372,7 @@ contains
   !> matrix-free path's all-at-once test (:416).  fun_a/fun_b present = operators applied by the
   !> host through callbacks (API-faithful matrix-free path).
   subroutine davidson_device_loop(h, n, lowest, method, max_iterations, tolerance, iters, max_dim, gev, &
-       sticky, eigenvalues, fun_a, fun_b, policy, device_rr)
+       sticky, eigenvalues, fun_a, fun_b, policy, device_rr, phase_seconds)
     type(c_ptr), intent(in) :: h
     integer, intent(in) :: n, lowest, max_iterations, max_dim
     character(len=*), intent(in) :: method
@@ -390,8 +387,11 @@ contains
     integer, intent(in), optional :: policy
     !> Rayleigh-Ritz on the device (engine_set_device_rr); bases wider than 128 columns use the host
     logical, intent(in), optional :: device_rr
+    !> wall time of this solve by phase (see davidson_engine%phase_seconds)
+    real(dp), intent(out), optional :: phase_seconds(8)
 
-    integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr, nvec
+    integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr, nvec, nrestart
+    integer, parameter :: refresh_every = 8
     integer(c_int), allocatable :: sel(:)
     integer(c_int) :: sweeps
     logical :: drr
@@ -404,9 +404,9 @@ contains
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
     logical, allocatable :: has_converged(:)
     logical :: host_ops, done
-    real(dp) :: t0, t1
+    real(dp) :: t0, t1, phase_s(8)
 
-    last_phase_seconds = 0.0_dp
+    phase_s = 0.0_dp
     host_ops = present(fun_a)
     if (host_ops) then
        meth = DAV_METHOD_DPR       ! the matrix-free driver never looks at `method`: always DPR (src/davidson.f90:428)
@@ -432,6 +432,7 @@ contains
     hm = 0.0_dp
     sm = 0.0_dp
     has_converged = .false.
+    nrestart = 0
     drr = .false.
     if (present(device_rr)) drr = device_rr .and. cap <= 128
     call check_dav(dav_rr_enable(h, merge(1_c_int, 0_c_int, drr)), "dav_rr_enable")
@@ -641,6 +642,15 @@ contains
              end if
              call check_dav(dav_restart(h, int(m, c_int), int(kt, c_int), y, int(m, c_int64_t)), "dav_restart")
           end if
+          ! W = A*V and B*V were contracted, not recomputed: each restart adds ~eps*|A|*sqrt(m) to W - A*V.  Every
+          ! `refresh_every`-th restart re-applies the operators to the kept block, as the reference does after every
+          ! restart (src/davidson.f90:223-226), so the drift of the residuals the convergence test reads stays bounded
+          ! over long runs (max_iterations = 1000)
+          nrestart = nrestart + 1
+          if (mod(nrestart, refresh_every) == 0) then
+             call check_dav(dav_expand(h, 0_c_int, int(kt, c_int)), "dav_expand")
+             if (host_ops) call apply_host_block(h, n, 0, kt, fun_a, fun_b)
+          end if
           call lap(7)
           hm = 0.0_dp
           sm = 0.0_dp
@@ -660,15 +670,16 @@ contains
     end if
     if (verbose()) then
        print "(a, i0, a, i0, a, 8f9.3)", "davidson: n=", n, " iters=", iters, &
-            " ms[setup rr ritz ortho apply project restart gjd]=", last_phase_seconds * 1.0e3_dp
+            " ms[setup rr ritz ortho apply project restart gjd]=", phase_s * 1.0e3_dp
     end if
+    if (present(phase_seconds)) phase_seconds = phase_s
 
   contains
 
     subroutine lap(slot)
       integer, intent(in) :: slot
       t1 = tick()
-      last_phase_seconds(slot) = last_phase_seconds(slot) + (t1 - t0)
+      phase_s(slot) = phase_s(slot) + (t1 - t0)
       t0 = t1
     end subroutine lap
 

@@ -235,10 +235,14 @@ contains
     iters = it
   end subroutine fd_engine_solve
 
-  subroutine fd_last_phase_seconds(out) bind(C, name="fd_last_phase_seconds")
+  !> wall time of the last solve on this engine by phase (davidson_engine%phase_seconds)
+  subroutine fd_engine_phase_seconds(p, out) bind(C, name="fd_engine_phase_seconds")
+    type(c_ptr), value :: p
     real(c_double), intent(out) :: out(8)
-    out = last_phase_seconds
-  end subroutine fd_last_phase_seconds
+    type(davidson_engine), pointer :: eng
+    call c_f_pointer(p, eng)
+    out = eng%phase_seconds
+  end subroutine fd_engine_phase_seconds
 
   ! ---- helper modules (unit tests mirror src/tests/test_call_lapack.f90) ----------------------------
   subroutine fd_lapack_eigensolver(n, mtx, has_stx, stx, evals, evecs) bind(C, name="fd_lapack_eigensolver")

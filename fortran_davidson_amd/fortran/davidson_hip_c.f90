@@ -18,12 +18,23 @@ module davidson_hip_c
      real(c_double) :: apply_kernel_ms, apply_flops
      integer(c_int64_t) :: apply_launches
      integer(c_int64_t) :: restarts
+     real(c_double) :: allgather_ms, reduce_scatter_ms, allreduce_ms
+     real(c_double) :: allgather_bytes, reduce_scatter_bytes, allreduce_bytes
+     integer(c_int64_t) :: collectives
+     integer(c_int32_t) :: comm_ranks, comm_overlap
   end type dav_stats
+  !> DAV_HIP_ABI_VERSION of include/davidson_hip.h these interfaces were written against: engine_create checks that the
+  !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101 and 102)
+  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 102
 
   interface
      function dav_last_error() bind(C, name="dav_last_error") result(p)
        import :: c_ptr
        type(c_ptr) :: p
+     end function
+     function dav_version() bind(C, name="dav_version") result(v)
+       import :: c_int
+       integer(c_int) :: v
      end function
      function dav_create(h, device, n, max_cols, gev, rank, nranks) bind(C, name="dav_create") result(ierr)
        import :: c_ptr, c_int, c_int64_t
@@ -40,12 +51,6 @@ module davidson_hip_c
      function dav_comm_unique_id(id) bind(C, name="dav_comm_unique_id") result(ierr)
        import :: c_char, c_int
        character(kind=c_char), intent(out) :: id(128)
-       integer(c_int) :: ierr
-     end function
-     function dav_comm_init_shm(h, name) bind(C, name="dav_comm_init_shm") result(ierr)
-       import :: c_ptr, c_int, c_char
-       type(c_ptr), value :: h
-       character(kind=c_char), intent(in) :: name(*)
        integer(c_int) :: ierr
      end function
      function dav_comm_init(h, id) bind(C, name="dav_comm_init") result(ierr)

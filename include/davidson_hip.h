@@ -64,8 +64,20 @@ typedef struct dav_stats {
   int64_t apply_launches;  /* launches of the block-matvec kernel (an apply of > 32 / 64 columns is  */
                            /* several launches)                                                      */
   int64_t restarts;        /* collapse restarts (dav_restart / dav_rr_restart) so far                */
+  /* collectives (dav_set_timing level 2; several ranks): HIP-event time on the stream they run on, and */
+  /* the payload per rank - all-gather: bytes received (nranks * count * 8), reduce-scatter: bytes      */
+  /* contributed (nranks * count * 8), all-reduce: count * 8                                            */
+  double allgather_ms, reduce_scatter_ms, allreduce_ms;
+  double allgather_bytes, reduce_scatter_bytes, allreduce_bytes;
+  int64_t collectives;     /* collectives (or groups of them) issued so far, at any timing level      */
+  int32_t comm_ranks;      /* ranks the RCCL communicator reports (ncclCommCount); 0 = no communicator */
+  int32_t comm_overlap;    /* 1 = wide blocks run their collectives on a second stream under the sweeps */
 } dav_stats;
 
+/* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */
+/* caller built against another layout of the statistics structure (it grew in 101 and 102) must not    */
+/* use the unsized call - the sized one, which copies at most `bytes` bytes, is safe across versions.   */
+#define DAV_HIP_ABI_VERSION 102
 const char* dav_last_error(void);
 int dav_version(void);
 
@@ -79,15 +91,9 @@ int dav_destroy(dav_handle_t h);
  * distributes it, every rank calls dav_comm_init.  Not needed when nranks == 1. */
 int dav_comm_unique_id(void* id128);
 int dav_comm_init(dav_handle_t h, const void* id128);
-/* Test transport: the n engines (created with rank r of n, same process, same GPU) exchange through
- * device copies and thread barriers instead of RCCL; each rank must then be driven by its own thread. */
-int dav_local_group_join(dav_handle_t* handles, int n);
-/* Second test transport: ranks are PROCESSES sharing one GPU; collectives go through the POSIX shared-memory
- * segment `name` ("/something", created by rank 0).  Exercises the complete multi-process launch flow
- * (one engine per process, as under torch.distributed.run) on a single-GPU box. */
-int dav_comm_init_shm(dav_handle_t h, const char* name);
 int dav_synchronize(dav_handle_t h);
 int dav_get_stats(dav_handle_t h, dav_stats* out);
+int dav_get_stats_n(dav_handle_t h, void* out, size_t bytes);
 int dav_reset_stats(dav_handle_t h);
 /* What dav_get_stats measures with HIP events on the engine's stream: 0 = nothing, 1 (default) = the block
  * applies (apply_ms: pack + kernel + reduction, apply_kernel_ms: the roofline kernel alone), 2 = also the
@@ -257,20 +263,6 @@ int dav_panel_get(dav_handle_t h, int panel, int c0, int k, double* out, int64_t
 /* panel[:, c0:c0+k] <- host(ld, k) holding all N rows (each rank keeps its slab) */
 int dav_panel_put(dav_handle_t h, int panel, int c0, int k, const double* in, int64_t ld);
 int dav_set_width(dav_handle_t h, int m);
-
-/* ---- measurement ------------------------------------------------------------------------------ */
-/* Time `reps` block applies of A on k columns with HIP events on the engine's stream (inputs resident).
- * Returns the average milliseconds per apply END TO END (operand packing + block-matvec kernel + reduction
- * of the partial sums - everything that produces W from V) and the algorithmic bytes per apply
- * (8*S + 16*N*k).  dav_bench_apply2 also returns the average of the block-matvec kernel
- * alone (kernel_ms) and the flops per apply. */
-int dav_bench_apply(dav_handle_t h, int which, int k, int reps, double* avg_ms, double* bytes);
-/* What the HBM of this box delivers to a plain streaming kernel (16 B per lane): device copy a = b and triad a = b + s c over
- * three arrays of `doubles` entries (0 = 2^28, i.e. 2 GiB each), read + written GB/s - the measured counterpart of the data
- * sheet's 8 TB/s that every HBM fraction of bench.py is also quoted against. */
-int dav_bench_stream(dav_handle_t h, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps);
-int dav_bench_apply2(dav_handle_t h, int which, int k, int reps, double* avg_ms, double* kernel_ms, double* bytes,
-                     double* flops);
 
 #ifdef __cplusplus
 }

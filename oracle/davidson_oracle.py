@@ -32,10 +32,11 @@ _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 # input generator (semantics: array_utils.f90:86-113; random stream: ours, counter based)
 # --------------------------------------------------------------------------------------------
 def _splitmix64(z):
+    """splitmix64 finaliser on uint64 values (arithmetic wraps modulo 2^64)"""
     with np.errstate(over="ignore"):
-        z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M64
-        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
-        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         return z ^ (z >> np.uint64(31))
 
 
@@ -45,23 +46,29 @@ def uniform01(seed, lo, hi):
     hi = np.asarray(hi, dtype=np.uint64)
     with np.errstate(over="ignore"):
         key = (lo << np.uint64(32)) + hi + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
-    z = _splitmix64(key & _M64)
+    z = _splitmix64(key)
     return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
 def generate_diagonal_dominant(m, sparsity, diag_val=None, seed=1, rows=None):
     """array_utils.f90:86-113: arr = U*sparsity, symmetrised from the upper triangle
     (arr(i,j) = arr(j,i) for i>j), diagonal = i (1-based) or diag_val.
-    `rows=(r0,r1)` returns only that row slab (used by the multi-GPU tests)."""
-    r0, r1 = (0, m) if rows is None else rows
-    i = np.arange(r0, r1, dtype=np.uint64)[:, None]
-    j = np.arange(m, dtype=np.uint64)[None, :]
-    lo = np.minimum(i, j)
-    hi = np.maximum(i, j)
-    a = uniform01(seed, lo, hi) * float(sparsity)
-    ii = np.arange(r0, r1)
-    a[ii - r0, ii] = (ii + 1).astype(np.float64) if diag_val is None else float(diag_val)
-    return np.asfortranarray(a)
+    `rows=(r0,r1)` returns only that row slab (used by the multi-GPU tests); `rows=<integer array>` returns
+    those rows (0-based, any order) - how the full-size tests obtain rows of a matrix that does not fit the host."""
+    if rows is None:
+        ii = np.arange(0, m)
+    elif isinstance(rows, tuple):
+        ii = np.arange(rows[0], rows[1])
+    else:
+        ii = np.asarray(rows, dtype=np.int64).ravel()
+    i = ii.astype(np.uint64)[:, None]
+    a = np.empty((len(ii), m), order="F")
+    step = max(256, (1 << 21) // max(len(ii), 1))        # column chunks: the temporaries stay small
+    for c0 in range(0, m, step):
+        j = np.arange(c0, min(m, c0 + step), dtype=np.uint64)[None, :]
+        a[:, c0:c0 + j.shape[1]] = uniform01(seed, np.minimum(i, j), np.maximum(i, j)) * float(sparsity)
+    a[np.arange(len(ii)), ii] = (ii + 1).astype(np.float64) if diag_val is None else float(diag_val)
+    return a
 
 
 # --------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 !> `prog_ranks <rank> <nranks> <tag>`; the ranks share GPU 0 and exchange through the shared-memory test
 !> transport (on a multi-GPU node: device = rank and engine_comm_init with the RCCL id instead).
 program prog_ranks
+  use iso_c_binding, only: c_ptr, c_int, c_char, c_null_char
   use numeric_kinds, only: dp
   use davidson, only: generalized_eigensolver
   use davidson_device
@@ -14,6 +15,16 @@ program prog_ranks
   type(davidson_engine) :: eng
   integer :: rank, nranks, it, it1, j, nfail
   character(len=64) :: arg, tag
+  ! the shared-memory transport exists in the TEST build of libdavidson_hip.so only (csrc/davidson_hip_private.h): it is
+  ! not part of the product's Fortran modules, the test binds it itself
+  interface
+     function dav_comm_init_shm(h, name) bind(C, name="dav_comm_init_shm") result(ierr)
+       import :: c_ptr, c_int, c_char
+       type(c_ptr), value :: h
+       character(kind=c_char), intent(in) :: name(*)
+       integer(c_int) :: ierr
+     end function
+  end interface
 
   call get_command_argument(1, arg); read (arg, *) rank
   call get_command_argument(2, arg); read (arg, *) nranks
@@ -24,7 +35,7 @@ program prog_ranks
   stx = generate_diagonal_dominant(dim, 1d-2, 1d0, 2)
 
   call engine_create(eng, dim, lowest, gev=.true., device=0, rank=rank, nranks=nranks)
-  call engine_comm_init_shm(eng, "/" // trim(tag))
+  if (dav_comm_init_shm(eng%h, "/" // trim(tag) // c_null_char) /= 0) error stop "dav_comm_init_shm failed"
   call engine_set_dense(eng, 1, mtx)
   call engine_set_dense(eng, 2, stx)
   call generalized_eigensolver(eng, ev, x, lowest, "DPR", 200, 1d-8, it, 24)

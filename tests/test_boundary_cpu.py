@@ -13,14 +13,42 @@ from oracle import davidson_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(path):
+    return sorted(set(re.findall(r"\b(dav_[a-z0-9_]+)\s*\(", open(path).read())))
+
+
 def test_c_abi_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "davidson_hip.h")).read()
-    names = sorted(set(re.findall(r"\b(dav_[a-z0-9_]+)\s*\(", hdr)))
+    """Both builds export every entry point of the public header; the private header (measurement doors of bench.py, doors of
+    the TEST build) is not part of include/: its test-transport doors exist in the test build only."""
+    names = _declared(os.path.join(ROOT, "include", "davidson_hip.h"))
     assert len(names) >= 30
-    lib = fd.hip_lib()
-    missing = [n for n in names if not hasattr(lib, n)]
-    assert not missing, missing
-    assert lib.dav_version() >= 100
+    assert not [n for n in names if n.startswith("dav_bench_") or n in ("dav_local_group_join", "dav_comm_init_shm")]
+    private = _declared(os.path.join(ROOT, "fortran_davidson_amd", "csrc", "davidson_hip_private.h"))
+    test_only = ["dav_local_group_join", "dav_comm_init_shm"]
+    assert all(n in private for n in test_only + ["dav_bench_apply2", "dav_bench_stream", "dav_apply_inner"])
+    libdir = os.path.join(ROOT, "fortran_davidson_amd", "lib")
+    fd.hip_lib()                 # first: it brings PyTorch's HIP runtime in before any other copy (see _lib.py)
+    for path, is_test in ((os.path.join(libdir, "libdavidson_hip.so"), False), (os.path.join(libdir, "test", "libdavidson_hip.so"), True)):
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+        want = names + [n for n in private if is_test or n not in test_only]
+        missing = [n for n in want if not hasattr(lib, n)]
+        assert not missing, (path, missing)
+        hdr = open(os.path.join(ROOT, "include", "davidson_hip.h")).read()
+        assert lib.dav_version() == int(re.search(r"#define DAV_HIP_ABI_VERSION (\d+)", hdr).group(1))
+    assert fd.hip_lib().dav_version() == fd.engine_c.ABI_VERSION
+
+
+def test_stats_mirror_has_the_size_of_the_c_structure():
+    """ctypes mirror of dav_stats against the C header, compiled here (a layout change without a version bump is an overrun
+    in a caller built against the old header: ADVICE round 3)."""
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "davidson_hip.h"\nint main(void){printf("%zu %d\\n", sizeof(dav_stats), DAV_HIP_ABI_VERSION);return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
+        size, ver = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(size) == ctypes.sizeof(fd.engine_c.Stats) and int(ver) == fd.engine_c.ABI_VERSION
 
 
 def test_fortran_host_exports_api_doors():
@@ -103,9 +131,8 @@ def test_rayleigh_ritz_solver_all_routes_against_scipy(n, nvec, gev):
 
 
 def test_product_library_is_built_without_the_test_transports():
-    """lib/libdavidson_hip.so (what a user links) carries no loopback / shared-memory transport: its two entry points are
-    stubs that fail; lib/test/libdavidson_hip.so (same sources, -DDAV_TEST_TRANSPORTS=1, same soname) is what pytest loads."""
-    import ctypes as C
+    """lib/libdavidson_hip.so (what a user links) carries no loopback / shared-memory transport - their entry points do not
+    exist in it; lib/test/libdavidson_hip.so (same sources, -DDAV_TEST_TRANSPORTS=1, same soname) is what pytest loads."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prod = os.path.join(root, "fortran_davidson_amd", "lib", "libdavidson_hip.so")
@@ -114,11 +141,13 @@ def test_product_library_is_built_without_the_test_transports():
         assert os.path.exists(path), path
         dyn = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
         assert "soname: [libdavidson_hip.so]" in dyn
-    stub_msg = b"built without DAV_TEST_TRANSPORTS"
-    assert stub_msg in open(prod, "rb").read()
-    assert stub_msg not in open(test, "rb").read()
-    assert os.environ.get("DAVIDSON_HIP_LIB") == test          # conftest.py
-    # the stubs fail without touching a GPU
-    lib = C.CDLL(prod, mode=C.RTLD_LOCAL)
-    lib.dav_last_error.restype = C.c_char_p
-    assert lib.dav_local_group_join(None, 0) != 0 and stub_msg in lib.dav_last_error()
+    syms = {path: subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout for path in (prod, test)}
+    for name in ("dav_local_group_join", "dav_comm_init_shm"):
+        assert name not in syms[prod] and name in syms[test]
+    assert b"DAV_TEST_STALL_MS" not in open(prod, "rb").read() and b"DAV_TEST_STALL_MS" in open(test, "rb").read()
+    # conftest.py points pytest at the test build unless the caller chose a library itself
+    assert os.path.samefile(fd._lib.HIP_LIB, test) or os.environ.get("DAVIDSON_HIP_LIB") not in (None, test)
+    # the Fortran host library links against the product build alone (no test door among its undefined symbols)
+    und = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(root, "fortran_davidson_amd", "lib", "libfortran_davidson_amd.so")],
+                         capture_output=True, text=True).stdout
+    assert "dav_create" in und and "dav_comm_init_shm" not in und and "dav_local_group_join" not in und

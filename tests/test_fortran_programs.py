@@ -20,8 +20,11 @@ REF_TESTS = "/root/reference/src/tests"
 needs_flang = pytest.mark.skipif(not os.path.exists(FC), reason="flang not available")
 
 
-def compile_link(sources, exe, workdir):
-    cmd = [FC, "-O1", "-fopenmp=libiomp5", f"-I{MODDIR}", "-module-dir", str(workdir), *sources,
+def compile_link(sources, exe, workdir, test_build=False):
+    """test_build: link against the TEST build of the engine (lib/test/libdavidson_hip.so, the one with the shared-memory
+    transport) - for programs that bind a door of csrc/davidson_hip_private.h themselves"""
+    hip_dirs = [f"-L{os.path.join(LIBDIR, 'test')}"] if test_build else []
+    cmd = [FC, "-O1", "-fopenmp=libiomp5", f"-I{MODDIR}", "-module-dir", str(workdir), *sources, *hip_dirs,
            f"-L{LIBDIR}", "-lfortran_davidson_amd", "-ldavidson_hip", f"-Wl,-rpath,{LIBDIR}",
            "-L/opt/conda/lib", "-Wl,-rpath,/opt/conda/lib", "-o", exe]
     res = subprocess.run(cmd, capture_output=True, text=True, cwd=workdir)
@@ -42,7 +45,7 @@ def build_programs(tmp_path):
 def build_ranks_program(tmp_path):
     bindir = os.path.join(SRC, "_bin")
     os.makedirs(bindir, exist_ok=True)
-    return compile_link([os.path.join(SRC, "prog_ranks.f90")], os.path.join(bindir, "prog_ranks"), tmp_path)
+    return compile_link([os.path.join(SRC, "prog_ranks.f90")], os.path.join(bindir, "prog_ranks"), tmp_path, test_build=True)
 
 
 def build_options_program(tmp_path):

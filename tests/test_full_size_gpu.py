@@ -1,25 +1,83 @@
-"""GPU, BASELINE.json's full sizes: no CPU oracle finishes there in seconds, so parity is checked
-through size-independent properties of the answer, computed with engine primitives that are
-independent of the solver phases (one extra block apply + one block transform + one Gram):
+"""GPU, BASELINE.json's full sizes.  No CPU oracle solves these problems in seconds, but the oracle's generator
+(oracle/davidson_oracle.py: generate_diagonal_dominant(..., rows=<index array>), semantics of src/array_utils.f90:86-113) produces
+any ROWS of the 160 GB matrix on the host: the block sweeps of the engine are compared with `A[rows, :] @ X` computed by numpy
+from those rows - ~500 rows placed where the symmetric-tiled kernels have their special cases (block row 0, both sides of the
+super-row boundaries of the first and the last group of four block rows, the last ragged block row, tiles whose offset passes
+2^31 / 2^32 / 2^33 entries, random rows in between) - to 1e-12 of the entry-wise scale sum_j |a_ij| |x_j|.  The solves are then
+checked through their eigen-residuals, computed with that anchored sweep:
 
-  * eigen-residuals  || A x_j - lambda_j B x_j ||_2 < tol  for the returned pairs,
+  * eigen-residuals  || A x_j - lambda_j B x_j ||_2 < tol  for the returned pairs (A x_j anchored to the oracle rows),
   * (B-)orthonormality of the returned vectors,
   * ascending eigenvalues inside the Gershgorin discs of the lowest diagonal entries,
   * agreement between independent routes to the same answer (full vs symmetric-tiled storage,
     dense vs matrix-free operator, DPR vs GJD).
 """
+import threading
+
 import numpy as np
 import pytest
 
 import fortran_davidson_amd as fd
 from fortran_davidson_amd.engine_c import OP_A, OP_B, PANEL_X, PANEL_R, PANEL_S
+from oracle import davidson_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-8
+ROW_TOL = 1e-12          # of sum_j |a_ij| |x_j| (and, a fortiori, of max |W|)
+TB = 256                 # tile edge of the symmetric storage
 
 
-def verify_on_device(eng, lam, gev, n, sparsity):
-    """Independent check of the Ritz pairs left in PANEL_X by the last solve."""
+def anchor_rows(n, nrandom=300):
+    """Row indices that reach every special case of the symmetric-tiled sweeps at order n."""
+    nb = (n + TB - 1) // TB
+    rows = []
+
+    def around(r, w=3):
+        rows.extend(range(max(0, r - w), min(n, r + w)))
+
+    for I in range(0, min(nb, 9)):                 # block rows 0-8: the first groups of four, both sides of the R = 2 / R = 4 super-row boundaries
+        around(I * TB)
+    rows.extend(range(min(n, TB + 100), min(n, TB + 104)))        # inside a diagonal super block
+    for bits in (31, 32, 33, 34):                  # block rows whose first tile lies beyond 2^bits entries of the storage
+        I = int(np.ceil((np.sqrt(1.0 + 8.0 * 2.0 ** bits / (TB * TB)) - 1.0) / 2.0))
+        if I + 1 < nb:
+            around(I * TB)
+            around((I + 1) * TB)
+    around(n // 2)
+    for I in range(max(0, 4 * ((nb - 1) // 4) - 1), nb):          # the last group of four block rows and the block row in front of it
+        around(I * TB)
+    rows.extend(range(max(0, n - 70), n))          # the last (ragged) block row, to the last row
+    rows.extend(np.random.default_rng(11).integers(0, n, nrandom).tolist())
+    return np.unique(np.asarray(rows, dtype=np.int64))
+
+
+_ROWS = {}
+_ROWS_LOCK = threading.Lock()
+
+
+def oracle_rows(n, sparsity, seed, diag_val=None, nrandom=300):
+    """(rows, A[rows, :]) of generate_diagonal_dominant(n, sparsity, diag_val, seed) from the oracle, cached per matrix."""
+    key = (n, sparsity, seed, diag_val, nrandom)
+    with _ROWS_LOCK:
+        if key not in _ROWS:
+            rows = anchor_rows(n, nrandom)
+            _ROWS[key] = (rows, O.generate_diagonal_dominant(n, sparsity, diag_val, seed, rows=rows))
+        return _ROWS[key]
+
+
+def assert_rows_match(W, X, rows, a_rows, what):
+    """W[rows] against the oracle rows times X, entry by entry."""
+    ref = a_rows @ X
+    scale = np.abs(a_rows) @ np.abs(X)
+    err = np.abs(W[rows] - ref)
+    worst = np.unravel_index(np.argmax(err / (scale + 1e-300)), err.shape)
+    assert (err <= ROW_TOL * scale + 1e-300).all(), (what, int(rows[worst[0]]), int(worst[1]), float(err[worst]), float(scale[worst]))
+    assert err.max() <= ROW_TOL * np.abs(W).max(), what
+
+
+def verify_on_device(eng, lam, gev, n, sparsity, anchor=None):
+    """Independent check of the Ritz pairs left in PANEL_X by the last solve.  anchor = dict(A=(seed, diag_val), B=(seed, diag_val) |
+    None): the products A X (and B X) the residuals are made of are themselves compared with the oracle's rows."""
     c = eng.c
     L = len(lam)
     c.apply(OP_A, PANEL_X, 0, L, PANEL_R, 0)                     # A X
@@ -27,6 +85,16 @@ def verify_on_device(eng, lam, gev, n, sparsity):
         c.apply(OP_B, PANEL_X, 0, L, PANEL_R, L)                 # B X
     else:
         c.panel_transform(PANEL_X, 0, L, np.eye(L), PANEL_R, L)  # X
+    if anchor is not None:
+        X = c.panel_get(PANEL_X, 0, L)                           # collective with several ranks: every rank calls it
+        AX = c.panel_get(PANEL_R, 0, L)
+        BX = c.panel_get(PANEL_R, L, L) if anchor.get("B") else None
+        if c.stats().rank == 0:
+            rows, a_rows = oracle_rows(n, sparsity, *anchor["A"])
+            assert_rows_match(AX, X, rows, a_rows, "A X of the residual check")
+            if BX is not None:
+                rows, b_rows = oracle_rows(n, sparsity, *anchor["B"])
+                assert_rows_match(BX, X, rows, b_rows, "B X of the residual check")
     M = np.vstack([np.eye(L), -np.diag(lam)])                    # [AX | BX] [I; -Lambda] = residues
     c.panel_transform(PANEL_R, 0, 2 * L, M, PANEL_S, 0)
     res = np.sqrt(np.diag(c.gram(PANEL_S, 0, L, PANEL_S, 0, L)))
@@ -48,7 +116,7 @@ def test_config2_n20000_full_and_symmetric_storage_agree():
             eng.generate_diagonal_dominant(1, sp, seed=1)
             lam, _, iters = eng.solve("DPR", 1000, TOL, want_vectors=False)
             assert iters == 3
-            verify_on_device(eng, lam, False, n, sp)
+            verify_on_device(eng, lam, False, n, sp, anchor={"A": (1, None)})
             lams[storage] = lam
     assert np.abs(lams["full"] - lams["symmetric"]).max() < 1e-10
 
@@ -61,7 +129,7 @@ def test_config3_n200000_one_gpu():
         eng.generate_diagonal_dominant(1, sp, seed=1)
         lam, _, iters = eng.solve("DPR", 1000, TOL, want_vectors=False)
         assert 0 < iters <= 1000
-        verify_on_device(eng, lam, False, n, sp)
+        verify_on_device(eng, lam, False, n, sp, anchor={"A": (1, None)})
         st = eng.c.stats()
         assert st.apply_bytes / st.applies > 1.5e11            # each pass swept the 160 GB triangle
 
@@ -74,10 +142,11 @@ def test_config4_n200000_generalized_dpr_and_gjd():
     with fd.DavidsonEngine(n, L, gev=True, storage="symmetric") as eng:
         eng.generate_diagonal_dominant(1, sp, seed=1)
         eng.set_hashed_operator(2, sp, 1.0, seed=2)
+        anchor = {"A": (1, None), "B": (2, 1.0)}
         lam_dpr, _, it_dpr = eng.solve("DPR", 100, TOL, want_vectors=False)
-        verify_on_device(eng, lam_dpr, True, n, sp)
+        verify_on_device(eng, lam_dpr, True, n, sp, anchor=anchor)
         lam_gjd, _, it_gjd = eng.solve("GJD", 100, TOL, want_vectors=False)
-        verify_on_device(eng, lam_gjd, True, n, sp)
+        verify_on_device(eng, lam_gjd, True, n, sp, anchor=anchor)
     assert np.abs(lam_dpr - lam_gjd).max() < 1e-8
     assert it_gjd <= it_dpr
 
@@ -107,7 +176,7 @@ def test_config5_n1000000_matrix_free_one_rank():
         eng.set_identity(2)
         lam, _, iters = eng.solve("DPR", 100, TOL, want_vectors=False)
         assert 0 < iters <= 100
-        verify_on_device(eng, lam, True, n, sp)
+        verify_on_device(eng, lam, True, n, sp, anchor={"A": (1, None)})      # B = I
 
 
 @pytest.mark.parametrize("storage", ["full", "symmetric"])
@@ -129,7 +198,7 @@ def test_config5_n1000000_matrix_free_four_ranks(storage):
             engs[r].set_hashed_operator(1, sp, seed=1)
             engs[r].set_identity(2)
             lam, _, iters = engs[r].solve("DPR", 100, TOL, want_vectors=False)
-            verify_on_device(engs[r], lam, True, n, sp)
+            verify_on_device(engs[r], lam, True, n, sp, anchor={"A": (1, None)})
             out[r] = (lam, iters)
         except Exception as exc:      # noqa: BLE001
             err[r] = exc
@@ -157,36 +226,74 @@ def test_config3_n200000_restart_forcing_variant():
         eng.generate_diagonal_dominant(1, sp, seed=3)
         lam, _, iters = eng.solve("DPR", 200, TOL, want_vectors=False)
         assert 3 < iters <= 200
-        verify_on_device(eng, lam, False, n, sp)
+        verify_on_device(eng, lam, False, n, sp, anchor={"A": (3, None)})
         st = eng.c.stats()
         assert st.restarts >= 1 and st.applies + st.restarts >= iters    # one sweep per growing iteration, none after a restart (W and B*V are contracted with V)
 
 
-def test_sweep_kernels_at_full_size_agree_with_each_other():
-    """The block sweep at N=200000 (160 GB of symmetric tiles), properties that need no reference product: the 64-column launch
-    (two workgroups per work item) is bit for bit the two 32-column launches of its halves; 16 columns (one column group per
-    workgroup) and 8 columns (the four-block-row kernel on the 4x4x4 MFMA - another kernel, another schedule, other sums)
-    agree with it to rounding; X^T (A Y) = (A X)^T Y."""
-    from fortran_davidson_amd.engine_c import PANEL_V, PANEL_W
-    n = 200000
+def test_sweep_kernels_at_full_size_against_oracle_rows():
+    """The block sweeps at N=200000 (160 GB of symmetric tiles) against rows of the oracle's matrix: 8 columns (four block rows per
+    workgroup, 4x4x4 MFMA), 16 (the one-wave-per-SIMD kernel on four block rows), 32 and 64 (the same on two block rows, one / two
+    workgroups per work item), the fp32-tile variant of the mixed-precision inner sweeps (against the fp32-rounded rows), and the
+    second operator of configs[3] - the same generator with unit diagonal, generated in the sweep and, where its tiles are kept
+    resident, read from HBM.  Then the relations between the launches: the 64-column launch is bit for bit the two 32-column
+    launches of its halves; X^T (A Y) = (A X)^T Y."""
+    from fortran_davidson_amd.engine_c import PANEL_V, PANEL_W, PANEL_BV
+    n, sp = 200000, 1e-3
     rng = np.random.default_rng(5)
-    with fd.CEngine(n=n, max_cols=64) as e:
+    rows, a_rows = oracle_rows(n, sp, 1, None)
+    with fd.CEngine(n=n, max_cols=64, gev=True) as e:
         e.set_storage(1)
-        e.set_dense_generated(OP_A, 1, 1e-3)
+        e.set_dense_generated(OP_A, 1, sp)
         X = rng.standard_normal((n, 64))
         e.panel_put(PANEL_V, 0, X)
         e.apply(OP_A, PANEL_V, 0, 64, PANEL_W, 0)
         W = e.panel_get(PANEL_W, 0, 64)
         assert np.isfinite(W).all()
+        assert_rows_match(W, X, rows, a_rows, "64 columns")
         for c0 in (0, 32):
             e.apply(OP_A, PANEL_V, c0, 32, PANEL_S, 0)
-            assert np.array_equal(e.panel_get(PANEL_S, 0, 32), W[:, c0:c0 + 32])
-        scale = np.abs(W).max()
+            W32 = e.panel_get(PANEL_S, 0, 32)
+            assert_rows_match(W32, X[:, c0:c0 + 32], rows, a_rows, f"32 columns from {c0}")
+            assert np.array_equal(W32, W[:, c0:c0 + 32])
         e.apply(OP_A, PANEL_V, 16, 16, PANEL_S, 0)
-        assert np.abs(e.panel_get(PANEL_S, 0, 16) - W[:, 16:32]).max() < 1e-12 * scale
+        assert_rows_match(e.panel_get(PANEL_S, 0, 16), X[:, 16:32], rows, a_rows, "16 columns")
         e.apply(OP_A, PANEL_V, 40, 8, PANEL_S, 0)
-        assert np.abs(e.panel_get(PANEL_S, 0, 8) - W[:, 40:48]).max() < 1e-12 * scale
+        assert_rows_match(e.panel_get(PANEL_S, 0, 8), X[:, 40:48], rows, a_rows, "8 columns")
+        e.apply(OP_A, PANEL_V, 3, 5, PANEL_S, 0)                   # a ragged width
+        assert_rows_match(e.panel_get(PANEL_S, 0, 5), X[:, 3:8], rows, a_rows, "5 columns")
         G = e.gram(PANEL_V, 0, 64, PANEL_W, 0, 64)                 # X^T A X: symmetric to rounding
         assert np.abs(G - G.T).max() < 1e-11 * np.abs(G).max()
-        # the diagonal dominates: (A X)_ij = (i + 1) X_ij + O(n * sparsity) - a coarse check of the values themselves
-        assert np.abs(W - np.arange(1, n + 1)[:, None] * X).max() < 1e-3 * n * 6 * 0.05 + 50
+        # the second operator of configs[3]: unit diagonal, never stored in full
+        rows_b, b_rows = oracle_rows(n, sp, 2, 1.0)
+        e.set_operator_hashed(OP_B, 2, sp, 1.0)
+        for c0, k in ((0, 16), (8, 8), (0, 32)):
+            e.apply(OP_B, PANEL_V, c0, k, PANEL_BV, 0)
+            assert_rows_match(e.panel_get(PANEL_BV, 0, k), X[:, c0:c0 + k], rows_b, b_rows, f"B, {k} columns, resident fraction {e.resident_fraction(OP_B):.2f}")
+        e.set_operator_identity(OP_B)                              # releases what was resident of B: room for the fp32 copy of A
+        # mixed-precision inner sweeps: the fp32 copy of the tiles, fp64 products and sums
+        e.set_inner_precision(32)
+        a32 = a_rows.astype(np.float32).astype(np.float64)
+        for c0, k in ((0, 16), (20, 8)):
+            e.apply_inner(OP_A, PANEL_V, c0, k, PANEL_S, 0)
+            W16 = e.panel_get(PANEL_S, 0, k)
+            assert_rows_match(W16, X[:, c0:c0 + k], rows, a32, f"fp32 tiles, {k} columns")
+            assert not np.array_equal(W16, W[:, c0:c0 + k])        # the fp32 copy really was what the sweep read
+
+
+def test_generated_sweeps_at_n1000000_against_oracle_rows():
+    """configs[4]'s operator at its stated order: the hashed diagonal-dominant operator generated in the symmetric sweep (every
+    pair once), 16 and 8 columns, against rows of the oracle's matrix (1.5e8 entries generated on the host)."""
+    from fortran_davidson_amd.engine_c import PANEL_V, PANEL_W
+    n, sp = 1000000, 1e-3
+    rows, a_rows = oracle_rows(n, sp, 1, None, nrandom=100)
+    rng = np.random.default_rng(6)
+    with fd.CEngine(n=n, max_cols=16) as e:
+        e.set_storage(1)
+        e.set_operator_hashed(OP_A, 1, sp)
+        X = rng.standard_normal((n, 16))
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_A, PANEL_V, 0, 16, PANEL_W, 0)
+        assert_rows_match(e.panel_get(PANEL_W, 0, 16), X, rows, a_rows, "generated, 16 columns")
+        e.apply(OP_A, PANEL_V, 4, 8, PANEL_W, 0)
+        assert_rows_match(e.panel_get(PANEL_W, 0, 8), X[:, 4:12], rows, a_rows, "generated, 8 columns")

@@ -77,15 +77,19 @@ def test_two_gpus_matrix_free_configs4_shape():
 
 
 def test_a_rank_that_dies_ends_the_launch_within_the_bound():
-    """One rank of two is killed between solves (DAV_TEST_KILL_RANK): its peer must not wait in a collective for ever - the
-    watchdog (DAVIDSON_COLLECTIVE_TIMEOUT) or the launcher ends it, and the launch returns a non-zero code well inside the bound."""
+    """One rank of two ends abruptly in the middle of a long run (tests/rank_killer.py: a timer in rank 1): its peer must not wait
+    in a collective for ever - the watchdog (DAVIDSON_COLLECTIVE_TIMEOUT) or the launcher ends it, and the launch returns a
+    non-zero code well inside the bound."""
     if _gpus() < 2:
         pytest.skip("needs two GPUs")
     import time
-    env = dict(os.environ, DAVIDSON_COLLECTIVE_TIMEOUT="20", DAV_TEST_KILL_RANK="1")
+    env = dict(os.environ, DAVIDSON_COLLECTIVE_TIMEOUT="20")
     env.pop("DAVIDSON_TRANSPORT", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     t0 = time.time()
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--order", "6000",
-                          "--headline-only"], capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+           os.path.join(ROOT, "tests", "rank_killer.py"), "1", "45", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1000000",
+           "--warmup", "1", "--order", "6000", "--headline-only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     assert res.returncode != 0
     assert time.time() - t0 < 300
