@@ -14,10 +14,13 @@ control plane (unique-id broadcast, barriers, max-over-ranks of the time).  valu
 per second over the K timed solves (strong scaling: the problem is the same for every N).
 
 Objects in the JSON line besides the contract's fields:
-  roofline       the dominant kernel of the timed region (the block matvec as the solve launches it: 32
-                 columns per launch - bound by the fp64 matrix pipe), HIP-event timed inside the solves
-  roofline_hbm   the north-star measurement: A*V at N=200000, k=8 on the same resident matrix, END TO END
-                 (operand packing + sweep kernel + fixed-order reduction) and the sweep kernel alone
+  roofline       the dominant kernel of the timed region (the block matvec as the solve launches it: 32 / 64
+                 columns per launch - bound by the fp64 matrix pipe), HIP-event timed inside the solves; its hbm_* keys
+                 (and the nested `hbm` object) carry the NORTH-STAR measurement - A*V at N=200000, k=8 on the same resident
+                 matrix, END TO END (operand packing + sweep kernel + fixed-order reduction) and the sweep kernel alone,
+                 against 8 TB/s and against the copy / triad rate measured in the same run - and k=16 beside it
+  roofline_hbm   the same north-star object at top level (kept for readers of earlier rounds)
+  comm           several GPUs: ranks RCCL reports, storage mode, per-solve all-gather / reduce-scatter / all-reduce ms and bytes
   apply          the same for k = 8, 16, 32
   hbm_measured   device copy / triad rate of this box (what 8 TB/s amount to in practice); HBM fractions are quoted against both
   configs2_restart  configs[2] with a denser coupling: the solve goes through collapse restarts at full size
@@ -79,6 +82,7 @@ def parse():
     ap.add_argument("--control-plane-only", action="store_true",
                     help="exercise the launch plumbing (rendezvous, id broadcast, barrier, max over ranks) without a GPU")
     ap.add_argument("--cpu-n", type=int, default=0, help="order for the CPU baseline (0 = same as --small-n)")
+    ap.add_argument("--cpu-n2", type=int, default=40000, help="second, larger order for the CPU baseline (0 = none)")
     return ap.parse_args()
 
 
@@ -86,28 +90,44 @@ CPU_CHILD = r"""
 import ctypes, json, os, sys, time
 sys.path.insert(0, {root!r})
 import numpy as np
-lowest, tol = {lowest}, {tol}
-A = np.load({path!r}, mmap_mode="r")
-A = np.asfortranarray(A)
+lowest, tol, sparsity, n_list = {lowest}, {tol}, {sparsity}, {n_list}
 from oracle import ref, davidson_oracle as O        # never imports the product, never touches the GPU
-out = dict(n=int(A.shape[0]))
+out = dict(runs=[])
+def numa_nodes():
+    try:
+        return len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        return None
+out["numa_nodes"] = numa_nodes()
+out["logical_cpus"] = os.cpu_count()
+try:
+    out["sockets"] = len(set(l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("physical id")))
+    out["cpu_model"] = next(l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+except Exception:
+    pass
 if ref.available():
     ref.lib()
-    try:
-        threads = int(ctypes.CDLL("/opt/conda/lib/libmkl_rt.so").mkl_get_max_threads())
-    except Exception:
-        threads = os.cpu_count()
-    t = time.perf_counter(); lam, vec, it = ref.dense_solve(A, lowest, "DPR", 1000, tol); dt0 = time.perf_counter() - t
-    # the second solve is the one reported: the first carries MKL's one-time initialisation (threads, code paths)
-    t = time.perf_counter(); lam, vec, it = ref.dense_solve(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
-    out.update(kind="reference", iters=int(it), seconds=dt, seconds_first_call=dt0, cores=threads, evals=[float(x) for x in lam])
-    # the primitive behind the reference's residual loop (lapack_matrix_vector -> DGEMV, src/lapack_wrapper.f90:330-364,
-    # called m times per iteration at src/davidson.f90:163-170): one sweep of A through MKL, all threads
-    try:
-        mkl = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so")
-        n = int(A.shape[0])
+    mkl = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so")
+    threads = int(mkl.mkl_get_max_threads())
+    out.update(kind="reference", cores=threads)
+    dp = ctypes.POINTER(ctypes.c_double)
+    for n in n_list:
+        # The matrix is produced INSIDE this process by the reference-side driver under OpenMP (oracle/ref_driver.f90:
+        # ref_generate - the product's counter-based generator restated there), so every page is first touched by the thread
+        # that owns those columns: the pages are spread over the NUMA nodes of the host, as a parallel producer would leave them
+        t = time.perf_counter(); A = ref.generate(n, sparsity, 1); tg = time.perf_counter() - t
+        run = dict(n=n, generate_seconds=round(tg, 2))
+        dt0 = None
+        if n == n_list[0]:
+            # the second solve is the one reported: the first carries MKL's one-time initialisation (threads, code paths)
+            t = time.perf_counter(); lam, vec, it = ref.dense_solve(A, lowest, "DPR", 1000, tol); dt0 = time.perf_counter() - t
+        t = time.perf_counter(); lam, vec, it = ref.dense_solve(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
+        if dt0 is None:
+            dt0 = dt
+        run.update(iters=int(it), seconds=dt, seconds_first_call=dt0, evals=[float(x) for x in lam])
+        # the primitive behind the reference's residual loop (lapack_matrix_vector -> DGEMV, src/lapack_wrapper.f90:330-364,
+        # called m times per iteration at src/davidson.f90:163-170): one sweep of A through MKL, all threads
         x = np.ones(n); y = np.zeros(n)
-        dp = ctypes.POINTER(ctypes.c_double)
         def sweep():
             mkl.cblas_dgemv(102, 111, n, n, ctypes.c_double(1.0), A.ctypes.data_as(dp), n, x.ctypes.data_as(dp), 1, ctypes.c_double(0.0),
                             y.ctypes.data_as(dp), 1)
@@ -115,27 +135,30 @@ if ref.available():
         t = time.perf_counter()
         for _ in range(5):
             sweep()
-        out["dgemv_sweep_GBps"] = 8.0 * n * n * 5 / (time.perf_counter() - t) / 1e9
-    except Exception as exc:
-        out["dgemv_sweep_error"] = repr(exc)[:200]
+        run["dgemv_sweep_GBps"] = 8.0 * n * n * 5 / (time.perf_counter() - t) / 1e9
+        out["runs"].append(run)
+        print("CPU_BASELINE_PROGRESS", n, round(dt, 2), flush=True)
+        del A
 else:
+    n = n_list[0]
+    A = O.generate_diagonal_dominant(n, sparsity, seed=1)
     t = time.perf_counter(); lam, vec, it = O.generalized_eigensolver_dense(A, lowest, "DPR", 1000, tol); dt = time.perf_counter() - t
-    out.update(kind="port", iters=int(it), seconds=dt, cores=os.cpu_count(), evals=[float(x) for x in lam])
+    out.update(kind="port", cores=os.cpu_count())
+    out["runs"].append(dict(n=n, iters=int(it), seconds=dt, evals=[float(x) for x in lam]))
 print("CPU_BASELINE " + json.dumps(out))
 """
 
 
-def cpu_baseline(path, lowest, tol):
-    """The reference's own CPU+LAPACK path (oracle/_ref = the reference compiled with flang + MKL) on a
-    generate_diagonal_dominant input, timed in a child process that never touches the GPU, never imports
-    torch (its libgomp breaks threaded MKL) and never loads the product libraries (they pin MKL to its
-    sequential layer).  The input was written by the host-side Fortran generator of the product
-    (bit-identical to the device generator) to the scratch file `path`."""
+def cpu_baseline(n_list, lowest, tol, sparsity):
+    """The reference's own CPU+LAPACK path (oracle/_ref = the reference compiled with flang + MKL) on generate_diagonal_dominant
+    inputs, timed in a child process that never touches the GPU, never imports torch (its libgomp breaks threaded MKL) and never
+    loads the product libraries (they pin MKL to its sequential layer).  The matrix is generated inside that child, in parallel
+    (first touch by the threads that later read it), bit-identical to the device generator."""
     try:
-        code = CPU_CHILD.format(root=ROOT, lowest=lowest, tol=tol, path=path)
+        code = CPU_CHILD.format(root=ROOT, lowest=lowest, tol=tol, sparsity=sparsity, n_list=list(n_list))
         env = dict(os.environ)
         env["HIP_VISIBLE_DEVICES"] = ""
-        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1200, env=env)
         for line in res.stdout.splitlines():
             if line.startswith("CPU_BASELINE "):
                 return json.loads(line[len("CPU_BASELINE "):])
@@ -150,7 +173,9 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
     file names (profiles/summarize.py).  `kernel` = name prefix; launches of one kernel are grouped by grid size
     (column groups per launch).  rank_by_grid = i: the i-th largest grid; None: the mean over the grid sizes (a solve
     launches each of them once: 32 and 64 columns).  None when no summary matches the workload."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_n{n}_{storage}.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_traffic_n{n}_{storage}.json")))
+    path = found[-1] if found else os.path.join(ROOT, "profiles", f"r04_pmc_traffic_n{n}_{storage}.json")
     try:
         with open(path) as f:
             doc = json.load(f)
@@ -172,6 +197,12 @@ def self_launch(args):
     let rank 0's JSON line through and return the child's exit code.  This (parent) process never imports torch and never
     touches the GPU - a process that has initialised the GPU must not be replaced by another program, and it is not."""
     import socket
+    preload = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD"))
+    if "rocprof" in preload.lower() or any(k.startswith("ROCPROF") for k in os.environ):
+        raise SystemExit("bench.py --gpus N will not start its own launcher under a profiler: the profiler's preloaded library has "
+                         "already initialised the GPU in this process, and launching torch.distributed.run from here is the "
+                         "launcher hop that is not allowed on this pool.  Profile one rank's program directly: "
+                         "rocprofv3 ... -- python3 bench.py --gpus 1 ..., or put the per-rank program after `--` under your own launcher.")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -327,6 +358,8 @@ def main():
     hbm_in_solve = st.apply_bytes / (st.apply_ms * 1e-3) / 1e9 if st.apply_ms > 0 else 0.0
     mfma_bound = cols_per_launch > 16
     tr_solve = pmc_traffic(n, storage, "matvec_symw_kernel<2" if storage == "symmetric" else "matvec_dense_kernel", None) if world == 1 else (None, None)
+    if tr_solve[0] is None and world == 1 and storage == "symmetric":       # small orders: the k <= 8 / one-block-row kernels carry the solve
+        tr_solve = pmc_traffic(n, storage, "matvec_sym", None)
     tr_k8 = pmc_traffic(n, storage, "matvec_sym9_kernel<4", 0) if (world == 1 and storage == "symmetric") else (None, None)
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": kernel_name,
                 "achieved": round(tflops, 2) if mfma_bound else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9, 1),
@@ -342,11 +375,12 @@ def main():
                 "in_solve_GBps_end_to_end": round(hbm_in_solve, 1),
                 "note": "per rank, measured over the timed solves.  In-solve launches carry 32 columns (the reference's policy "
                         "corrects every basis vector): 2*N*N*k flops against 8*S bytes is above the fp64 ridge, so this kernel "
-                        "is priced against the fp64 matrix peak; the HBM-bound case (k=8) is roofline_hbm"}
+                        "is priced against the fp64 matrix peak; the HBM-bound case of BASELINE's metric (A*V at N x k = hbm_N x hbm_k, end to end) is in the hbm_* keys"}
 
     # north-star microbenchmark: A*V at k = 8 (16, 32) on the same resident matrix, end to end and kernel only
     apply_k = apply_rooflines(eng, (8, 16, 32), 10 if n >= 100000 else 20)
-    a8 = apply_k["k8"]
+    a8, a16 = apply_k["k8"], apply_k["k16"]
+    tr_k16 = pmc_traffic(n, storage, "matvec_symw_kernel<1", 0) if (world == 1 and storage == "symmetric") else (None, None)
     roofline_hbm = {"bound": "hbm", "kernel": kernel_name, "N": n, "k": 8,
                     "achieved": a8["GBps_end_to_end"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a8["frac_of_8TBps_end_to_end"],
                     "achieved_kernel_only": a8["GBps_kernel_only"], "frac_kernel_only": a8["frac_of_8TBps_kernel_only"],
@@ -356,8 +390,45 @@ def main():
                     "traffic": tr_k8[0], "traffic_source": tr_k8[1],
                     "note": "per rank: bytes = 8*S + 16*N*k, S = N(N+1)/2 / n_gpus (symmetric-tiled) or nloc*N (row slab); end to end = "
                             "pack_xt (+ all-gather) + sweep kernel + fixed-order reduction of the partial sums (+ reduce-scatter); HIP events on the engine's stream"}
+    # ... and INSIDE `roofline` (flat scalar keys: the driver's record keeps the scalars of this object), so that the record alone
+    # lets a reader recompute both the MFMA fraction of the in-solve launches and the HBM fraction of BASELINE's metric (N x k stated)
+    roofline.update({
+        "hbm_N": n, "hbm_k": 8, "hbm_peak_GBps": HBM_PEAK_GBPS,
+        "hbm_algorithmic_bytes": a8["algorithmic_bytes"],
+        "hbm_ms_end_to_end": a8["ms_end_to_end"], "hbm_ms_kernel_only": a8["ms_kernel_only"],
+        "hbm_GBps_end_to_end": a8["GBps_end_to_end"], "hbm_GBps_kernel_only": a8["GBps_kernel_only"],
+        "hbm_frac": a8["frac_of_8TBps_end_to_end"], "hbm_frac_kernel_only": a8["frac_of_8TBps_kernel_only"],
+        "hbm_measured_stream_GBps": stream_gbps or None, "hbm_frac_of_measured_stream": a8["frac_of_measured_stream_end_to_end"],
+        "hbm_traffic": tr_k8[0],
+        "hbm_k16_ms_end_to_end": a16["ms_end_to_end"], "hbm_k16_ms_kernel_only": a16["ms_kernel_only"],
+        "hbm_k16_algorithmic_bytes": a16["algorithmic_bytes"], "hbm_k16_GBps_end_to_end": a16["GBps_end_to_end"],
+        "hbm_k16_frac": a16["frac_of_8TBps_end_to_end"], "hbm_k16_traffic": tr_k16[0],
+        # what of a solve is not the roofline kernel: the rest of the applies (pack + fixed-order reduction) and the rest of the solve
+        "ms_per_solve": round(elapsed / args.steps * 1e3, 3),
+        "non_kernel_ms_per_solve": round(elapsed / args.steps * 1e3 - st.apply_kernel_ms / args.steps, 3),
+        "apply_non_kernel_ms_per_solve": round((st.apply_ms - st.apply_kernel_ms) / args.steps, 3),
+        "hbm": {k_: roofline_hbm[k_] for k_ in ("N", "k", "ms_end_to_end", "ms_kernel_only", "achieved", "frac", "frac_kernel_only",
+                                                "frac_of_measured_stream", "algorithmic_bytes_per_launch", "traffic")}})
 
     extras = {}
+    if world > 1:
+        # collectives of one solve (separate, untimed solve at timing level 2: an event pair around every collective or group)
+        eng.c.set_timing(2)
+        eng.c.synchronize(); eng.c.reset_stats()
+        eng.solve("DPR", 1000, args.tol, want_vectors=False)
+        eng.c.synchronize()
+        sc = eng.c.stats()
+        eng.c.set_timing(1)
+        extras["comm"] = {
+            "transport": transport, "ranks_reported_by_rccl": int(sc.comm_ranks), "world_size": world, "storage": storage,
+            "collectives_overlapped_with_sweeps": bool(sc.comm_overlap),
+            "collectives_per_solve": int(sc.collectives),
+            "allgather_ms_per_solve": round(sc.allgather_ms, 3), "allgather_MB_per_solve": round(sc.allgather_bytes / 1e6, 2),
+            "reduce_scatter_ms_per_solve": round(sc.reduce_scatter_ms, 3), "reduce_scatter_MB_per_solve": round(sc.reduce_scatter_bytes / 1e6, 2),
+            "allreduce_ms_per_solve": round(sc.allreduce_ms, 3), "allreduce_MB_per_solve": round(sc.allreduce_bytes / 1e6, 3),
+            "sweep_kernel_ms_per_solve": round(sc.apply_kernel_ms, 3), "apply_ms_end_to_end_per_solve": round(sc.apply_ms, 3),
+            "note": "rank 0's view of one solve; payload per rank (all-gather: bytes received, reduce-scatter: bytes contributed); with "
+                    "overlapped collectives their time runs under the sweeps and is not additive to apply_ms"}
     if not args.headline_only:
         # opt-in correction policy (not the reference's, so never part of `value`)
         eng.set_correction_policy("unconverged")
@@ -410,10 +481,13 @@ def main():
                 g.c.synchronize(); g.c.reset_stats()
                 dt_g, it_g, lam_g = timed_solves(g, "GJD", 1, args.tol)
                 sg = g.c.stats()
+                b_resident = g.c.resident_fraction(1)
                 dev_other = sg.gram_ms + sg.panel_ms + sg.comm_ms       # panel_ms includes the sweeps of B
                 extras["configs3_gjd"] = {
-                    "workload": f"N={gn} generalized (A stored {storage}, B hashed unit-diagonal operator generated in the sweep), "
+                    "workload": f"N={gn} generalized (A stored {storage}, B = hashed unit-diagonal operator: the tiles of its longest block rows "
+                                f"resident next to A - {b_resident:.3f} of them - the others generated in the sweep), "
                                 f"GJD, lowest=8, max_dim_sub=80, tol={args.tol}, {world} GPU(s)",
+                    "B_resident_fraction_of_tiles": round(b_resident, 4),
                     "iters": it_g, "seconds": round(dt_g, 4), "iterations_per_s": round(it_g / dt_g, 4),
                     "sweeps_of_A": int(sg.applies), "columns_swept": int(sg.apply_cols),
                     "ms_per_sweep_of_A_end_to_end": round(sg.apply_ms / max(sg.applies, 1), 3),
@@ -434,11 +508,16 @@ def main():
                                  "GBps_end_to_end": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9, 1) if sg.apply_ms > 0 else None,
                                  "frac_of_8TBps": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sg.apply_ms > 0 else None,
                                  "TFLOPs_kernel_only": round(sg.apply_flops / (sg.apply_kernel_ms * 1e-3) / 1e12, 2) if sg.apply_kernel_ms > 0 else None},
-                    "B_sweeps": {"bound": "valu-int + mfma on one issue port (generator)", "sixteen_column_groups": groups, "ms_per_group_upper_bound": round(ms_b_group, 2),
+                    "B_sweeps": {"bound": "resident block rows: hbm / mfma like A; generated block rows: valu-int + mfma on one issue port", "resident_fraction_of_tiles": round(b_resident, 4),
+                                 "sixteen_column_groups": groups, "ms_per_group_upper_bound": round(ms_b_group, 2),
+                                 "ms_per_group_model": round(b_resident * sg.apply_ms / max(groups, 1) + (1.0 - b_resident) * 36.0, 2),
                                  "hash_evaluations_per_s_lower_bound": round(evals_b / (ms_b_group * 1e-3), 0) if ms_b_group > 0 else None,
                                  "peak": round(peak_evals, 0),
                                  "frac_lower_bound": round(evals_b / (ms_b_group * 1e-3) / peak_evals, 4) if ms_b_group > 0 else None,
-                                 "note": "upper bound on the time: all other device phases of the solve (Gram, panel products) are counted into it"},
+                                 "note": "upper bound on the time: all other device phases of the solve (Gram, panel products) are counted into it; the hash-evaluation "
+                                         "figures price the whole group as if generated (peak = the generator's issue bound), so a resident fraction lifts "
+                                         "frac_lower_bound above what generation alone could reach; ms_per_group_model = resident fraction x the measured A rate per "
+                                         "16 columns + generated fraction x 36 ms (the fully generated sweep of round 3)"},
                     "device_floor_seconds": round((sg.apply_ms + dev_other) * 1e-3, 3),
                     "note": "fp64 MFMA and the generator's integer VALU work share the SIMD's issue port (DESIGN section 0, item 3): a fused A + B pass "
                             "could hide generation only under the HBM stalls of the 16-column A sweeps"}
@@ -495,7 +574,6 @@ def main():
                 extras["configs4_free"] = {"error": repr(exc)[:300]}
 
         # ---- configs[1]: N=20000 dense, lowest=8, DPR (full storage; latency-bound at this size) ---------------
-        host_matrix_path = None
         if args.small_n > 0:
             try:
                 sn = args.small_n
@@ -529,7 +607,7 @@ def main():
                                       "iters_per_solve": it_r // 50,
                                       "max_abs_eigenvalue_diff_vs_host_rr": float(np.abs(lam_r - lam_s).max()),
                                       "note": "one-workgroup Jacobi eigensolver on the device instead of host DSYEV/DSYEVD; not the default"}
-                small["apply"] = apply_rooflines(s, (8, 16, 32), 20)
+                small["apply"] = apply_rooflines(s, (8, 16, 32, 64), 20)
                 s.close()
                 # the same problem with only the lower block triangle resident (engine_set_storage(eng, "symmetric")): half the bytes per sweep
                 y = make_engine(sn, 8, None, "symmetric")
@@ -574,46 +652,52 @@ def main():
                         del os.environ["DAVIDSON_STORAGE"]
                 except Exception as exc:       # noqa: BLE001
                     extras["dropin"] = {"error": repr(exc)[:300]}
+            del A_host
             if not args.no_cpu_baseline:
-                host_matrix_path = os.path.join(tempfile.gettempdir(), f"davidson_cpu_baseline_{os.getpid()}.npy")
-                try:
-                    np.save(host_matrix_path, A_host)
-                    del A_host
-                    raw = cpu_baseline(host_matrix_path, 8, args.tol)
-                finally:
-                    if os.path.exists(host_matrix_path):
-                        os.remove(host_matrix_path)
-                if "seconds" in raw:
+                # two orders: the configs[1] problem and a second, larger one that supports the extrapolation to the timed workload
+                cn2 = args.cpu_n2 if args.cpu_n2 > cn else 0
+                raw = cpu_baseline([cn] + ([cn2] if cn2 else []), 8, args.tol, args.sparsity)
+                runs = raw.get("runs") or []
+                if runs and "seconds" in runs[0]:
+                    r0 = runs[0]
                     extras["cpu_baseline"] = {
-                        "value": round(raw["iters"] / raw["seconds"], 4), "unit": "iterations/s", "cores": raw["cores"],
-                        "kind": raw["kind"], "seconds": round(raw["seconds"], 3), "iters": raw["iters"],
-                        "seconds_first_call": round(raw.get("seconds_first_call", raw["seconds"]), 3),
+                        "value": round(r0["iters"] / r0["seconds"], 4), "unit": "iterations/s", "cores": raw["cores"],
+                        "kind": raw["kind"], "seconds": round(r0["seconds"], 3), "iters": r0["iters"],
+                        "seconds_first_call": round(r0.get("seconds_first_call", r0["seconds"]), 3),
+                        "sockets": raw.get("sockets"), "numa_nodes": raw.get("numa_nodes"), "logical_cpus": raw.get("logical_cpus"),
+                        "cpu_model": raw.get("cpu_model"),
                         "sample": f"one full solve (the second of two: the first warms MKL up) at N={cn}, lowest=8, DPR, tol={args.tol} (the configs[1] problem - the timed "
                                   "N=200000 matrix needs 320 GB in the reference's full storage and (m+1) sweeps of it per iteration) "
-                                  "by the reference built with flang+MKL (oracle/_ref), all host threads",
-                        "max_abs_eigenvalue_diff_vs_gpu": float(np.abs(np.array(raw["evals"][:3]) - np.array(extras["small"]["eigenvalues"])).max())
+                                  "by the reference built with flang+MKL (oracle/_ref), all host threads; the matrix is generated in the child under "
+                                  "OpenMP (parallel first touch: its pages are spread over the NUMA nodes)",
+                        "max_abs_eigenvalue_diff_vs_gpu": float(np.abs(np.array(r0["evals"][:3]) - np.array(extras["small"]["eigenvalues"])).max())
                         if cn == args.small_n and "eigenvalues" in extras.get("small", {}) else None}
-                    # sweeps of A the reference makes and what they cost on these host cores; the timed N=200000
-                    # problem stated as (m+1) sweeps per iteration x 8 N^2 bytes / the measured CPU rate
-                    widths = [2 * 8 * 2 ** i for i in range(raw["iters"])]
-                    sweeps = sum(m + 1 for m in widths)
                     cb = extras["cpu_baseline"]
-                    cb["sweeps_of_A_in_the_sample"] = {"basis_widths": widths, "sweeps": sweeps, "GB_swept": round(sweeps * 8.0 * cn * cn / 1e9, 1),
-                                                       "GBps_if_all_time_were_sweeps": round(sweeps * 8.0 * cn * cn / raw["seconds"] / 1e9, 1)}
-                    if "dgemv_sweep_GBps" in raw:
-                        bw = raw["dgemv_sweep_GBps"]
+                    # sweeps of A the reference makes and what they cost on these host cores
+                    per_n = []
+                    for r in runs:
+                        widths = [2 * 8 * 2 ** i for i in range(r["iters"])]
+                        sweeps = sum(m + 1 for m in widths)
+                        per_n.append({"N": r["n"], "iters": r["iters"], "seconds": round(r["seconds"], 3),
+                                      "iterations_per_s": round(r["iters"] / r["seconds"], 4), "basis_widths": widths, "sweeps_of_A": sweeps,
+                                      "GB_swept": round(sweeps * 8.0 * r["n"] * r["n"] / 1e9, 1),
+                                      "GBps_if_all_time_were_sweeps": round(sweeps * 8.0 * r["n"] * r["n"] / r["seconds"] / 1e9, 1),
+                                      "dgemv_sweep_GBps": round(r.get("dgemv_sweep_GBps", 0.0), 1), "generate_seconds": r.get("generate_seconds")})
+                    cb["by_order"] = per_n
+                    if "dgemv_sweep_GBps" in r0:
+                        cb["dgemv_sweep_GBps"] = round(r0["dgemv_sweep_GBps"], 1)
+                        bw = max(r.get("dgemv_sweep_GBps", 0.0) for r in runs)
                         w2 = [2 * lowest * 2 ** i for i in range(total_iters // args.steps)]
                         s2 = sum(m + 1 for m in w2)
                         est = s2 * 8.0 * float(n) * float(n) / (bw * 1e9)
-                        cb["dgemv_sweep_GBps"] = round(bw, 1)
                         cb["extrapolation_to_timed_workload"] = {
                             "N": n, "lowest": lowest, "basis_widths": w2, "sweeps_of_A": s2, "bytes_per_sweep": 8.0 * float(n) * float(n),
+                            "dgemv_rate_used_GBps": round(bw, 1),
                             "seconds_per_solve_at_measured_dgemv_rate": round(est, 1),
                             "iterations_per_s": round((total_iters // args.steps) / est, 5),
-                            "gpu_speedup_vs_extrapolation": round(est / (elapsed / args.steps), 1),
                             "assumption": "the reference's (m+1) sweeps of A per iteration (m DGEMVs for the residues + 1 DGEMM, src/davidson.f90:163-170,223) "
-                                          "at the DGEMV rate measured above on these cores, full storage (320 GB - would have to fit host memory); "
-                                          "QR and the small eigenproblem not counted"}
+                                          "at the best DGEMV rate measured above on these cores, full storage (320 GB - would have to fit host memory); "
+                                          "QR and the small eigenproblem not counted; by_order shows how the measured solves compare with that sweep model"}
                 else:
                     extras["cpu_baseline"] = raw
 

@@ -251,8 +251,6 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->gjd_ws);
   ingest_release(e);
   shm_release(e);
-  hipFree(e->sym_items);
-  hipFree(e->sym_row_begin);
   hipFree(e->sym_slab);
   hipFree(e->rr_H); hipFree(e->rr_S); hipFree(e->rr_Y); hipFree(e->rr_theta); hipFree(e->rr_work); hipFree(e->rr_info);
   hipFree(e->rr_Ypk); hipFree(e->rr_Y2pk); hipFree(e->rr_thpk);
@@ -273,10 +271,9 @@ extern "C" int dav_destroy(dav_handle_t e) {
     delete e->wd;
     e->wd = nullptr;
   }
-  hipFree(e->sym_row_off);
+  sym_set_release(e->sym);
   hipFree(e->sym_wpart);
   hipFree(e->sym_wrecv);
-  for (auto& pl : e->sym_plan) { hipFree(pl.items); hipFree(pl.row_begin); hipFree(pl.zslot_begin); }
   for (int i = 0; i < N_SMALL; ++i) {
     hipFree(e->sm[i].dev);
     if (e->sm[i].host) hipHostFree(e->sm[i].host);
@@ -287,6 +284,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
     if (e->ev[i][1]) hipEventDestroy(e->ev[i][1]);
   }
   for (int w = 0; w < 2; ++w) {
+    sym_resident_release(e->op[w]);
     hipFree(e->op[w].a);
     hipFree(e->op[w].a32);
     hipFree(e->op[w].e_table);

@@ -9,7 +9,7 @@
 bool inner_f32_tiles(E* e, OpDesc& o) {
   if (e->inner_bits != 32 || o.kind != DAV_KIND_DENSE || o.storage != 1 || o.a32_refused) return false;
   if (o.a32_valid) return true;
-  const size_t count = (size_t)std::max<int64_t>(e->sym_ntiles_local, 1) * SYM_TB * SYM_TB;
+  const size_t count = (size_t)std::max<int64_t>(e->sym.ntiles, 1) * SYM_TB * SYM_TB;
   if (!o.a32 && hipMalloc(&o.a32, sizeof(float) * count) != hipSuccess) {
     (void)hipGetLastError();
     o.a32 = nullptr;
@@ -28,22 +28,22 @@ bool inner_f32_tiles(E* e, OpDesc& o) {
 // than 16 only, 0: never (A/B runs)
 bool sym_wide_enabled(const E* e) { return e->tune.sym_wide > 1; }   // ... for 9-16 columns too
 
-void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
-                       int npair, int64_t dstride, int64_t tstride) {
+void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const SymSet& set, const SymPlan* pl, const double* xt, int kk, double* slabD,
+                double* slabT, int npair, int64_t dstride, int64_t tstride) {
   const int wide = e->tune.sym_wide;
   if (o.kind == DAV_KIND_DENSE && !use32 && wide > 0 && ((R == 2 && (kk > 16 || wide > 1)) || (R == 4 && kk > 8 && kk <= 16))) {
     const int nbw = kk > 16 ? 2 : 1;
-    launch_matvec_symw(e->stream, nbw, R == 4, false, o.a, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+    launch_matvec_symw(e->stream, nbw, R == 4, false, o.a, set.row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
                        (npair + nbw - 1) / nbw, e->xt_group_stride, dstride, tstride);
     return;
   }
   // fp32 tiles (mixed-precision inner sweeps, up to 16 columns): the wide kernel's fp32 variant; Tune::sym_wide32 = 0: the two-wave kernel
   if (o.kind == DAV_KIND_DENSE && use32 && wide > 1 && e->tune.sym_wide32 && R == 2 && kk <= 16) {
-    launch_matvec_symw(e->stream, 1, false, true, o.a32, e->sym_row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+    launch_matvec_symw(e->stream, 1, false, true, o.a32, set.row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
                        npair, e->xt_group_stride, dstride, tstride);
     return;
   }
-  launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, e->sym_row_off,
+  launch_matvec_sym9(e->stream, R, o.kind != DAV_KIND_DENSE, use32 ? (const void*)o.a32 : (const void*)o.a, use32, set.row_off,
                      o.kind != DAV_KIND_DENSE ? op_params(o) : OpParams{}, e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk,
                      slabD, slabT, npair, e->xt_group_stride, dstride, tstride, e->tune.sym_mfma4 != 0);
 }
@@ -90,7 +90,7 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
   const int64_t total_rows = (int64_t)e->nranks * e->nslab;
   const bool use32 = false;                            // chunks of 32 columns: the fp64 tiles on the wide kernel (see apply_ptr)
   const int R = 2;                                     // 32-column chunks: the paired two-block-row schedule
-  const E::SymPlan* pl = &e->sym_plan[0];
+  const SymPlan* pl = &e->sym.plan[0];
   const int64_t dstride = (int64_t)pl->nitems * R * 16 * SYM_TB, tstride = pl->zslots * 16 * SYM_TB;
   if (sym_ensure_slabs(e, (size_t)2 * (size_t)(dstride + tstride) + 1) != 0) return 2;   // serial path: it degrades 4 -> 2 -> 1 column groups
   int slot = -1;
@@ -130,12 +130,12 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
     double* slabT = e->sym_slab + (int64_t)npair * dstride;
     if (pl->nitems > 0)
-      sym9_sweep(e, R, o, use32, pl, xt_of(i), kk, e->sym_slab, slabT, npair, dstride, tstride);
+      sym9_sweep(e, R, o, use32, e->sym, pl, xt_of(i), kk, e->sym_slab, slabT, npair, dstride, tstride);
     CHK(timed_end(e, kslot));
     // partial of the whole product of this chunk (the buffer of this parity was last read by the reduce-scatter of chunk
     // i - 2, whose completion the main stream waited for when it finished chunk i - 2 below)
     for (int g = 0; g < npair; ++g)
-      launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, e->sym_row_off, R,
+      launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, e->sym.row_off, R,
                          e->sym_nb, e->nloc, std::min(16, kk - 16 * g), e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->ldp,
                          e->nslab, total_rows);
     HIPCHK(hipEventRecord(e->ov_reduced[p], e->stream));
@@ -158,17 +158,12 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
   return 0;
 }
 
-// inner = true: a sweep inside the GJD correction solve (may run on the fp32 copy, dav_set_inner_precision)
-int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner) {
-  OpDesc& o = e->op[which];
-  if (o.kind == DAV_KIND_NONE) return fail("dav_apply: operator not set");
-  if (o.kind == DAV_KIND_HOST) return fail("dav_apply: host operator - move blocks with dav_panel_get/put");
-  if (o.kind == DAV_KIND_IDENTITY) {
-    launch_copy_columns(e->stream, src, e->ldp, dst, e->ldp, e->nloc_pad, k);
-    return 0;
-  }
-  CHK(need_comm(e));
-  if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS) && o.storage == 1) {
+// The symmetric-tiled sweep of the block rows of `set` of operator view `o` (stored tiles at o.a / generated entries):
+// dst[:, 0:k] (+)= Op * src[:, 0:k].  partial: `set` is not all of the rank's block rows (an operator swept in two parts: its
+// resident and its generated block rows); accumulate: the result is added to dst.
+static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool partial, bool accumulate, const double* src, int k, double* dst,
+                         bool timed, bool inner) {
+  {
     // symmetric-tiled sweep: every off-diagonal tile read (or generated) once, used twice.  16 columns per workgroup; 32
     // columns per launch as paired workgroups that share their tile reads through the memory-side cache.
     // Several ranks: each sweeps the block rows it stores against the all-gathered block and holds a partial of the
@@ -186,7 +181,7 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
       HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
       HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
     }
-    const int64_t* owned = multi ? e->sym_row_off : nullptr;
+    const int64_t* owned = (multi || partial) ? set.row_off : nullptr;
     const int64_t total_rows = (int64_t)e->nranks * e->nslab;
     {
       // Default over a real multi-rank communicator (Tune::sym_overlap = -1; DAV_SYM_OVERLAP=0 / 1 at dav_create forces it off / on,
@@ -194,7 +189,7 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
       // stream under the sweeps.  All collectives of the pipeline are issued on that ONE stream in the same order on every rank,
       // ordered against the engine's stream by events, so no two collectives of the communicator are ever in flight together.
       const bool overlap = e->tune.sym_overlap < 0 ? e->nranks > 1 : e->tune.sym_overlap != 0;
-      if (overlap && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
+      if (overlap && !partial && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
         const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
         if (rc != 2) return rc;                        // 2: its streams / buffers / slabs could not be set up - serial path below
       }
@@ -207,8 +202,8 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
       const bool use32 = inner && kk <= 16 && inner_f32_tiles(e, o);
       int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, kk, o.kind == DAV_KIND_DENSE && !use32);
       if (use32 && R == 1) R = 2;            // the fp32 tiles are read by the super-row kernels only
-      const E::SymPlan* pl = R > 1 ? &e->sym_plan[R == 4 ? 1 : 0] : nullptr;
-      const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)e->sym_nitems * 16 * SYM_TB;
+      const SymPlan* pl = R > 1 ? &set.plan[R == 4 ? 1 : 0] : nullptr;
+      const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)set.nitems * 16 * SYM_TB;
       const int64_t tstride = R > 1 ? pl->zslots * 16 * SYM_TB : (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
       while (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride) + 1) != 0) {
         // not enough memory for this many column groups per launch: fewer from here on (4 -> 2 -> 1)
@@ -217,7 +212,9 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
         else { e->sym_no_pair = true; step = 16; kk = 16; npair = 1; }
       }
       int slot = -1, kslot = -1;
-      const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks : 0.0;
+      // stored bytes of this part: the whole triangle dealt out over the ranks, or - a part of an operator - the set's own tiles
+      const double stored = o.kind == DAV_KIND_DENSE ? (use32 ? 4.0 : 8.0) * (partial ? (double)set.ntiles * SYM_TB * SYM_TB
+                                                                                        : 0.5 * (double)e->n * ((double)e->n + 1.0) / e->nranks) : 0.0;
       double bytes = stored + 16.0 * (double)e->n * kk;
       // end to end: everything that turns the source columns into W - packing, (all-gather,) the sweep, the fixed-order sum(, reduce-scatter)
       if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, bytes, &slot));
@@ -233,15 +230,15 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
       }
       if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
       double* slabT = e->sym_slab + (int64_t)npair * dstride;
-      const int nitems = R > 1 ? pl->nitems : e->sym_nitems;
+      const int nitems = R > 1 ? pl->nitems : set.nitems;
       if (nitems > 0) {                      // a rank can be left without a block row (more ranks than groups of block rows)
         if (R > 1)
-          sym9_sweep(e, R, o, use32, pl, e->xt, kk, e->sym_slab, slabT, npair, dstride, tstride);
+          sym9_sweep(e, R, o, use32, set, pl, e->xt, kk, e->sym_slab, slabT, npair, dstride, tstride);
         else if (o.kind != DAV_KIND_DENSE)
-          launch_matvec_sym_generated(e->stream, op_params(o), e->n, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
+          launch_matvec_sym_generated(e->stream, op_params(o), e->n, set.items, set.nitems, e->xt, kk, e->sym_slab, slabT, npair,
                                       e->xt_group_stride, dstride, tstride);
         else
-          launch_matvec_sym(e->stream, o.a, e->sym_row_off, e->sym_items, e->sym_nitems, e->xt, kk, e->sym_slab, slabT, npair,
+          launch_matvec_sym(e->stream, o.a, set.row_off, set.items, set.nitems, e->xt, kk, e->sym_slab, slabT, npair,
                             e->xt_group_stride, dstride, tstride);
       }
       CHK(timed_end(e, kslot));
@@ -250,10 +247,10 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
         double* out = multi ? e->sym_wpart + (size_t)g * (size_t)total_rows * 16 : dst + (int64_t)(c + 16 * g) * e->ldp;
         if (R > 1)
           launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, owned, R, e->sym_nb,
-                             e->nloc, kg, out, e->ldp, multi ? e->nslab : 0, total_rows);
+                             e->nloc, kg, out, e->ldp, multi ? e->nslab : 0, total_rows, accumulate && !multi);
         else
-          launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, e->sym_row_begin, owned, e->sym_nb, e->nloc, kg,
-                            out, e->ldp, multi ? e->nslab : 0, total_rows);
+          launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, set.row_begin, owned, e->sym_nb, e->nloc, kg,
+                            out, e->ldp, multi ? e->nslab : 0, total_rows, accumulate && !multi);
       }
       if (multi) {
         CollGroup grp(e);
@@ -266,7 +263,7 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
         CHK(grp.end("reduce-scatter of the partial products", e->stream));
         for (int g = 0; g < npair; ++g)
           launch_chunk_to_panel(e->stream, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad,
-                                std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp);
+                                std::min(16, kk - 16 * g), dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp, accumulate);
       }
       CHK(timed_end(e, slot));
       if (which == DAV_OP_A) {
@@ -276,6 +273,33 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     }
     HIPCHK(hipGetLastError());
     return 0;
+  }
+}
+
+// inner = true: a sweep inside the GJD correction solve (may run on the fp32 copy, dav_set_inner_precision)
+int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner) {
+  OpDesc& o = e->op[which];
+  if (o.kind == DAV_KIND_NONE) return fail("dav_apply: operator not set");
+  if (o.kind == DAV_KIND_HOST) return fail("dav_apply: host operator - move blocks with dav_panel_get/put");
+  if (o.kind == DAV_KIND_IDENTITY) {
+    launch_copy_columns(e->stream, src, e->ldp, dst, e->ldp, e->nloc_pad, k);
+    return 0;
+  }
+  CHK(need_comm(e));
+  if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS) && o.storage == 1) {
+    // A generated second operator whose tiles (partly) fit next to everything else is kept resident for its longest block rows
+    // (configs[3]: B = the unit-diagonal generator next to a stored A): those rows run the stored kernels - half the time per
+    // 16 columns of the generated sweep, a quarter in the 32- / 64-column launches - the others are generated as before; the
+    // two parts are summed in fixed order (the generated part adds to the resident part's result).
+    if (o.kind == DAV_KIND_HASHED && which == DAV_OP_B && !o.res_decided) CHK(sym_resident_split(e, which));
+    if (o.res && o.res_tiles > 0) {
+      OpDesc stored = OpDesc();
+      stored.kind = DAV_KIND_DENSE; stored.storage = 1; stored.a = o.res_a; stored.a32_refused = true;
+      CHK(apply_sym_set(e, which, stored, *o.res, true, false, src, k, dst, timed, inner));
+      if (o.gen->ntiles > 0) CHK(apply_sym_set(e, which, o, *o.gen, true, true, src, k, dst, timed, inner));
+      return 0;
+    }
+    return apply_sym_set(e, which, o, e->sym, false, false, src, k, dst, timed, inner);
   }
   for (int c = 0; c < k; c += 64) {
     int kk = std::min(64, k - c);

@@ -72,6 +72,30 @@ struct LocalGroup;
 struct ShmGroup;
 
 // ------------------------------------------------------------------------------------------------
+// super-row schedules (k_matvec_sym9.hip / k_matvec_symw.hip): plan p = 0 / 1 for R = 2 / 4 block rows per workgroup
+struct SymPlan {
+  int R = 0, nitems = 0, nsuper = 0;
+  int64_t zslots = 0;               // transposed-partial slots: one per (super row, tile column below its last block row)
+  int* items = nullptr;             // device: (super row, J0, J1, slab slot) per item, longest first
+  int* row_begin = nullptr;         // device: first item of each super row (nsuper + 1)
+  int* zslot_begin = nullptr;       // device: first slot of each super row (nsuper + 1)
+};
+// Work lists of the symmetric sweep over a SET of block rows: all block rows of this rank (dav_engine::sym), or - for a
+// generated operator that is kept partly resident (OpDesc::res / gen) - the stored and the generated ones.  Several ranks: the
+// lower block triangle is dealt out by groups of 4 block rows (what every schedule's super rows nest in), longest group first to
+// the least loaded rank (sym_group_owners); a set always consists of whole groups.
+struct SymSet {
+  std::vector<int64_t> row_off_h;   // per block row: first tile of the row inside the set's storage, -1 = not in the set
+  int64_t* row_off = nullptr;       // device copy
+  int64_t ntiles = 0;
+  int nitems = 0;                   // one-block-row kernel: runs of tiles
+  int* items = nullptr;             // device: (I, J0, J1, slot) per item
+  int* row_begin = nullptr;         // device: first item of each block row (nb + 1)
+  SymPlan plan[2];
+  bool built = false;
+};
+void sym_set_release(SymSet& s);
+
 struct OpDesc {
   int kind = DAV_KIND_NONE;
   double* a = nullptr;       // dense: nloc_pad x ncols_pad, column-major, lda = nloc_pad
@@ -88,9 +112,11 @@ struct OpDesc {
   // generated symmetric operator (hashed, storage 1) kept PARTLY resident: the tiles of its longest block rows (I >= res_first)
   // are stored like a dense operator's (res_tiles of them at res_a, addressed through res_row_off), the others are generated in the sweep
   double* res_a = nullptr;
-  int64_t* res_row_off = nullptr;   // device, per block row: first tile inside res_a, -1 = generated
   int64_t res_tiles = 0;
   int res_first = 0;                // first resident block row (resident rows form the tail: the longest ones)
+  bool res_decided = false;         // the split was made (at the first sweep of the operator); cleared when the operator is set again
+  SymSet* res = nullptr;            // work lists over the resident block rows (tiles at res_a) ...
+  SymSet* gen = nullptr;            // ... and over the generated ones
 };
 
 struct SmallBuf {            // device small matrix + pinned staging
@@ -147,9 +173,8 @@ struct dav_engine {
   double* norm_partial = nullptr;
   double* gjd_ws = nullptr;       // GJD inner-solver workspace (lazy)
   int storage = 0;                // storage mode for dense operators set after dav_set_storage
-  int sym_nb = 0, sym_nitems = 0; // symmetric-tiled sweep: block rows, work items (runs of tiles)
-  int* sym_items = nullptr;       // device: (I, J0, J1) per item
-  int* sym_row_begin = nullptr;   // device: first item of each block row (nb + 1)
+  int sym_nb = 0;                 // symmetric-tiled sweep: block rows of the whole matrix
+  SymSet sym;                     // work lists over the block rows this rank stores (or generates)
   double* sym_slab = nullptr;     // device: direct slabs (per item) followed by transposed slabs (per tile)
   size_t sym_slab_doubles = 0;    // grown on demand: what the largest launch so far needed (schedule x column groups)
   bool sym_no_pair = false;       // paired 32-column launches did not fit the memory: 16 columns per launch
@@ -158,9 +183,6 @@ struct dav_engine {
   // Several ranks: the lower block triangle is dealt out by groups of 4 block rows (what every schedule's super rows
   // nest in), longest group first to the least loaded rank (sym_group_owners).  row_off[I] = first tile of block row I
   // in this rank's storage, -1 = another rank's.
-  std::vector<int64_t> sym_row_off_h;
-  int64_t* sym_row_off = nullptr; // device copy
-  int64_t sym_ntiles_local = 0;
   double* sym_wpart = nullptr;    // several ranks: this rank's partial of the whole product, [rank][column][row of its slab]
   double* sym_wrecv = nullptr;    // ... and the summed chunk the reduce-scatter hands back (nslab x 32)
   // RCCL only: a second stream for the collectives of the symmetric sweep, so that the all-gather of the NEXT 32 columns
@@ -174,14 +196,6 @@ struct dav_engine {
              ov_scattered[2] = {nullptr, nullptr};
   double* sym_wpart2[2] = {nullptr, nullptr};
   double* sym_wrecv2[2] = {nullptr, nullptr};
-  // super-row schedules (k_matvec_sym9.hip): plan p = 0 / 1 for R = 2 / 4 block rows per workgroup
-  struct SymPlan {
-    int R = 0, nitems = 0, nsuper = 0;
-    int64_t zslots = 0;               // transposed-partial slots: one per (super row, tile column below its last block row)
-    int* items = nullptr;             // device: (super row, J0, J1, slab slot) per item, longest first
-    int* row_begin = nullptr;         // device: first item of each super row (nsuper + 1)
-    int* zslot_begin = nullptr;       // device: first slot of each super row (nsuper + 1)
-  } sym_plan[2];
   // device-resident Rayleigh-Ritz (dav_rr_enable): projected matrices, eigenpairs and their operand images stay in HBM
   bool rr_on = false;
   int64_t rr_ld = 0;
@@ -310,6 +324,9 @@ int refresh_diag_host(E* e, int which);
 int sym_schedule(const E* e, int kk, bool stored_fp64);
 std::vector<int> sym_group_owners(int nb, int nranks);
 int sym_setup(E* e);
+int sym_build_set(E* e, int first_block_row, int end_block_row, SymSet& out);
+int sym_resident_split(E* e, int which);
+void sym_resident_release(OpDesc& o);
 int sym_diag(E* e, OpDesc& o);
 int sym_ensure_slabs(E* e, size_t doubles);
 int alloc_dense(E* e, int which);
@@ -322,7 +339,7 @@ OpParams op_params(const OpDesc& o);
 // ---- engine_apply.hip ------------------------------------------------------------------------------------
 bool inner_f32_tiles(E* e, OpDesc& o);
 bool sym_wide_enabled(const E* e);
-void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const E::SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
+void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const SymPlan* pl, const double* xt, int kk, double* slabD, double* slabT,
                        int npair, int64_t dstride, int64_t tstride);
 int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner);
 int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner = false);

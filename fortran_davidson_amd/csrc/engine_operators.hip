@@ -64,19 +64,34 @@ std::vector<int> sym_group_owners(int nb, int nranks) {
   return owner;
 }
 
+void sym_set_release(SymSet& s) {
+  hipFree(s.row_off); hipFree(s.items); hipFree(s.row_begin);
+  for (SymPlan& pl : s.plan) { hipFree(pl.items); hipFree(pl.row_begin); hipFree(pl.zslot_begin); }
+  s = SymSet();
+}
+
 int sym_setup(E* e) {
   // work lists of the symmetric sweep over the block rows THIS rank stores
-  if (e->sym_items) return 0;
+  if (e->sym.built) return 0;
   const int nb = (int)(e->ncols_pad / SYM_TB);
-  e->sym_row_off_h.assign(nb, -1);
+  e->sym_nb = nb;
+  return sym_build_set(e, 0, nb, e->sym);
+}
+
+// Work lists over the block rows [first, end) that this rank owns (first and end multiples of 4, or end = nb): storage offsets
+// of the set, the runs of the one-block-row kernel, the items of the two super-row schedules.
+int sym_build_set(E* e, int first, int end, SymSet& out) {
+  const int nb = (int)(e->ncols_pad / SYM_TB);
+  sym_set_release(out);
+  out.row_off_h.assign(nb, -1);
   int64_t ntiles = 0;
   const std::vector<int> gowner = sym_group_owners(nb, e->nranks);
-  for (int I = 0; I < nb; ++I)
-    if (gowner[I / 4] == e->rank) { e->sym_row_off_h[I] = ntiles; ntiles += I + 1; }
-  e->sym_ntiles_local = ntiles;
-  HIPCHK(hipMalloc(&e->sym_row_off, sizeof(int64_t) * nb));
-  HIPCHK(hipMemcpy(e->sym_row_off, e->sym_row_off_h.data(), sizeof(int64_t) * nb, hipMemcpyHostToDevice));
-  auto owned = [&](int I) { return e->sym_row_off_h[I] >= 0; };
+  for (int I = first; I < std::min(end, nb); ++I)
+    if (gowner[I / 4] == e->rank) { out.row_off_h[I] = ntiles; ntiles += I + 1; }
+  out.ntiles = ntiles;
+  HIPCHK(hipMalloc(&out.row_off, sizeof(int64_t) * nb));
+  HIPCHK(hipMemcpy(out.row_off, out.row_off_h.data(), sizeof(int64_t) * nb, hipMemcpyHostToDevice));
+  auto owned = [&](int I) { return out.row_off_h[I] >= 0; };
   // One-block-row kernel: runs of <= C consecutive tiles of one block row.
   // Run length: ~12 rounds of the 256 resident workgroups, between 4 tiles (a workgroup costs ~7 us to start
   // and drain) and 32 (the tail of the sweep is at most one run long).  Slab slots stay in block-row order
@@ -100,17 +115,16 @@ int sym_setup(E* e) {
   items.reserve(list.size() * 4 + 4);
   for (const Item& it : list) { items.push_back(it.I); items.push_back(it.J0); items.push_back(it.J1); items.push_back(it.slot); }
   items.resize(std::max<size_t>(items.size(), 4), 0);
-  e->sym_nb = nb;
-  e->sym_nitems = row_begin[nb];
-  HIPCHK(hipMalloc(&e->sym_items, sizeof(int) * items.size()));
-  HIPCHK(hipMalloc(&e->sym_row_begin, sizeof(int) * row_begin.size()));
-  HIPCHK(hipMemcpy(e->sym_items, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(e->sym_row_begin, row_begin.data(), sizeof(int) * row_begin.size(), hipMemcpyHostToDevice));
+  out.nitems = row_begin[nb];
+  HIPCHK(hipMalloc(&out.items, sizeof(int) * items.size()));
+  HIPCHK(hipMalloc(&out.row_begin, sizeof(int) * row_begin.size()));
+  HIPCHK(hipMemcpy(out.items, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(out.row_begin, row_begin.data(), sizeof(int) * row_begin.size(), hipMemcpyHostToDevice));
   // Super-row schedules: items = (super row of R block rows) x (run of C tile columns).  Per tile the schedule
   // writes 1/R of a transposed and 1/C of a direct partial; C is bounded by the tail of the sweep (an item is
   // R*C tiles long) and below by the number of items that keeps 256 workgroups busy.
   for (int p = 0; p < 2; ++p) {
-    E::SymPlan& pl = e->sym_plan[p];
+    SymPlan& pl = out.plan[p];
     pl.R = p == 0 ? 2 : 4;
     pl.nsuper = (nb + pl.R - 1) / pl.R;
     int64_t Cp = std::min<int64_t>(64 / pl.R, std::max<int64_t>(1, (ntiles + 3071) / (3072 * pl.R)));
@@ -141,6 +155,7 @@ int sym_setup(E* e) {
     HIPCHK(hipMemcpy(pl.row_begin, prow.data(), sizeof(int) * prow.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pl.zslot_begin, zbeg.data(), sizeof(int) * zbeg.size(), hipMemcpyHostToDevice));
   }
+  out.built = true;
   return 0;
 }
 
@@ -148,11 +163,11 @@ int sym_setup(E* e) {
 // live where their block rows do: every rank contributes its pieces, one all-reduce of n doubles at set-up
 int sym_diag(E* e, OpDesc& o) {
   if (e->nranks == 1) {
-    launch_diag_sym(e->stream, o.a, e->sym_row_off, e->n, e->nloc_pad, o.diag);
+    launch_diag_sym(e->stream, o.a, e->sym.row_off, e->n, e->nloc_pad, o.diag);
     return 0;
   }
   if (!(e->comm || e->lg || e->shm)) return fail("multi-rank engine used before dav_comm_init");
-  launch_diag_sym(e->stream, o.a, e->sym_row_off, e->n, e->ncols_pad, e->gather_dev);
+  launch_diag_sym(e->stream, o.a, e->sym.row_off, e->n, e->ncols_pad, e->gather_dev);
   CHK(coll_allreduce(e, e->gather_dev, (size_t)e->ncols_pad));
   HIPCHK(hipMemcpyAsync(o.diag, e->gather_dev + e->row0, sizeof(double) * (size_t)e->nslab, hipMemcpyDeviceToDevice, e->stream));
   return 0;
@@ -180,6 +195,8 @@ int sym_ensure_slabs(E* e, size_t doubles) {
 
 int alloc_dense(E* e, int which) {
   OpDesc& o = e->op[which];
+  sym_resident_release(o);
+  o.res_decided = false;
   o.a32_valid = false;       // new contents: the fp32 copy is rebuilt when the next inner sweep asks for it
   o.a32_refused = false;
   if (o.a && o.storage != e->storage) { hipFree(o.a); o.a = nullptr; }
@@ -188,7 +205,7 @@ int alloc_dense(E* e, int which) {
     size_t bytes;
     if (o.storage == 1) {
       CHK(sym_setup(e));
-      bytes = sizeof(double) * (size_t)std::max<int64_t>(e->sym_ntiles_local, 1) * SYM_TB * SYM_TB;
+      bytes = sizeof(double) * (size_t)std::max<int64_t>(e->sym.ntiles, 1) * SYM_TB * SYM_TB;
     } else {
       bytes = sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
     }
@@ -210,6 +227,14 @@ int alloc_dense(E* e, int which) {
 // Operators that are not stored symmetric tiles (row slabs, generated operators) are not affected.
 extern "C" int dav_set_inner_precision(dav_handle_t e, int bits) {
   if (bits != 32 && bits != 64) return fail("dav_set_inner_precision: 32 or 64");
+  if (bits == 32 && e->inner_bits != 32) {
+    // the fp32 copy of A (made at the first inner sweep) needs room: a generated operator that is kept partly resident is split
+    // again at its next sweep, with that copy in the reserve
+    CHK(bind(e));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (OpDesc& o : e->op)
+      if (o.res_decided && !e->op[DAV_OP_A].a32) { sym_resident_release(o); o.res_decided = false; }
+  }
   e->inner_bits = bits;
   return 0;
 }
@@ -246,7 +271,7 @@ int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind 
       const int64_t r0 = (int64_t)J * SYM_TB, nr = e->n - r0;
       const int nc = (int)std::min<int64_t>(SYM_TB, e->n - r0);
       if (nr <= 0) {                                    // block rows / columns wholly in the padding: zero tiles
-        launch_retile_panel(e->stream, stage[J & 1], ldp_stage, 0, 0, J, nb, e->sym_row_off, o.a);
+        launch_retile_panel(e->stream, stage[J & 1], ldp_stage, 0, 0, J, nb, e->sym.row_off, o.a);
         continue;
       }
       if (hipMemcpy2DAsync(stage[J & 1], sizeof(double) * ldp_stage, a + r0 + r0 * lda, sizeof(double) * lda, sizeof(double) * nr,
@@ -255,7 +280,7 @@ int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind 
         rc = fail("dav_set_dense: copy of a block column failed");
         break;
       }
-      launch_retile_panel(e->stream, stage[J & 1], ldp_stage, nr, nc, J, nb, e->sym_row_off, o.a);
+      launch_retile_panel(e->stream, stage[J & 1], ldp_stage, nr, nc, J, nb, e->sym.row_off, o.a);
     }
     hipStreamSynchronize(e->stream);
     hipFree(stage[0]);
@@ -301,7 +326,7 @@ extern "C" int dav_dense_begin(dav_handle_t e, int which) {
   CHK(alloc_dense(e, which));
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_DENSE;
-  size_t bytes = o.storage == 1 ? sizeof(double) * (size_t)e->sym_ntiles_local * SYM_TB * SYM_TB
+  size_t bytes = o.storage == 1 ? sizeof(double) * (size_t)e->sym.ntiles * SYM_TB * SYM_TB
                                 : sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
   HIPCHK(hipMemsetAsync(o.a, 0, bytes, e->stream));
   // ~128 MiB per staging buffer, whole rows, at least 32 of them
@@ -335,7 +360,7 @@ int ingest_commit(E* e, int64_t row0, int64_t nrows) {
   OpDesc& o = e->op[e->ing_which];
   int b = e->ing_flip;
   HIPCHK(hipMemcpyAsync(e->ing_dev[b], e->ing_host[b], sizeof(double) * (size_t)(nrows * e->n), hipMemcpyHostToDevice, e->stream));
-  launch_rows_scatter(e->stream, e->ing_dev[b], e->n, row0, nrows, e->n, o.a, e->nloc_pad, e->row0, e->nloc, o.storage == 1, e->sym_row_off);
+  launch_rows_scatter(e->stream, e->ing_dev[b], e->n, row0, nrows, e->n, o.a, e->nloc_pad, e->row0, e->nloc, o.storage == 1, e->sym.row_off);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ing_done[b], e->stream));
   e->ing_pending[b] = true;
@@ -434,7 +459,7 @@ extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed,
   OpDesc& o = e->op[which];
   o.kind = DAV_KIND_DENSE;
   if (o.storage == 1) {
-    launch_generate_sym_tiles(e->stream, o.a, e->sym_row_off_h.data(), e->sym_nb, e->n, seed, sparsity, use_diag_val, diag_val);
+    launch_generate_sym_tiles(e->stream, o.a, e->sym.row_off_h.data(), e->sym_nb, e->n, seed, sparsity, use_diag_val, diag_val);
     CHK(sym_diag(e, o));
   } else {
     launch_generate_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->row0, e->nloc, e->n, seed, sparsity,
@@ -457,6 +482,9 @@ extern "C" int dav_set_operator_hashed(dav_handle_t e, int which, uint64_t seed,
   if (which < 0 || which > 1) return fail("dav_set_operator_hashed: bad operator id");
   CHK(bind(e));
   OpDesc& o = e->op[which];
+  HIPCHK(hipStreamSynchronize(e->stream));      // sweeps in flight may still read the resident tiles of the previous definition
+  sym_resident_release(o);
+  o.res_decided = false;
   o.kind = DAV_KIND_HASHED; o.seed = seed; o.sparsity = sparsity; o.use_diag = use_diag_val; o.diag_val = diag_val;
   // storage mode "symmetric" (single rank) also applies to the generated operator: every entry of the lower
   // block triangle is produced once and used for both products
@@ -471,6 +499,9 @@ extern "C" int dav_set_operator_harness(dav_handle_t e, int which, const double*
   if (which < 0 || which > 1 || !e_table) return fail("dav_set_operator_harness: bad arguments");
   CHK(bind(e));
   OpDesc& o = e->op[which];
+  HIPCHK(hipStreamSynchronize(e->stream));
+  sym_resident_release(o);
+  o.res_decided = false;
   o.kind = DAV_KIND_HARNESS; o.trig = which == DAV_OP_A ? 0 : 1;
   o.storage = e->storage == 1 ? 1 : 0;      // symmetric mode: each entry generated once
   if (o.storage == 1) CHK(sym_setup(e));
@@ -486,6 +517,9 @@ extern "C" int dav_set_operator_identity(dav_handle_t e, int which) {
   if (which < 0 || which > 1) return fail("dav_set_operator_identity: bad operator id");
   CHK(bind(e));
   OpDesc& o = e->op[which];
+  HIPCHK(hipStreamSynchronize(e->stream));
+  sym_resident_release(o);
+  o.res_decided = false;
   o.kind = DAV_KIND_IDENTITY;
   launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
   CHK(refresh_diag_host(e, which));
@@ -496,6 +530,9 @@ extern "C" int dav_set_operator_host(dav_handle_t e, int which, const double* di
   if (which < 0 || which > 1 || !diag) return fail("dav_set_operator_host: bad arguments");
   CHK(bind(e));
   OpDesc& o = e->op[which];
+  HIPCHK(hipStreamSynchronize(e->stream));
+  sym_resident_release(o);
+  o.res_decided = false;
   o.kind = DAV_KIND_HOST;
   if (e->nloc > 0)
     HIPCHK(hipMemcpyAsync(o.diag, diag + e->row0, sizeof(double) * e->nloc, hipMemcpyHostToDevice, e->stream));
@@ -511,10 +548,77 @@ extern "C" int dav_get_diagonal(dav_handle_t e, int which, double* out) {
   return 0;
 }
 
+// ---- a generated symmetric operator kept (partly) resident ------------------------------------------------------------------
+// configs[3] (N=200000 generalized): A's lower block triangle takes 160.5 GB, B = the same generator with unit diagonal is never
+// stored in full - but ~100 GB of HBM stand empty next to A, and a stored 16-column sweep costs half of a generated one (a
+// quarter in the 32- / 64-column launches of the one-wave-per-SIMD kernel).  At the first sweep of such an operator the engine
+// stores the tiles of as many of its LONGEST block rows (whole groups of four, from the bottom of the triangle up) as fit next to
+// what the sweeps still have to allocate - the partial-sum slabs of the widest launch, the fp32 copy of A when the mixed-precision
+// inner sweeps are on - and keeps generating the others.  Tune::b_resident (DAV_B_RESIDENT at dav_create): 0 = never, 1 = by the free
+// memory (default; nothing below a fifth of the tiles), 2..100 = at most that percentage of the tiles (tests of the mixed path).
+void sym_resident_release(OpDesc& o) {
+  if (o.res) { sym_set_release(*o.res); delete o.res; o.res = nullptr; }
+  if (o.gen) { sym_set_release(*o.gen); delete o.gen; o.gen = nullptr; }
+  hipFree(o.res_a);
+  o.res_a = nullptr;
+  o.res_tiles = 0;
+  o.res_first = 0;
+}
+
+int sym_resident_split(E* e, int which) {
+  OpDesc& o = e->op[which];
+  sym_resident_release(o);
+  o.res_decided = true;
+  if (e->tune.b_resident == 0 || o.kind != DAV_KIND_HASHED || o.storage != 1) return 0;
+  CHK(sym_setup(e));
+  const int nb = e->sym_nb;
+  const double tile_bytes = 8.0 * SYM_TB * SYM_TB;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  // what the sweeps may still allocate: slabs of the widest launch (four column groups of the two-block-row schedule), the fp32 copy
+  const SymPlan& p2 = e->sym.plan[0];
+  const double slabs = 4.0 * 8.0 * 16.0 * SYM_TB * ((double)p2.nitems * 2 + (double)p2.zslots);
+  double reserve = std::max(0.0, slabs - 8.0 * (double)e->sym_slab_doubles) + 0.01 * (double)total_b + 2.0e9;
+  const OpDesc& a = e->op[DAV_OP_A];
+  if (e->inner_bits == 32 && a.kind == DAV_KIND_DENSE && a.storage == 1 && !a.a32) reserve += 4.0 * SYM_TB * SYM_TB * (double)e->sym.ntiles;
+  int64_t fit = (int64_t)std::max(0.0, ((double)free_b - reserve) / tile_bytes);
+  if (e->tune.b_resident > 1) fit = std::min<int64_t>(fit, e->sym.ntiles * std::min(e->tune.b_resident, 100) / 100);
+  // whole groups of four block rows, from the bottom of the triangle up, while the rank's tiles of them fit
+  int first = nb;
+  int64_t tiles = 0;
+  for (int q = (nb + 3) / 4 - 1; q >= 0; --q) {
+    int64_t t = 0;
+    for (int I = 4 * q; I < std::min(nb, 4 * q + 4); ++I)
+      if (e->sym.row_off_h[I] >= 0) t += I + 1;
+    if (tiles + t > fit) break;
+    tiles += t;
+    first = 4 * q;
+  }
+  if (tiles == 0 || (e->tune.b_resident == 1 && tiles * 5 < e->sym.ntiles)) return 0;      // too little to be worth a second pass
+  o.res = new SymSet();
+  o.gen = new SymSet();
+  int rc = sym_build_set(e, first, nb, *o.res);
+  if (rc == 0) rc = sym_build_set(e, 0, first, *o.gen);
+  if (rc == 0 && hipMalloc(&o.res_a, (size_t)(tile_bytes * (double)std::max<int64_t>(o.res->ntiles, 1))) != hipSuccess) {
+    (void)hipGetLastError();
+    o.res_a = nullptr;
+    rc = -1;
+  }
+  if (rc != 0) {                      // no room after all: the operator stays generated
+    sym_resident_release(o);
+    return rc > 0 ? rc : 0;
+  }
+  launch_generate_sym_tiles(e->stream, o.res_a, o.res->row_off_h.data(), nb, e->n, o.seed, o.sparsity, o.use_diag, o.diag_val);
+  o.res_tiles = o.res->ntiles;
+  o.res_first = first;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // fraction of the block rows (by tiles) of operator `which` that a generated symmetric operator keeps resident as stored tiles
 extern "C" int dav_resident_fraction(dav_handle_t e, int which, double* fraction) {
   if (which < 0 || which > 1 || !fraction) return fail("dav_resident_fraction: bad arguments");
   const OpDesc& o = e->op[which];
-  *fraction = (o.res_tiles > 0 && e->sym_ntiles_local > 0) ? (double)o.res_tiles / (double)e->sym_ntiles_local : 0.0;
+  *fraction = (o.res_tiles > 0 && e->sym.ntiles > 0) ? (double)o.res_tiles / (double)e->sym.ntiles : 0.0;
   return 0;
 }

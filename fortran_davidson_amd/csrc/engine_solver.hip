@@ -112,7 +112,7 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
     OpDesc& o = e->op[w];
     int dst = w == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
     if (o.kind == DAV_KIND_DENSE && o.storage == 1 && e->nranks == 1)
-      launch_gather_columns_sym(e->stream, o.a, e->sym_row_off, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
+      launch_gather_columns_sym(e->stream, o.a, e->sym.row_off, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
     else if (o.kind == DAV_KIND_DENSE && o.storage == 0)
       launch_gather_columns(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
     else if (o.kind == DAV_KIND_HOST) {

@@ -308,7 +308,7 @@ void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const i
 __global__ __launch_bounds__(256) void sym_reduce_kernel(const double* __restrict__ slabD, const double* __restrict__ slabT,
                                                          const int* __restrict__ row_item_begin, const int64_t* __restrict__ owned,
                                                          int nb, int ncol16, int64_t nloc, int k, double* __restrict__ dst, int64_t ldd,
-                                                         int64_t chunk_rows, int64_t total_rows) {
+                                                         int64_t chunk_rows, int64_t total_rows, int accumulate) {
   const int J = blockIdx.x, col = blockIdx.y, r = threadIdx.x;
   if (col >= k) return;
   double sum = 0.0;
@@ -325,14 +325,14 @@ __global__ __launch_bounds__(256) void sym_reduce_kernel(const double* __restric
   if (chunk_rows > 0) {
     if (row < total_rows) dst[(row / chunk_rows) * (chunk_rows * k) + (int64_t)col * chunk_rows + row % chunk_rows] = sum;
   } else {
-    dst[(int64_t)col * ldd + row] = row < nloc ? sum : 0.0;
+    dst[(int64_t)col * ldd + row] = row < nloc ? (accumulate ? dst[(int64_t)col * ldd + row] + sum : sum) : 0.0;
   }
 }
 
 void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, const int64_t* owned,
-                       int nb, int64_t nloc, int k, double* dst, int64_t ldd, int64_t chunk_rows, int64_t total_rows) {
+                       int nb, int64_t nloc, int k, double* dst, int64_t ldd, int64_t chunk_rows, int64_t total_rows, bool accumulate) {
   hipLaunchKernelGGL(sym_reduce_kernel, dim3(nb, k), dim3(256), 0, st, slabD, slabT, row_item_begin_dev, owned, nb, 16, nloc, k,
-                     dst, ldd, chunk_rows, total_rows);
+                     dst, ldd, chunk_rows, total_rows, accumulate && chunk_rows == 0 ? 1 : 0);
 }
 
 // ---- storage helpers ---------------------------------------------------------------------------------

@@ -93,16 +93,18 @@ void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double*
 
 // dst[i, c] = i < nloc ? src[c * lds + i] : 0 for i < nrows_pad: the chunk a reduce-scatter delivered (columns of nslab
 // contiguous rows) becomes panel columns with their zero padding
+// (accumulate: added to what dst holds - the second part of an operator that is swept in two parts)
 __global__ __launch_bounds__(256) void chunk_to_panel_kernel(const double* __restrict__ src, int64_t lds, int64_t nloc, int64_t nrows_pad,
-                                                             double* __restrict__ dst, int64_t ldd) {
+                                                             double* __restrict__ dst, int64_t ldd, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
-  if (i < nrows_pad) dst[(int64_t)c * ldd + i] = i < nloc ? src[(int64_t)c * lds + i] : 0.0;
+  if (i < nrows_pad) dst[(int64_t)c * ldd + i] = i < nloc ? (accumulate ? dst[(int64_t)c * ldd + i] : 0.0) + src[(int64_t)c * lds + i] : 0.0;
 }
-void launch_chunk_to_panel(hipStream_t st, const double* src, int64_t lds, int64_t nloc, int64_t nrows_pad, int k, double* dst, int64_t ldd) {
+void launch_chunk_to_panel(hipStream_t st, const double* src, int64_t lds, int64_t nloc, int64_t nrows_pad, int k, double* dst, int64_t ldd,
+                           bool accumulate) {
   if (k <= 0) return;
   hipLaunchKernelGGL(chunk_to_panel_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, src, lds, nloc, nrows_pad,
-                     dst, ldd);
+                     dst, ldd, accumulate ? 1 : 0);
 }
 
 // ---- stream microbenchmark (dav_bench_stream): what the HBM delivers to plain streaming kernels on this box ------------------

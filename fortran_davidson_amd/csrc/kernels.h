@@ -98,10 +98,11 @@ void launch_matvec_sym(hipStream_t st, const double* tiles, const int64_t* row_o
 void launch_matvec_sym_generated(hipStream_t st, OpParams op, int64_t n, const int* items_dev, int nitems, const double* xt, int kcols,
                                  double* slabD, double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride,
                                  int64_t slabT_gstride);
+// accumulate: the sums are ADDED to dst (panel layout only: the second part of an operator that is swept in two parts).
 // chunk_rows = 0: dst = panel columns (ldd), rows >= nloc zeroed.  chunk_rows = nslab (several ranks): dst = this rank's
 // partial product in reduce-scatter layout [rank][column][row of the rank's slab], rows < total_rows
 void launch_sym_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev, const int64_t* owned,
-                       int nb, int64_t nloc, int k, double* dst, int64_t ldd, int64_t chunk_rows, int64_t total_rows);
+                       int nb, int64_t nloc, int k, double* dst, int64_t ldd, int64_t chunk_rows, int64_t total_rows, bool accumulate = false);
 // super-row schedules (k_matvec_sym9.hip): R = 2 or 4 block rows per workgroup, transposed partials summed on chip
 void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool tiles_f32, const int64_t* row_off, OpParams op, int64_t n,
                         int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
@@ -117,7 +118,7 @@ void launch_matvec_symw(hipStream_t st, int nbw, bool tall, bool tiles_f32, cons
 void launch_tiles_to_f32(hipStream_t st, const double* src, float* dst, int64_t count);
 void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,
                         const int* zslot_begin_dev, const int64_t* owned, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd,
-                        int64_t chunk_rows, int64_t total_rows);
+                        int64_t chunk_rows, int64_t total_rows, bool accumulate = false);
 void launch_generate_sym_tiles(hipStream_t st, double* tiles, const int64_t* row_off_host, int nb, int64_t n, uint64_t seed,
                                double sparsity, int use_diag, double diag_val);
 void launch_retile_panel(hipStream_t st, const double* panel, int64_t ldp, int64_t nrows, int ncols, int J, int nb,
@@ -126,7 +127,8 @@ void launch_diag_sym(hipStream_t st, const double* tiles, const int64_t* row_off
 void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows_pad,
                                const int64_t* idx_dev, int k, double* dst, int64_t ldd);
 // dst[i, c] = i < nloc ? src[c * lds + i] : 0 for i < nrows_pad (the received chunk of a reduce-scatter -> panel columns)
-void launch_chunk_to_panel(hipStream_t st, const double* src, int64_t lds, int64_t nloc, int64_t nrows_pad, int k, double* dst, int64_t ldd);
+void launch_chunk_to_panel(hipStream_t st, const double* src, int64_t lds, int64_t nloc, int64_t nrows_pad, int k, double* dst, int64_t ldd,
+                           bool accumulate = false);
 
 // ---- device-side Rayleigh-Ritz (k_smalleig.hip): all eigenpairs of H y = theta y / H y = theta S y, order m <= 128 ------
 size_t small_eig_work_doubles(int m);

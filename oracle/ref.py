@@ -54,6 +54,15 @@ def dense_solve(a, lowest, method="DPR", max_it=1000, tol=1e-8, max_dim=None, b=
     return evals, evecs, iters.value
 
 
+def generate(n, sparsity, seed=1, diag_val=None):
+    """generate_diagonal_dominant of the oracle (davidson_oracle.py, bit-identical) produced under OpenMP into a fresh array:
+    parallel first touch - the input of the CPU baseline (ref_driver.f90: ref_generate)."""
+    a = np.empty((n, n), order="F")
+    lib().ref_generate(C.c_int(n), C.c_double(sparsity), C.c_int(seed), C.c_int(0 if diag_val is None else 1),
+                       C.c_double(0.0 if diag_val is None else diag_val), _p(a))
+    return a
+
+
 def free_solve_harness(n, lowest, max_it=1000, tol=1e-8, max_dim=20):
     """Reference matrix-free solve with its own test operators (tests/test_utils.f90:11-116)."""
     evals = np.zeros(lowest)

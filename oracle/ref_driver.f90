@@ -189,3 +189,43 @@ subroutine ref_lapack_solver(n, arr, brr) bind(C)
   real(c_double), intent(inout) :: arr(n, n), brr(n, 1)
   call lapack_solver(arr, brr)
 end subroutine ref_lapack_solver
+
+
+!> Input for the CPU baseline: OUR counter-based generate_diagonal_dominant (semantics of array_utils.f90:86-113; the splitmix64
+!> stream of oracle/davidson_oracle.py: uniform01 - bit-identical to the device generator) written into a caller-provided,
+!> still untouched n x n array under OpenMP, column blocks per thread: every page is first touched by a thread of the team that
+!> later reads it, so the matrix is spread over the NUMA nodes of the host the way a parallel producer leaves it (a single-threaded
+!> copy would put all 3.2 GB of the N=20000 matrix on one node and halve what MKL's DGEMV gets).  Not reference code.
+subroutine ref_generate(n, sparsity, seed, has_diag, diag_val, a) bind(C)
+  use iso_c_binding
+  use iso_fortran_env, only: int64
+  implicit none
+  integer(c_int), value :: n, seed, has_diag
+  real(c_double), value :: sparsity, diag_val
+  real(c_double), intent(out) :: a(n, n)
+  integer(int64) :: golden, m1, m2, key, z
+  integer :: i, j
+  golden = ior(shiftl(int(z'9E3779B9', int64), 32), int(z'7F4A7C15', int64))
+  m1 = ior(shiftl(int(z'BF58476D', int64), 32), int(z'1CE4E5B9', int64))
+  m2 = ior(shiftl(int(z'94D049BB', int64), 32), int(z'133111EB', int64))
+  !$omp parallel do schedule(static) private(i, key, z)
+  do j = 1, n
+     do i = 1, n
+        if (i == j) then
+           if (has_diag /= 0) then
+              a(i, j) = diag_val
+           else
+              a(i, j) = real(j, c_double)
+           end if
+        else
+           key = shiftl(int(min(i, j) - 1, int64), 32) + int(max(i, j) - 1, int64) + int(seed, int64) * golden
+           z = key + golden
+           z = ieor(z, shiftr(z, 30)) * m1
+           z = ieor(z, shiftr(z, 27)) * m2
+           z = ieor(z, shiftr(z, 31))
+           a(i, j) = real(shiftr(z, 11), c_double) * (1.0_c_double / 9007199254740992.0_c_double) * sparsity
+        end if
+     end do
+  end do
+  !$omp end parallel do
+end subroutine ref_generate

@@ -302,7 +302,7 @@ def test_dense_matrix_from_device_memory(storage):
         assert np.array_equal(e.get_diagonal(OP_A), np.diag(A))
 
 
-@pytest.mark.parametrize("env", [{"DAV_SYM_V8": "0"}, {"DAV_SYM_PAIR": "0"}, {"DAV_SYM_RUN": "1"}, {"DAV_SYM_RUN": "7"},
+@pytest.mark.parametrize("env", [{"DAV_SYM_PAIR": "0"}, {"DAV_SYM_RUN": "1"}, {"DAV_SYM_RUN": "7"},
                                  {"DAV_SYM_R": "2"}, {"DAV_SYM_R": "2", "DAV_SYM_WIDE": "0"}, {"DAV_SYM_R": "2", "DAV_SYM_WIDE": "1"},
                                  {"DAV_SYM_R": "2", "DAV_SYM_WIDE": "2", "DAV_SYM_RUN9": "1"}, {"DAV_SYM_R": "4"}, {"DAV_SYM_R": "4", "DAV_SYM_RUN9": "1"},
                                  {"DAV_SYM_R": "2", "DAV_SYM_RUN9": "3"}, {"DAV_SYM_R": "2", "DAV_SYM_PAIR": "0"},
@@ -311,8 +311,8 @@ def test_symmetric_sweep_alternative_kernels_and_schedules(env):
     """The A/B knobs of the symmetric sweep (one-wave-per-SIMD kernel, unpaired 16-column launches, other run
     lengths, the super-row schedules with 2 / 4 block rows per workgroup that large matrices select by
     themselves - with 2 block rows: the wide one-wave-per-SIMD kernel of k_matvec_symw.hip for more than 8 columns
-    (DAV_SYM_WIDE = 2, default), for more than 16 only (1) or never (0: matvec_sym9_kernel<2>)) are read once per
-    process, so each runs in a child process; same product, bit-reproducible.
+    (DAV_SYM_WIDE = 2, default), for more than 16 only (1) or never (0: matvec_sym9_kernel<2>)) are read when an engine is
+    created; each set runs in a child process; same product, bit-reproducible.
     Orders cover 1..10 block rows: ragged super rows, diagonal super blocks, a single block row."""
     import os
     import subprocess
@@ -380,6 +380,67 @@ def test_hashed_operator_symmetric_generation_equals_the_dense_generator(n, k):
         e.panel_put(PANEL_V, 0, X)
         e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
         assert np.abs(e.panel_get(PANEL_W, 0, k) - A @ X).max() <= 1e-12 * np.abs(A @ X).max()
+
+
+@pytest.mark.parametrize("percent", ["0", "1", "30", "60", "85"])
+@pytest.mark.parametrize("sched", ["0", "2", "4"])
+def test_generated_second_operator_kept_partly_resident(percent, sched, monkeypatch):
+    """configs[3]'s second operator (the generator with unit diagonal, never stored in full) with the tiles of its longest block
+    rows kept resident (DAV_B_RESIDENT = percentage of the tiles at most; 1 = what the free memory allows: everything at these
+    sizes; 0 = nothing): the resident block rows run the stored kernels, the others are generated, the two parts are summed in
+    fixed order - same product as the dense generator's matrix, bit-reproducible, for every schedule and ragged orders."""
+    monkeypatch.setenv("DAV_B_RESIDENT", percent)
+    if sched != "0":
+        monkeypatch.setenv("DAV_SYM_R", sched)
+    for n, k in [(2500, 16), (2500, 40), (1300, 8), (3333, 64), (3333, 5), (700, 24)]:
+        Bm = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=21)
+        X = np.random.default_rng(n + k).standard_normal((n, k))
+        with fd.CEngine(n=n, max_cols=max(k, 16), gev=True) as e:
+            e.set_storage(1)
+            e.set_operator_hashed(OP_B, 21, 1e-2, 1.0)
+            assert np.array_equal(e.get_diagonal(OP_B), np.diag(Bm))
+            e.panel_put(PANEL_V, 0, X)
+            e.apply(OP_B, PANEL_V, 0, k, PANEL_W, 0)
+            W = e.panel_get(PANEL_W, 0, k)
+            ref = Bm @ X
+            frac = e.resident_fraction(OP_B)
+            assert np.abs(W - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (n, k, frac)
+            e.apply(OP_B, PANEL_V, 0, k, PANEL_S, 0)
+            assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
+            if percent == "0":
+                assert frac == 0.0
+            elif percent == "1":
+                assert frac == 1.0
+            else:
+                assert frac <= int(percent) / 100.0 + 1e-12
+                if n >= 2500 and int(percent) >= 60:
+                    assert 0.0 < frac < 1.0                       # a real split: both parts ran
+            # a new definition of the operator drops what was resident
+            e.set_operator_identity(OP_B)
+            assert e.resident_fraction(OP_B) == 0.0
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_partly_resident_operator_over_several_ranks(nranks, monkeypatch):
+    """the same split on every rank of a multi-rank engine (each rank keeps resident the longest of ITS block rows)"""
+    monkeypatch.setenv("DAV_B_RESIDENT", "50")
+    n, k = 3333, 24
+    Bm = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=21)
+    X = np.random.default_rng(3).standard_normal((n, k))
+
+    def work(r, e):
+        e.set_storage(1)
+        e.set_operator_hashed(OP_B, 21, 1e-2, 1.0)
+        e.panel_put(PANEL_V, 0, X)
+        e.apply(OP_B, PANEL_V, 0, k, PANEL_W, 0)
+        return e.panel_get(PANEL_W, 0, k), e.resident_fraction(OP_B)
+
+    out = _run_ranks(nranks, lambda r: fd.CEngine(n=n, max_cols=32, gev=True, rank=r, nranks=nranks), work)
+    ref = Bm @ X
+    for W, frac in out:
+        assert np.abs(W - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.array_equal(W, out[0][0])
+    assert any(0.0 < frac < 1.0 for _, frac in out)
 
 
 @pytest.mark.parametrize("n,k", [(51700, 8), (51700, 16), (51700, 40), (51700, 64), (16700, 16), (16700, 40), (16700, 8)])
