@@ -189,6 +189,7 @@ struct dav_engine {
   // and the reduce-scatter of the PREVIOUS ones run under the sweep of the current ones; buffers alternate by chunk parity
   Watchdog* wd = nullptr;         // watches the RCCL collectives of this engine (dav_comm_init)
   int group_depth = 0;            // inside ncclGroupStart / ncclGroupEnd: the group is marked once, at its end
+  bool group_timed = false;       // a CollGroup times its members as a whole
   long iter_hint = -1;            // outer iteration the driver is in (dav_ranks_agree), for the watchdog's message
   hipStream_t comm_stream = nullptr;
   bool ov_ready = false;          // stream, events and buffers of apply_sym_overlapped all exist
@@ -305,16 +306,22 @@ struct CollGroup {
   explicit CollGroup(E* e_) : e(e_) {}
   // kind 5 / 6: the group is an all-gather / a reduce-scatter of `bytes` payload per rank, timed as a whole on `stream`
   int begin(int kind = 0, double bytes = 0.0, hipStream_t stream = nullptr) {
-    if (kind != 0 && e->comm) { int rc = timed_begin_on(e, kind, bytes, &slot, stream ? stream : e->stream); if (rc != 0) return rc; e->st.collectives += 1; }
+    if (kind != 0) {         // any transport: with a test transport the members run one by one inside this pair
+      int rc = timed_begin_on(e, kind, bytes, &slot, stream ? stream : e->stream);
+      if (rc != 0) return rc;
+      e->st.collectives += 1;
+      e->group_timed = true;
+    }
     int rc = coll_group_begin(e); open = rc == 0; return rc;
   }
   int end(const char* what, hipStream_t stream) {
     open = false;
+    e->group_timed = false;
     int rc = coll_group_end(e, what, stream);
     if (rc != 0) return rc;
     return timed_end_on(e, slot, stream);
   }
-  ~CollGroup() { if (open) coll_group_abort(e); }
+  ~CollGroup() { e->group_timed = false; if (open) coll_group_abort(e); }
 };
 int coll_allgather(E* e, const double* send, double* recv, size_t count);
 int coll_allreduce(E* e, double* buf, size_t count);
