@@ -14,6 +14,26 @@ __device__ __forceinline__ f64x4 mfma_f64(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// "Last workgroup" pattern: every workgroup of a launch writes its partial result to global memory and calls this (all threads,
+// convergent); exactly ONE workgroup - the one that arrives last - gets true and may then read ALL partials and finish the
+// reduction in whatever fixed order it likes (the result does not depend on who arrives last).  Release / acquire at device
+// scope around the ticket: on gfx950 every XCD has its own L2, so the fence before the ticket writes this workgroup's partials
+// back and the fence after it invalidates what the last workgroup's CU and L2 may hold of the others'.  The counter must be 0
+// before the launch; the last workgroup resets it, so one zeroed word serves every later launch on the same stream.
+__device__ __forceinline__ bool dav_last_workgroup(unsigned* counter, unsigned total) {
+  __shared__ unsigned dav_ticket;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) dav_ticket = atomicAdd(counter, 1u);
+  __syncthreads();
+  const bool last = dav_ticket == total - 1;
+  if (last) {
+    __threadfence();
+    if (threadIdx.x == 0) *counter = 0u;
+  }
+  return last;
+}
+
 // splitmix64 counter-based stream shared (bit for bit) with oracle/davidson_oracle.py:uniform01.
 __host__ __device__ __forceinline__ uint64_t dav_splitmix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;

@@ -292,11 +292,15 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     // 16 columns of the generated sweep, a quarter in the 32- / 64-column launches - the others are generated as before; the
     // two parts are summed in fixed order (the generated part adds to the resident part's result).
     if (o.kind == DAV_KIND_HASHED && which == DAV_OP_B && !o.res_decided) CHK(sym_resident_split(e, which));
-    if (o.res && o.res_tiles > 0) {
-      OpDesc stored = OpDesc();
-      stored.kind = DAV_KIND_DENSE; stored.storage = 1; stored.a = o.res_a; stored.a32_refused = true;
-      CHK(apply_sym_set(e, which, stored, *o.res, true, false, src, k, dst, timed, inner));
-      if (o.gen->ntiles > 0) CHK(apply_sym_set(e, which, o, *o.gen, true, true, src, k, dst, timed, inner));
+    if (o.res) {
+      bool accumulate = false;
+      if (o.pass_res) {
+        OpDesc stored = OpDesc();
+        stored.kind = DAV_KIND_DENSE; stored.storage = 1; stored.a = o.res_a; stored.a32_refused = true;
+        CHK(apply_sym_set(e, which, stored, *o.res, true, false, src, k, dst, timed, inner));
+        accumulate = true;
+      }
+      if (o.pass_gen) CHK(apply_sym_set(e, which, o, *o.gen, true, accumulate, src, k, dst, timed, inner));
       return 0;
     }
     return apply_sym_set(e, which, o, e->sym, false, false, src, k, dst, timed, inner);

@@ -115,6 +115,7 @@ struct OpDesc {
   int64_t res_tiles = 0;
   int res_first = 0;                // first resident block row (resident rows form the tail: the longest ones)
   bool res_decided = false;         // the split was made (at the first sweep of the operator); cleared when the operator is set again
+  bool pass_res = false, pass_gen = false;   // the passes every rank makes (agreed on across the ranks when the split was made)
   SymSet* res = nullptr;            // work lists over the resident block rows (tiles at res_a) ...
   SymSet* gen = nullptr;            // ... and over the generated ones
 };
@@ -171,6 +172,7 @@ struct dav_engine {
   double* gather_dev = nullptr;   // nranks*nslab staging for panel_get / diagonal gather
   int64_t* idx_dev = nullptr;
   double* norm_partial = nullptr;
+  unsigned* counters = nullptr;   // zeroed words of the last-workgroup finishes: [0, GRAM_MAX_COUNTERS) Gram tiles, [GRAM_MAX_COUNTERS] the panel norms
   double* gjd_ws = nullptr;       // GJD inner-solver workspace (lazy)
   int storage = 0;                // storage mode for dense operators set after dav_set_storage
   int sym_nb = 0;                 // symmetric-tiled sweep: block rows of the whole matrix

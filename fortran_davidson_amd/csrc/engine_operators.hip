@@ -563,6 +563,7 @@ void sym_resident_release(OpDesc& o) {
   o.res_a = nullptr;
   o.res_tiles = 0;
   o.res_first = 0;
+  o.pass_res = o.pass_gen = false;
 }
 
 int sym_resident_split(E* e, int which) {
@@ -594,7 +595,20 @@ int sym_resident_split(E* e, int which) {
     tiles += t;
     first = 4 * q;
   }
-  if (tiles == 0 || (e->tune.b_resident == 1 && tiles * 5 < e->sym.ntiles)) return 0;      // too little to be worth a second pass
+  if (tiles == 0 || (e->tune.b_resident == 1 && tiles * 5 < e->sym.ntiles)) { tiles = 0; first = nb; }      // too little to be worth a second pass
+  // Several ranks: the sweeps of the parts carry collectives (all-gather of the block, reduce-scatter of the partial products), so
+  // every rank must make the SAME passes whatever its own memory allowed: a pass over the resident block rows if any rank has
+  // some, a pass over the generated ones if any rank has some (a rank without rows in a part sweeps an empty set)
+  double flags[2] = {tiles > 0 ? 1.0 : 0.0, e->sym.ntiles - tiles > 0 ? 1.0 : 0.0};
+  if (has_comm(e)) {
+    HIPCHK(hipMemcpyAsync(e->gram_dev, flags, sizeof(flags), hipMemcpyHostToDevice, e->stream));
+    CHK(coll_allreduce(e, e->gram_dev, 2));
+    HIPCHK(hipMemcpyAsync(flags, e->gram_dev, sizeof(flags), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  if (flags[0] == 0.0) return 0;       // nothing resident anywhere: the operator stays generated (one pass over e->sym)
+  o.pass_res = true;
+  o.pass_gen = flags[1] > 0.0;
   o.res = new SymSet();
   o.gen = new SymSet();
   int rc = sym_build_set(e, first, nb, *o.res);
@@ -602,11 +616,12 @@ int sym_resident_split(E* e, int which) {
   if (rc == 0 && hipMalloc(&o.res_a, (size_t)(tile_bytes * (double)std::max<int64_t>(o.res->ntiles, 1))) != hipSuccess) {
     (void)hipGetLastError();
     o.res_a = nullptr;
-    rc = -1;
+    rc = fail("hipMalloc of the resident tiles of a generated operator failed (" + std::to_string((size_t)(tile_bytes * (double)o.res->ntiles) >> 20) +
+              " MiB): set DAV_B_RESIDENT=0");
   }
-  if (rc != 0) {                      // no room after all: the operator stays generated
+  if (rc != 0) {                       // (the passes were agreed on across the ranks: no way back to the one-pass route from here)
     sym_resident_release(o);
-    return rc > 0 ? rc : 0;
+    return rc;
   }
   launch_generate_sym_tiles(e->stream, o.res_a, o.res->row_off_h.data(), nb, e->n, o.seed, o.sparsity, o.use_diag, o.diag_val);
   o.res_tiles = o.res->ntiles;

@@ -22,7 +22,7 @@ int gram_impl(E* e, const double* P, int p, const double* Q, int q) {
   if (gram_scratch_doubles(p, q, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
-  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, result_target(e));
+  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, result_target(e), e->counters);
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
   CHK(result_fetch(e, (size_t)p * q));
@@ -53,10 +53,10 @@ extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
   launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_W, c0), e->ldp, k, e->nloc_pad, e->scratch,
-              result_target(e));
+              result_target(e), e->counters);
   if (both)
     launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_BV, c0), e->ldp, k, e->nloc_pad,
-                e->scratch, result_target(e) + blk);
+                e->scratch, result_target(e) + blk, e->counters);
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
   if (e->rr_on) {
@@ -183,13 +183,13 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
   r.q = ncorr; r.nloc = e->nloc; r.nrows_pad = e->nloc_pad;
   r.theta = dTheta; r.dA = e->op[DAV_OP_A].diag; r.dB = e->gev ? e->op[DAV_OP_B].diag : nullptr;
   r.nnorm = lowest; r.norm_partial = e->norm_partial;
+  r.norm_out = result_target(e); r.counter = e->counters + GRAM_MAX_COUNTERS;      // the last workgroup sums the partial norms (no norm_finish launch)
   if (method == DAV_METHOD_DPR) {
     r.out = panel_ptr(e, DAV_PANEL_V, m); r.ldo = e->ldp; r.epilogue = 1;
   } else {
     r.out = panel_ptr(e, DAV_PANEL_R, 0); r.ldo = e->ldp; r.epilogue = 2;
   }
   launch_panel_gemm(e->stream, r);
-  launch_norm_finish(e->stream, e->norm_partial, (int)(e->nloc_pad / PG_ROWS), lowest, result_target(e));
   // optionally the Gram block the first orthonormalisation pass needs, [V T]^T T with T = V[:, m:m+ncorr] just
   // written: it rides on the same reduction and the same fetch as the norms (one synchronisation less)
   size_t count = (size_t)lowest;
@@ -199,7 +199,7 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
     if (goff + (size_t)p * ncorr > e->gram_doubles) return fail("gram result exceeds engine capacity");
     if (gram_scratch_doubles(p, ncorr, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
     launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, p, panel_ptr(e, DAV_PANEL_V, m), e->ldp, ncorr, e->nloc_pad,
-                e->scratch, result_target(e) + goff);
+                e->scratch, result_target(e) + goff, e->counters);
     count = goff + (size_t)p * ncorr;
   }
   CHK(timed_end(e, slot));
@@ -281,10 +281,13 @@ extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, i
   PanelGemmArgs a{};
   a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.ldm1 = ld_m;
   a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.ldm2 = ld_cm;
-  a.out = panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
+  // in place where one workgroup covers all kt output columns (k_panel.hip: a wave has read its rows of every input column before
+  // it stores the first output); wider blocks go through the scratch panel
+  const bool in_place = kt <= PG_INPLACE_COLS;
+  a.out = in_place ? panel_ptr(e, DAV_PANEL_V, m) : panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
   a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
   launch_panel_gemm(e->stream, a);
-  launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, m), e->ldp, e->nloc_pad, kt);
+  if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, m), e->ldp, e->nloc_pad, kt);
   CHK(timed_end(e, slot));
   HIPCHK(hipGetLastError());
   return 0;
@@ -317,7 +320,11 @@ extern "C" int dav_panel_transform(dav_handle_t e, int src_panel, int s0, int p,
   a.P1 = panel_ptr(e, src_panel, s0); a.ld1 = e->ldp; a.p1 = p; a.M1 = e->sm[3].dev; a.ldm1 = ld_m;
   a.p2 = 0;
   a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = q; a.ldo = e->ldp;
-  bool overlap = (src_panel == dst_panel);
+  // source and destination in one panel: in place when the column ranges coincide and one workgroup covers all q output columns
+  // (a wave reads its rows of all p input columns before it stores), through the scratch panel otherwise
+  const bool same = (src_panel == dst_panel);
+  const bool in_place = same && s0 == d0 && q <= p && q <= PG_INPLACE_COLS;
+  bool overlap = same && !in_place;
   a.out = overlap ? panel_ptr(e, DAV_PANEL_S, 0) : panel_ptr(e, dst_panel, d0);
   if (overlap && src_panel == DAV_PANEL_S) return fail("dav_panel_transform: scratch panel cannot be transformed in place");
   launch_panel_gemm(e->stream, a);
@@ -338,9 +345,10 @@ int restart_contract(E* e, int m, int keep, const double* Mdev, int64_t ldm) {
     a.P1 = panel_ptr(e, panels[i], 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = Mdev; a.ldm1 = ldm;
     a.p2 = 0;
     a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = keep; a.ldo = e->ldp;
-    a.out = panel_ptr(e, DAV_PANEL_S, 0);
+    const bool in_place = keep <= PG_INPLACE_COLS;      // the kept columns overwrite the leading columns of the panel they are made from
+    a.out = in_place ? panel_ptr(e, panels[i], 0) : panel_ptr(e, DAV_PANEL_S, 0);
     launch_panel_gemm(e->stream, a);
-    launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, panels[i], 0), e->ldp, e->nloc_pad, keep);
+    if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, panels[i], 0), e->ldp, e->nloc_pad, keep);
   }
   CHK(timed_end(e, slot));
   e->m = keep;

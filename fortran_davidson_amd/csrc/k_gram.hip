@@ -7,14 +7,29 @@
 // group read one full 128-byte line per column), and MFMA step s uses element s of both fragments,
 // so A and B operands see the same permutation of the contraction index.  Each wave owns a
 // (16 PT) x (16 QT) tile of C over a 256-row chunk, the four waves of a workgroup are summed through
-// LDS, workgroup partials go to a slab, a second kernel adds the slabs in a fixed order.
+// LDS, workgroup partials go to a slab, and the slabs are added in a fixed order - by a second small kernel, or
+// (few row chunks: the launch-bound sizes) by the workgroup that finishes last (dav_last_workgroup).
+//
+// Round 4: a "step" (16 rows of the wave's PT + QT panel columns = 2 (PT + QT) 16-byte loads per lane, 4 PT QT MFMAs) used to
+// wait for its own loads - a chain of memory latencies, with 2 x 16 PT QT accumulator copies between the register halves around
+// every step (N=200000, 64 x 32: 113 us for 296 MB = 0.33 of 8 TB/s).  The loop now runs through a static ring of U steps -
+// the loads of step s + U are requested behind the MFMAs of step s (2 (PT + QT) U KB in flight per wave) - and the file is
+// compiled with the accumulators in VGPRs (-amdgpu-mfma-vgpr-form, csrc/Makefile): no copies.
 #include "kernels.h"
 
+namespace {
 template <int PT, int QT>
+struct GramStep {
+  f64x2 pf[PT][2], qf[QT][2];
+};
+}  // namespace
+
+template <int PT, int QT, int U>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P, int64_t ldp, int p,
                                                    const double* __restrict__ Q, int64_t ldq, int q,
                                                    int64_t nrows_pad, int ptiles, int qtiles, int nchunks,
-                                                   double* __restrict__ slab, int ppad, int qpad, int rows_per_wg) {
+                                                   double* __restrict__ slab, int ppad, int qpad, int rows_per_wg,
+                                                   double* __restrict__ out, unsigned* __restrict__ counters) {
   __shared__ double red[4][PT * QT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -65,28 +80,56 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
 #pragma unroll
       for (int ch = 0; ch < NC; ++ch) acc[a][b][ch] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  for (int64_t n = n0; n < n1; n += 16) {
-    f64x2 pf[PT][2], qf[QT][2];
+  auto fetch = [&](int64_t n, GramStep<PT, QT>& st) {
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-      pf[t][0] = *reinterpret_cast<const f64x2*>(pp[t] + n);
-      pf[t][1] = *reinterpret_cast<const f64x2*>(pp[t] + n + 2);
+      st.pf[t][0] = *reinterpret_cast<const f64x2*>(pp[t] + n);
+      st.pf[t][1] = *reinterpret_cast<const f64x2*>(pp[t] + n + 2);
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      qf[t][0] = *reinterpret_cast<const f64x2*>(qp[t] + n);
-      qf[t][1] = *reinterpret_cast<const f64x2*>(qp[t] + n + 2);
+      st.qf[t][0] = *reinterpret_cast<const f64x2*>(qp[t] + n);
+      st.qf[t][1] = *reinterpret_cast<const f64x2*>(qp[t] + n + 2);
     }
+  };
+  auto mfmas = [&](const GramStep<PT, QT>& st) {
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int a = 0; a < PT; ++a)
 #pragma unroll
         for (int b = 0; b < QT; ++b) {
-          const double pa = (st & 1) ? pf[a][st >> 1].y : pf[a][st >> 1].x;
-          const double qb = (st & 1) ? qf[b][st >> 1].y : qf[b][st >> 1].x;
-          acc[a][b][st % NC] = mfma_f64(pa, qb, acc[a][b][st % NC]);
+          const double pa = (s & 1) ? st.pf[a][s >> 1].y : st.pf[a][s >> 1].x;
+          const double qb = (s & 1) ? st.qf[b][s >> 1].y : st.qf[b][s >> 1].x;
+          acc[a][b][s % NC] = mfma_f64(pa, qb, acc[a][b][s % NC]);
         }
+  };
+
+  // steps of 16 rows: full rounds of U through the ring (the loads of step s + U behind the MFMAs of step s; in the last round
+  // the last step is requested again - no branch), the rest unpipelined
+  const int64_t nsteps = n1 > n0 ? (n1 - n0) / 16 : 0;
+  const int64_t nring = nsteps / U * U;
+  if (nring > 0) {
+    GramStep<PT, QT> ring[U];
+    int64_t nf = n0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { fetch(nf, ring[u]); nf += 16; }
+    for (int64_t s0 = 0; s0 < nring; s0 += U) {
+      const bool more = s0 + U < nring;
+      const int64_t dn = more ? 16 : 0;
+      if (!more) nf -= 16;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        mfmas(ring[u]);
+        fetch(nf, ring[u]);
+        nf += dn;
+      }
+    }
+  }
+  for (int64_t n = n0 + 16 * nring; n < n1; n += 16) {
+    GramStep<PT, QT> st;
+    fetch(n, st);
+    mfmas(st);
   }
 
   // cross-wave sum through LDS, then one partial tile per workgroup
@@ -102,14 +145,34 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
         red[wave][((a * QT + b) * 4 + r) * 64 + lane] = v;
       }
   __syncthreads();
-  double* out = slab + (int64_t)chunk * ppad * qpad;
+  double* part = slab + (int64_t)chunk * ppad * qpad;
   for (int e = threadIdx.x; e < PT * QT * 256; e += 256) {
     double v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
     int l = e & 63, r = (e >> 6) & 3, ab = e >> 8;
     int a = ab / QT, b = ab % QT;
     int prow = pc0 + 16 * a + (l >> 4) + 4 * r;   // index into P columns  (row of C)
     int qcol = qc0 + 16 * b + (l & 15);           // index into Q columns  (column of C)
-    if (prow < p && qcol < q) out[(int64_t)qcol * ppad + prow] = v;
+    if (prow < p && qcol < q) part[(int64_t)qcol * ppad + prow] = v;
+  }
+  if (counters) {
+    // few row chunks: the workgroup that finishes this output tile last adds the partial tiles of all chunks, chunk by chunk
+    // with eight interleaved partial sums - the order gram_reduce_kernel uses, so both routes give the same bits
+    if (dav_last_workgroup(counters + tile, (unsigned)nchunks)) {
+      const int64_t stride = (int64_t)ppad * qpad;
+      for (int e = threadIdx.x; e < PT * QT * 256; e += 256) {
+        const int prow = pc0 + (e & (16 * PT - 1)), qcol = qc0 + e / (16 * PT);
+        if (prow >= p || qcol >= q) continue;
+        const double* src = slab + (int64_t)qcol * ppad + prow;
+        double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int ch = 0;
+        for (; ch + 8 <= nchunks; ch += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s8[u] += src[(ch + u) * stride];
+        }
+        for (int u = 0; ch < nchunks; ++ch, ++u) s8[u] += src[ch * stride];
+        out[(int64_t)qcol * p + prow] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+      }
+    }
   }
 }
 
@@ -139,31 +202,35 @@ size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
   return (size_t)nchunks * pad16(p) * pad16(q);
 }
 
-template <int PT, int QT>
-static int launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                             int64_t nrows_pad, double* scratch, int ppad, int qpad) {
+template <int PT, int QT, int U>
+static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
+                              int64_t nrows_pad, double* scratch, int ppad, int qpad, double* out_dev, unsigned* counters) {
   const int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
   // rows per workgroup: as tall as possible (fewer partial tiles) while the grid still fills the chip
   int rows_per_wg = GRAM_ROWS;
   while (rows_per_wg > GRAM_MIN_ROWS && (int64_t)ptiles * qtiles * ((nrows_pad + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg /= 2;
   const int nchunks = (int)((nrows_pad + rows_per_wg - 1) / rows_per_wg);
-  hipLaunchKernelGGL((gram_kernel<PT, QT>), dim3(ptiles * qtiles * nchunks), dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, ptiles,
-                     qtiles, nchunks, scratch, ppad, qpad, rows_per_wg);
-  return nchunks;
+  // last-workgroup finish where the sum over the chunks is short and a second launch is what costs (<= GRAM_FUSE_CHUNKS row
+  // chunks, one counter per output tile); the two-kernel route where hundreds of chunks want more than one workgroup per tile
+  const bool fuse = counters && nchunks <= GRAM_FUSE_CHUNKS && ptiles * qtiles <= GRAM_MAX_COUNTERS;
+  hipLaunchKernelGGL((gram_kernel<PT, QT, U>), dim3(ptiles * qtiles * nchunks), dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, ptiles,
+                     qtiles, nchunks, scratch, ppad, qpad, rows_per_wg, out_dev, fuse ? counters : (unsigned*)nullptr);
+  if (!fuse) {
+    const int total = p * q;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, nchunks, p, q, ppad, qpad, out_dev);
+  }
 }
 
+// counters: GRAM_MAX_COUNTERS zeroed device words (nullptr: always the two-kernel route)
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev) {
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters) {
   int ppad = pad16(p), qpad = pad16(q);
-  int nchunks;
   // register tile of a wave: 32 x 32 down to 16 x 16 (a 64 x 64 tile was measured: 430 -> 387 us at
   // p=256, q=128 on N=200000 but 130 -> 142 us at p=128, q=64 - one wave per SIMD; not kept)
   if (p > 16 && q > 16)
-    nchunks = launch_gram_tiles<2, 2>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad);
+    launch_gram_tiles<2, 2, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
   else if (p > 16)
-    nchunks = launch_gram_tiles<2, 1>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad);
+    launch_gram_tiles<2, 1, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
   else
-    nchunks = launch_gram_tiles<1, 1>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad);
-  int total = p * q;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, nchunks, p, q, ppad, qpad, out_dev);
+    launch_gram_tiles<1, 1, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
 }

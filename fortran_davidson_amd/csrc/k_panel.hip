@@ -9,31 +9,89 @@
 //   * the block Gram-Schmidt update T <- T*M + V*(-C*M)    (instead of lapack_qr, :213)
 //   * the collapse restart V <- V*Y(:, 1:2L)               (src/davidson.f90:218, :438)
 //
-// The panels are column-major with the long dimension contiguous, so the MFMA A operand
-// (16 rows x 4 columns, here 32 rows via one 16-byte load per lane) is read straight from HBM/L2 in
-// 256-byte row runs; the small matrix is the B operand, served by L1/L2.  Accumulators: 32 rows x
-// 16*QT columns per wave.  HBM-bound on the panel reads (m/8..m/4 flop/B), executed on
+// The panels are column-major with the long dimension contiguous, so the MFMA A operand (16 rows x 4 columns, here 32 rows via
+// one 16-byte load per lane) is read straight from HBM in 256-byte row runs; the small matrix is the B operand, served by L2.
+// Accumulators: 32 rows x 16*QT columns per wave.  HBM-bound on the panel reads (m/8..m/4 flop/B), executed on
 // v_mfma_f64_16x16x4_f64.
+//
+// Round 4: the k loop is software-pipelined through a static register ring.  A "step" is four panel columns = ONE 16-byte
+// load per lane (1 KB per wave) + QT 8-byte loads of the small matrix + 2 QT MFMAs; the first version issued the loads of a step
+// and waited for them before its MFMAs - a chain of p/4 memory latencies per wave (N=200000, p = 128 -> 64 columns: 154 us for
+// 313 MB = 0.25 of 8 TB/s, neither bound: PMC traffic = algorithmic bytes).  Now the operands of step s + U are requested before
+// the MFMAs of step s (U = 8: 8 KB of panel data in flight per wave, 64-128 KB per CU); the ring is indexed by compile-time
+// constants only (fully unrolled rounds of U steps), so there are no register moves and the compiler counts vmcnt itself.
+// Steps past the end of a term are made of a repeated valid load and a zeroed A operand: straight-line code, no branches.
+// The two rows (2j, 2j + 1) a lane holds of an output column leave as ONE 16-byte store.  In-place use (OUT aliases P1, e.g.
+// the Gram-Schmidt update of the new columns or the restart) is safe whenever one workgroup covers all q columns (q <= 64):
+// a wave has read its 32 rows of every input column before it stores the first output, and no other wave touches those rows.
 #include "kernels.h"
 
-template <int QT>
-__device__ __forceinline__ void pg_term(const double* __restrict__ P, int64_t ld, int p, const double* __restrict__ M,
-                                        int64_t ldm, int64_t i0, int q0, int c, int g, f64x4 (&acc)[2][QT]) {
-  const double* ap = P + i0 + 2 * c + (int64_t)g * ld;
+namespace {
+struct PgStep {      // operands of one step, as loaded
+  f64x2 a;
+  double b[4];
+};
+}  // namespace
+
+// acc += P[rows of the wave, 0:p] * M[0:p, q0 : q0 + 16 QT].  A "step" is four panel columns: one 16-byte load per lane of the
+// panel (lane (c, g): rows 2c, 2c + 1 of column 4 s + g) and QT 8-byte loads of the small matrix (row 4 s + g of column
+// q0 + 16 t + c), then 2 QT MFMAs.  Steps whose four columns all exist run through a ring of U slots (operands of step s + U
+// requested behind the MFMAs of step s; past the last such step the last one is requested again: no branch, nothing masked);
+// a trailing step with fewer than four columns - and what does not fill a round of U - runs unpipelined behind them: a missing
+// column is replaced by the last valid one, which meets rows of the small matrix that are zero (the small matrices are zero
+// padded to multiples of 4 rows and 64 columns by small_upload / rr_pack), so its product vanishes whatever the panel holds.
+template <int QT, int U>
+__device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, const double* __restrict__ M, int64_t ldm, int64_t i0, int q0,
+                                        int c, int g, f64x4 (&acc)[2][QT]) {
+  const double* ap = P + i0 + 2 * c + (int64_t)g * ld;            // this lane's column of step 0
   const double* bp = M + (int64_t)(q0 + c) * ldm + g;
-  for (int kk = 0; kk < p; kk += 4) {
-    f64x2 a = *reinterpret_cast<const f64x2*>(ap + (int64_t)kk * ld);
-    if (kk + g >= p) a = f64x2{0.0, 0.0};     // columns past the panel width may hold anything
+  auto fetch = [&](const double* a, const double* b, PgStep& st) {
+    st.a = *reinterpret_cast<const f64x2*>(a);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) st.b[t] = b[(int64_t)(16 * t) * ldm];
+  };
+  auto mfmas = [&](const PgStep& st) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      double b = bp[(int64_t)(16 * t) * ldm + kk];
-      acc[0][t] = mfma_f64(a.x, b, acc[0][t]);
-      acc[1][t] = mfma_f64(a.y, b, acc[1][t]);
+      acc[0][t] = mfma_f64(st.a.x, st.b[t], acc[0][t]);
+      acc[1][t] = mfma_f64(st.a.y, st.b[t], acc[1][t]);
     }
+  };
+  const int64_t astep = 4 * ld;
+  const int nfull = (p >> 2) / U * U;                             // steps of the pipelined rounds
+  if (nfull > 0) {
+    PgStep ring[U];
+    const double* af = ap;                                        // where the next request goes
+    const double* bf = bp;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      fetch(af, bf, ring[u]);
+      af += astep; bf += 4;
+    }
+    for (int s0 = 0; s0 < nfull; s0 += U) {
+      const bool more = s0 + U < nfull;                           // another round behind this one (uniform)
+      const int64_t da = more ? astep : 0;
+      const int db = more ? 4 : 0;
+      if (!more) { af -= astep; bf -= 4; }                        // last round: the last pipelined step again and again
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // the MFMAs of step s first, then the requests for step s + U: the slot is dead by then (no second register set), and
+        // the loads are issued in the shadow of the last MFMA
+        mfmas(ring[u]);
+        fetch(af, bf, ring[u]);
+        af += da; bf += db;
+      }
+    }
+  }
+  for (int s = nfull; 4 * s < p; ++s) {
+    const int col = min(4 * s + g, p - 1);
+    PgStep st;
+    fetch(P + i0 + 2 * c + (int64_t)col * ld, bp + 4 * s, st);
+    mfmas(st);
   }
 }
 
-template <int QT>
+template <int QT, int U>
 __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
   __shared__ double nrm[4][16 * QT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,8 +105,8 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) acc[h][t] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  pg_term<QT>(A.P1, A.ld1, A.p1, A.M1, A.ldm1, i0, q0, c, g, acc);
-  if (A.p2 > 0) pg_term<QT>(A.P2, A.ld2, A.p2, A.M2, A.ldm2, i0, q0, c, g, acc);
+  pg_term<QT, U>(A.P1, A.ld1, A.p1, A.M1, A.ldm1, i0, q0, c, g, acc);
+  if (A.p2 > 0) pg_term<QT, U>(A.P2, A.ld2, A.p2, A.M2, A.ldm2, i0, q0, c, g, acc);
 
   // acc[h][t][reg] = OUT[i0 + 2*(g + 4*reg) + h][q0 + 16 t + c]
 #pragma unroll
@@ -57,22 +115,24 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
     double ssq = 0.0;
     const double th = (A.epilogue == 1 && col < A.q) ? A.theta[col] : 0.0;   // epilogue 2: store + norms
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int64_t row = i0 + 2 * (g + 4 * reg) + h;
-        double v = acc[h][t][reg];
-        if (row >= A.nloc) v = 0.0;
-        if (A.epilogue >= 1) ssq += v * v;
-        if (A.epilogue == 1) {
-          if (row < A.nloc) {
-            double db = A.dB ? A.dB[row] : 1.0;
-            double den = th * db - A.dA[row];
-            v = (den != 0.0) ? v / den : 0.0;
-          }
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t row = i0 + 2 * (g + 4 * reg);
+      f64x2 v = f64x2{acc[0][t][reg], acc[1][t][reg]};
+      if (row >= A.nloc) v.x = 0.0;
+      if (row + 1 >= A.nloc) v.y = 0.0;
+      if (A.epilogue >= 1) ssq += v.x * v.x + v.y * v.y;
+      if (A.epilogue == 1) {
+        if (row < A.nloc) {
+          const double den = th * (A.dB ? A.dB[row] : 1.0) - A.dA[row];
+          v.x = (den != 0.0) ? v.x / den : 0.0;
         }
-        if (col < A.q) A.out[(int64_t)col * A.ldo + row] = v;
+        if (row + 1 < A.nloc) {
+          const double den = th * (A.dB ? A.dB[row + 1] : 1.0) - A.dA[row + 1];
+          v.y = (den != 0.0) ? v.y / den : 0.0;
+        }
       }
+      if (col < A.q) *reinterpret_cast<f64x2*>(A.out + (int64_t)col * A.ldo + row) = v;
+    }
     if (A.epilogue >= 1 && A.nnorm > 0) {
       ssq += __shfl_xor(ssq, 16);
       ssq += __shfl_xor(ssq, 32);
@@ -87,22 +147,36 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
         A.norm_partial[(int64_t)blockIdx.x * A.nnorm + col] =
             nrm[0][threadIdx.x] + nrm[1][threadIdx.x] + nrm[2][threadIdx.x] + nrm[3][threadIdx.x];
     }
+    if (A.norm_out) {
+      // Last-workgroup finish: the workgroup that arrives last adds the per-workgroup partial sums in a fixed order (one wave per
+      // column, lanes stride over the row blocks, fixed shuffle tree) - the same sum norm_finish_kernel makes, without its launch
+      if (dav_last_workgroup(A.counter, gridDim.x * gridDim.y)) {
+        const int nblocks = gridDim.x;
+        for (int j = wave; j < A.nnorm; j += 4) {
+          double s = 0.0;
+          for (int b = lane; b < nblocks; b += 64) s += A.norm_partial[(int64_t)b * A.nnorm + j];
+          for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+          if (lane == 0) A.norm_out[j] = s;     // squared norm; all-reduce (several ranks) and sqrt happen on the host side
+        }
+      }
+    }
   }
 }
 
 void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a) {
   unsigned gx = (unsigned)(a.nrows_pad / PG_ROWS);
   if (a.q <= 16) {
-    hipLaunchKernelGGL(panel_gemm_kernel<1>, dim3(gx, (a.q + 15) / 16), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((panel_gemm_kernel<1, 8>), dim3(gx, (a.q + 15) / 16), dim3(256), 0, st, a);
   } else if (a.q <= 32) {
-    hipLaunchKernelGGL(panel_gemm_kernel<2>, dim3(gx, (a.q + 31) / 32), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((panel_gemm_kernel<2, 8>), dim3(gx, (a.q + 31) / 32), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL(panel_gemm_kernel<4>, dim3(gx, (a.q + 63) / 64), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((panel_gemm_kernel<4, 8>), dim3(gx, (a.q + 63) / 64), dim3(256), 0, st, a);
   }
 }
 
 // out[j] = sum_b partial[b][j]: one wave per output column, lanes stride over the blocks, fixed
-// shuffle tree -> reproducible.  (A single-thread serial sum cost 20 us at 157 blocks.)
+// shuffle tree -> reproducible.  (A single-thread serial sum cost 20 us at 157 blocks.)  Used when the panel kernel
+// does not finish the norms itself (PanelGemmArgs::norm_out == nullptr).
 __global__ __launch_bounds__(256) void norm_finish_kernel(const double* __restrict__ partial, int nblocks, int nnorm,
                                                           double* __restrict__ out) {
   const int lane = threadIdx.x & 63;

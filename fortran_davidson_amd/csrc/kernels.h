@@ -29,8 +29,12 @@ constexpr int GRAM_ROWS = 1024;   // rows per workgroup at most (4 waves x 256) 
 constexpr int GRAM_MIN_ROWS = 256; // ... and at least (small problems: more, shorter workgroups)
 // out (p x q, column-major ld = p) = P^T Q over nrows_pad rows (multiple of 16; pad rows are zero).
 // scratch must hold gram_scratch_doubles(...) doubles.  Deterministic two-stage reduction.
+// counters: GRAM_MAX_COUNTERS zeroed device words - with at most GRAM_FUSE_CHUNKS row chunks the workgroup that finishes an output
+// tile last sums its partial tiles itself (no second launch); nullptr: always the two-kernel route.  Same bits either way.
+constexpr int GRAM_FUSE_CHUNKS = 128;
+constexpr int GRAM_MAX_COUNTERS = 256;
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev);
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr);
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
 
 // ---- K3/K4/K5: panel x small matrix ---------------------------------------------------------------
@@ -44,8 +48,12 @@ struct PanelGemmArgs {
   int epilogue;
   const double* theta; const double* dA; const double* dB;   // dB == nullptr: B diagonal = 1
   int nnorm; double* norm_partial;          // [gridDim.x][nnorm] partial sums of acc^2 (cols < nnorm)
+  // norm_out != nullptr: the LAST workgroup of the launch sums the partials into norm_out[0:nnorm] (fixed order; replaces the
+  // launch of norm_finish_kernel); counter = a zeroed device word (dav_last_workgroup)
+  double* norm_out; unsigned* counter;
 };
 constexpr int PG_ROWS = 128;
+constexpr int PG_INPLACE_COLS = 64;       // q <= this: one workgroup column (grid.y == 1), so OUT may alias P1 (see k_panel.hip)
 void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a);
 // out[j] = sqrt(sum_b partial[b][j])
 void launch_norm_finish(hipStream_t st, const double* partial, int nblocks, int nnorm, double* out);
