@@ -216,8 +216,8 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   HIPCHK(hipMalloc(&e->gather_dev, sizeof(double) * (size_t)e->ncols_pad));
   HIPCHK(hipMalloc(&e->idx_dev, sizeof(int64_t) * e->cols_alloc));
   HIPCHK(hipMalloc(&e->norm_partial, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc));
-  HIPCHK(hipMalloc(&e->counters, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8)));
-  HIPCHK(hipMemsetAsync(e->counters, 0, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8), e->stream));
+  HIPCHK(hipMalloc(&e->counters, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8 + MV_FUSE_ROWBLOCKS)));
+  HIPCHK(hipMemsetAsync(e->counters, 0, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8 + MV_FUSE_ROWBLOCKS), e->stream));
   e->small_doubles = 3 * (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
   for (int i = 0; i < N_SMALL; ++i) {
     HIPCHK(hipMalloc(&e->sm[i].dev, sizeof(double) * e->small_doubles));

@@ -172,7 +172,7 @@ struct dav_engine {
   double* gather_dev = nullptr;   // nranks*nslab staging for panel_get / diagonal gather
   int64_t* idx_dev = nullptr;
   double* norm_partial = nullptr;
-  unsigned* counters = nullptr;   // zeroed words of the last-workgroup finishes: [0, GRAM_MAX_COUNTERS) Gram tiles, [GRAM_MAX_COUNTERS] the panel norms
+  unsigned* counters = nullptr;   // zeroed words of the last-workgroup finishes: [0, GRAM_MAX_COUNTERS) Gram tiles, [GRAM_MAX_COUNTERS] the panel norms, [GRAM_MAX_COUNTERS + 8, ...) the row blocks of the stored row-slab sweep
   double* gjd_ws = nullptr;       // GJD inner-solver workspace (lazy)
   int storage = 0;                // storage mode for dense operators set after dav_set_storage
   int sym_nb = 0;                 // symmetric-tiled sweep: block rows of the whole matrix

@@ -6,14 +6,20 @@
 // ---- K1: block matvec ---------------------------------------------------------------------------
 // Row tile of one workgroup (4 waves x 64 rows).  Panels and A are padded to a multiple of it.
 constexpr int MV_ROWS = 256;
+constexpr int MV_FUSE_ROWBLOCKS = 512;    // row blocks up to which the stored row-slab sweep finishes its own column-chunk sum
 // Pack k columns of a column-major panel into the transposed MFMA-B layout Xt[group][row][16]
 // (zero padded) for rows [0, nloc_pad) of this rank, written at row offset `row_off`.
 void launch_pack_xt(hipStream_t st, const double* src, int64_t ld, int64_t nloc, int64_t nslab, int k,
                     double* xt, int64_t xt_group_stride, int64_t row_off);
 // slab[s][col][row] = A[rows, chunk s] * X[chunk s, col]; ngroups = ceil(k/16) in {1,2,4}.
+// fin.counters != nullptr (one zeroed word per 256-row block): the last workgroup of every row block also sums the chunks into
+// fin.dst[:, 0:k] (what launch_slab_reduce does otherwise)
+struct MatvecFinish {
+  unsigned* counters; double* dst; int64_t ldd; int64_t nloc; int k;
+};
 void launch_matvec_dense(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad,
                          const double* xt, int64_t xt_group_stride, int ngroups, double* slab,
-                         int nsplit, int jc);
+                         int nsplit, int jc, MatvecFinish fin = MatvecFinish{nullptr, nullptr, 0, 0, 0});
 void launch_matvec_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t n,
                         int64_t nrows_pad, int64_t ncols_pad, const double* xt, int64_t xt_group_stride,
                         int ngroups, double* slab, int nsplit, int jc);
