@@ -169,6 +169,7 @@ Tune tune_from_env() {
   t.mv_target = std::max(0, geti("DAV_MV_TARGET", 0));
   t.mv_nsplit = std::max(0, geti("DAV_MV_NSPLIT", 0));
   t.b_resident = geti("DAV_B_RESIDENT", t.b_resident);
+  t.gram_tile = geti("DAV_GRAM_TILE", t.gram_tile);
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
   return t;
 }

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
     int64_t nf = n0;
 #pragma unroll
     for (int u = 0; u < U; ++u) { fetch(nf, ring[u]); nf += 16; }
+    __builtin_amdgcn_sched_barrier(0);
     for (int64_t s0 = 0; s0 < nring; s0 += U) {
       const bool more = s0 + U < nring;
       const int64_t dn = more ? 16 : 0;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
         mfmas(ring[u]);
         fetch(nf, ring[u]);
         nf += dn;
+        __builtin_amdgcn_sched_barrier(0);      // this order is the schedule (see k_panel.hip): MFMAs of step s, then the requests for step s + U
       }
     }
   }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
   }
   if (counters) {
     // few row chunks: the workgroup that finishes this output tile last adds the partial tiles of all chunks, chunk by chunk
-    // with eight interleaved partial sums - the order gram_reduce_kernel uses, so both routes give the same bits
+    // with eight interleaved partial sums (a fixed order: reproducible run to run; not the order of gram_reduce_kernel)
     if (dav_last_workgroup(counters + tile, (unsigned)nchunks)) {
       const int64_t stride = (int64_t)ppad * qpad;
       for (int e = threadIdx.x; e < PT * QT * 256; e += 256) {
@@ -176,23 +178,35 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
   }
 }
 
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ slab, int nchunks, int p, int q,
-                                                          int ppad, int qpad, double* __restrict__ out) {
-  int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= p * q) return;
-  int row = e % p, col = e / p;
-  // eight interleaved partial sums in a fixed order (reproducible): eight loads in flight per thread instead
-  // of one - the loop is pure load latency (79 chunks at N = 20000 took 20 us as a serial chain)
-  const double* src = slab + (int64_t)col * ppad + row;
-  const int64_t stride = (int64_t)ppad * qpad;
-  double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int ch = 0;
-  for (; ch + 8 <= nchunks; ch += 8) {
+// out[e] = sum over the row chunks of the partial tiles, fixed order: a workgroup of 1024 threads owns 64 output entries; wave w
+// (16 of them) adds the chunks w, w + 16, ... of its entries with four interleaved partial sums, the 16 stripe sums are added in
+// order through LDS.  (One thread per entry over all chunks - the first version - is a chain of nchunks / 8 load latencies:
+// 19 us at 391 chunks, 39 us at 782, more than the Gram kernel itself for narrow blocks.)
+__global__ __launch_bounds__(1024) void gram_reduce_kernel(const double* __restrict__ slab, int nchunks, int p, int q,
+                                                           int ppad, int qpad, double* __restrict__ out) {
+  __shared__ double stripe[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  if (e < p * q) {
+    const int row = e % p, col = e / p;
+    const double* src = slab + (int64_t)col * ppad + row;
+    const int64_t stride = (int64_t)ppad * qpad;
+    int ch = w;
+    for (; ch + 48 < nchunks; ch += 64) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s8[u] += src[(ch + u) * stride];
+      for (int u = 0; u < 4; ++u) s4[u] += src[(int64_t)(ch + 16 * u) * stride];
+    }
+    for (int u = 0; ch < nchunks; ch += 16, ++u) s4[u] += src[(int64_t)ch * stride];
   }
-  for (int u = 0; ch < nchunks; ++ch, ++u) s8[u] += src[ch * stride];
-  out[(int64_t)col * p + row] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  stripe[w][lane] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  __syncthreads();
+  if (w == 0 && e < p * q) {
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += stripe[u][lane];
+    out[(int64_t)(e / p) * p + e % p] = s;
+  }
 }
 
 static inline int pad16(int x) { return (x + 15) / 16 * 16; }
@@ -217,17 +231,20 @@ static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int 
                      qtiles, nchunks, scratch, ppad, qpad, rows_per_wg, out_dev, fuse ? counters : (unsigned*)nullptr);
   if (!fuse) {
     const int total = p * q;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, nchunks, p, q, ppad, qpad, out_dev);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, st, scratch, nchunks, p, q, ppad, qpad, out_dev);
   }
 }
 
-// counters: GRAM_MAX_COUNTERS zeroed device words (nullptr: always the two-kernel route)
+// counters: GRAM_MAX_COUNTERS zeroed device words (nullptr: always the two-kernel route); tile_mode: 0 = by the shape,
+// 1 = never the 64 x 32 register tile (A/B runs)
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters) {
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters, int tile_mode) {
   int ppad = pad16(p), qpad = pad16(q);
-  // register tile of a wave: 32 x 32 down to 16 x 16 (a 64 x 64 tile was measured: 430 -> 387 us at
-  // p=256, q=128 on N=200000 but 130 -> 142 us at p=128, q=64 - one wave per SIMD; not kept)
-  if (p > 16 && q > 16)
+  // register tile of a wave: 64 x 32 for wide blocks (every output tile re-reads its panel columns through L2: 128 x 64 as eight
+  // 32 x 32 tiles moves 819 MB through L2 for 307 MB of panels), 32 x 32 down to 16 x 16 below
+  if (p > 32 && q > 16 && tile_mode != 1)
+    launch_gram_tiles<4, 2, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
+  else if (p > 16 && q > 16)
     launch_gram_tiles<2, 2, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
   else if (p > 16)
     launch_gram_tiles<2, 1, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);

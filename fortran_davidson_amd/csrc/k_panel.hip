@@ -68,6 +68,7 @@ __device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, cons
       fetch(af, bf, ring[u]);
       af += astep; bf += 4;
     }
+    __builtin_amdgcn_sched_barrier(0);
     for (int s0 = 0; s0 < nfull; s0 += U) {
       const bool more = s0 + U < nfull;                           // another round behind this one (uniform)
       const int64_t da = more ? astep : 0;
@@ -80,6 +81,10 @@ __device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, cons
         mfmas(ring[u]);
         fetch(af, bf, ring[u]);
         af += da; bf += db;
+        // the order above IS the schedule: without the barrier the machine scheduler hoists a round's requests to its top and the
+        // round's first MFMAs wait for loads issued just in front of them (seen in the ISA: vmcnt(28) behind 30 loads, vmcnt(0)
+        // at the end of every round) - a latency per round instead of a pipeline
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

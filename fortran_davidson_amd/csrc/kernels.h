@@ -36,11 +36,11 @@ constexpr int GRAM_MIN_ROWS = 256; // ... and at least (small problems: more, sh
 // out (p x q, column-major ld = p) = P^T Q over nrows_pad rows (multiple of 16; pad rows are zero).
 // scratch must hold gram_scratch_doubles(...) doubles.  Deterministic two-stage reduction.
 // counters: GRAM_MAX_COUNTERS zeroed device words - with at most GRAM_FUSE_CHUNKS row chunks the workgroup that finishes an output
-// tile last sums its partial tiles itself (no second launch); nullptr: always the two-kernel route.  Same bits either way.
-constexpr int GRAM_FUSE_CHUNKS = 128;
+// tile last sums its partial tiles itself (no second launch); nullptr: always the two-kernel route.
+constexpr int GRAM_FUSE_CHUNKS = 24;
 constexpr int GRAM_MAX_COUNTERS = 256;
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr);
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr, int tile_mode = 0);
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
 
 // ---- K3/K4/K5: panel x small matrix ---------------------------------------------------------------
