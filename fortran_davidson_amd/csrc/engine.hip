@@ -73,33 +73,13 @@ int timed_end_on(E* e, int slot, hipStream_t stream) {
   return 0;
 }
 
-// upload a p x q host matrix (ld) into small buffer i, zero padded to (pad4(p)) x (pad64(q)); returns ldm
-int small_upload(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* ldm_out) {
-  SmallBuf& b = e->sm[i];
-  int64_t ldm = roundup(std::max(p, 1), 4), qp = roundup(std::max(q, 1), 64);
-  if ((size_t)(ldm * qp) > e->small_doubles) return fail("small matrix exceeds engine capacity");
-  if (b.pending) {
-    HIPCHK(hipEventSynchronize(b.done));
-    b.pending = false;
-  }
-  std::memset(b.host, 0, sizeof(double) * ldm * qp);
-  for (int j = 0; j < q; ++j) std::memcpy(b.host + j * ldm, src + j * ld, sizeof(double) * p);
-  HIPCHK(hipMemcpyAsync(b.dev, b.host, sizeof(double) * ldm * qp, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipEventRecord(b.done, e->stream));
-  b.pending = true;
-  *ldm_out = ldm;
-  return 0;
-}
-
-// several small matrices in ONE staging buffer and ONE host-to-device copy (each H2D command costs
-// ~10 us of launch latency, which is what the small phases are made of)
+// several small matrices in ONE staging buffer and ONE host-to-device copy (each H2D command costs ~10 us of launch latency,
+// which is what the small phases are made of).  Plain: zero padded to pad4(p) x pad64(q), column-major (ldm out); image: the
+// MFMA-B operand image panel_gemm_kernel reads (tiles per step out) - the same number of doubles.
 int small_upload_multi(E* e, int i, SmallMat* mats, int n) {
   SmallBuf& b = e->sm[i];
   size_t total = 0;
-  for (int k = 0; k < n; ++k) {
-    mats[k].ldm = roundup(std::max(mats[k].p, 1), 4);
-    total += (size_t)mats[k].ldm * roundup(std::max(mats[k].q, 1), 64);
-  }
+  for (int k = 0; k < n; ++k) total += (size_t)pg_image_doubles(mats[k].p, mats[k].q);
   if (total > e->small_doubles) return fail("small matrices exceed engine capacity");
   if (b.pending) {
     HIPCHK(hipEventSynchronize(b.done));
@@ -109,13 +89,36 @@ int small_upload_multi(E* e, int i, SmallMat* mats, int n) {
   size_t off = 0;
   for (int k = 0; k < n; ++k) {
     SmallMat& mt = mats[k];
-    for (int j = 0; j < mt.q; ++j) std::memcpy(b.host + off + j * mt.ldm, mt.src + j * mt.ld, sizeof(double) * mt.p);
+    double* dst = b.host + off;
+    if (mt.image) {
+      mt.ldm = pg_image_tiles(mt.q);
+      for (int j = 0; j < mt.q; ++j)
+        for (int r = 0; r < mt.p; ++r) dst[pg_image_index(r, j, mt.ldm)] = mt.src[j * mt.ld + r];
+    } else {
+      mt.ldm = roundup(std::max(mt.p, 1), 4);
+      for (int j = 0; j < mt.q; ++j) std::memcpy(dst + j * mt.ldm, mt.src + j * mt.ld, sizeof(double) * mt.p);
+    }
     mt.dev = b.dev + off;
-    off += (size_t)mt.ldm * roundup(std::max(mt.q, 1), 64);
+    off += (size_t)pg_image_doubles(mt.p, mt.q);
   }
   HIPCHK(hipMemcpyAsync(b.dev, b.host, sizeof(double) * total, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipEventRecord(b.done, e->stream));
   b.pending = true;
+  return 0;
+}
+
+// one matrix into small buffer i, plain (see above); returns ldm
+int small_upload(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* ldm_out) {
+  SmallMat m{src, ld, p, q, nullptr, 0, false};
+  CHK(small_upload_multi(e, i, &m, 1));
+  *ldm_out = m.ldm;
+  return 0;
+}
+// ... as operand image; returns its tiles per step
+int small_upload_image(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* tp_out) {
+  SmallMat m{src, ld, p, q, nullptr, 0, true};
+  CHK(small_upload_multi(e, i, &m, 1));
+  *tp_out = m.ldm;
   return 0;
 }
 
@@ -170,6 +173,7 @@ Tune tune_from_env() {
   t.mv_nsplit = std::max(0, geti("DAV_MV_NSPLIT", 0));
   t.b_resident = geti("DAV_B_RESIDENT", t.b_resident);
   t.gram_tile = geti("DAV_GRAM_TILE", t.gram_tile);
+  t.pg_pin = geti("DAV_PG_PIN", t.pg_pin);
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
   return t;
 }

@@ -145,6 +145,7 @@ struct Tune {
   int sym_mfma4 = 1;      // DAV_SYM_MFMA4: the 4x4x4 MFMA at k <= 8
   int64_t mv_target = 0;  // DAV_MV_TARGET / DAV_MV_NSPLIT: grid of the row-slab kernel (0 = by the shape)
   int64_t mv_nsplit = 0;
+  int pg_pin = 1;         // DAV_PG_PIN: the panel kernel's k loop in the pinned order (1) or the compiler's (0) (A/B runs)
   int gram_tile = 0;      // DAV_GRAM_TILE: 1 = never the 64 x 32 register tile of the Gram kernel (A/B runs)
   int b_resident = 1;     // DAV_B_RESIDENT: keep what fits of a generated second operator resident as stored tiles (dav_set_operator_hashed, storage 1)
   bool gjd_trace = false; // DAV_GJD_TRACE
@@ -204,7 +205,8 @@ struct dav_engine {
   bool rr_on = false;
   int64_t rr_ld = 0;
   double *rr_H = nullptr, *rr_S = nullptr, *rr_Y = nullptr, *rr_theta = nullptr, *rr_work = nullptr, *rr_info = nullptr;
-  double *rr_Ypk = nullptr, *rr_Y2pk = nullptr, *rr_thpk = nullptr;
+  double *rr_Ypk = nullptr, *rr_Y2pk = nullptr, *rr_thpk = nullptr;   // operand images of Y and -Y Theta (kernels.h: pg_image_index), packed theta
+  int64_t rr_tp = 4;              // tiles per step of those images as last packed
   SmallBuf sm[N_SMALL];
   size_t small_doubles = 0;
   ncclComm_t comm = nullptr;
@@ -264,7 +266,8 @@ static inline int64_t roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m
 // ~10 us of launch latency, which is what the small phases are made of)
 struct SmallMat {
   const double* src; int64_t ld; int p, q;   // in
-  double* dev; int64_t ldm;                  // out
+  double* dev; int64_t ldm;                  // out: device address; leading dimension of the padded copy, or - image - tiles per step
+  bool image = false;                        // in: upload as MFMA-B operand image (kernels.h: pg_image_index) for panel_gemm_kernel
 };
 
 // ---- engine.hip ------------------------------------------------------------------------------------------
@@ -277,6 +280,7 @@ int timed_begin_on(E* e, int kind, double bytes, int* slot, hipStream_t stream);
 int timed_end_on(E* e, int slot, hipStream_t stream);
 int small_upload(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* ldm_out);
 int small_upload_multi(E* e, int i, SmallMat* mats, int n);
+int small_upload_image(E* e, int i, const double* src, int64_t ld, int p, int q, int64_t* tp_out);
 double* panel_ptr(E* e, int panel, int col);
 int check_panel(E* e, int panel, int c0, int k);
 int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, int nranks);

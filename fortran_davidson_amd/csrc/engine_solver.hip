@@ -155,12 +155,12 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
   std::vector<double> y2;
   if (dev) {
     dY = e->rr_Ypk; dY2 = e->rr_Y2pk; dTheta = e->rr_thpk;
-    ldm_y = ldm_y2 = roundup(m, 4);
+    ldm_y = ldm_y2 = e->rr_tp;                 // tiles per step of the images launch_rr_pack made
   } else {
     y2.resize((size_t)m * ncorr);
     for (int j = 0; j < ncorr; ++j)
       for (int i = 0; i < m; ++i) y2[(size_t)j * m + i] = -Y[j * ldy + i] * theta[j];
-    SmallMat sm3[3] = {{Y, ldy, m, ncorr, nullptr, 0}, {y2.data(), m, m, ncorr, nullptr, 0}, {theta, ncorr, ncorr, 1, nullptr, 0}};
+    SmallMat sm3[3] = {{Y, ldy, m, ncorr, nullptr, 0, true}, {y2.data(), m, m, ncorr, nullptr, 0, true}, {theta, ncorr, ncorr, 1, nullptr, 0, false}};
     CHK(small_upload_multi(e, 0, sm3, 3));
     dY = sm3[0].dev; dY2 = sm3[1].dev; dTheta = sm3[2].dev;
     ldm_y = sm3[0].ldm; ldm_y2 = sm3[1].ldm;
@@ -171,15 +171,16 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
   // X = V * Y(:, 1:nx)
   int nx = method == DAV_METHOD_GJD ? ncorr : lowest;
   PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = dY; a.ldm1 = ldm_y;
+  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = dY; a.tp1 = ldm_y;
   a.p2 = 0;
   a.out = panel_ptr(e, DAV_PANEL_X, 0); a.ldo = e->ldp; a.q = nx;
   a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
+  a.pin = e->tune.pg_pin;
   launch_panel_gemm(e->stream, a);
   // R = W*Y + Z*(-Y*diag(theta)), norms, (DPR) T
   PanelGemmArgs r{};
-  r.P1 = panel_ptr(e, DAV_PANEL_W, 0); r.ld1 = e->ldp; r.p1 = m; r.M1 = dY; r.ldm1 = ldm_y;
-  r.P2 = panel_ptr(e, e->gev ? DAV_PANEL_BV : DAV_PANEL_V, 0); r.ld2 = e->ldp; r.p2 = m; r.M2 = dY2; r.ldm2 = ldm_y2;
+  r.P1 = panel_ptr(e, DAV_PANEL_W, 0); r.ld1 = e->ldp; r.p1 = m; r.M1 = dY; r.tp1 = ldm_y;
+  r.P2 = panel_ptr(e, e->gev ? DAV_PANEL_BV : DAV_PANEL_V, 0); r.ld2 = e->ldp; r.p2 = m; r.M2 = dY2; r.tp2 = ldm_y2;
   r.q = ncorr; r.nloc = e->nloc; r.nrows_pad = e->nloc_pad;
   r.theta = dTheta; r.dA = e->op[DAV_OP_A].diag; r.dB = e->gev ? e->op[DAV_OP_B].diag : nullptr;
   r.nnorm = lowest; r.norm_partial = e->norm_partial;
@@ -189,6 +190,7 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
   } else {
     r.out = panel_ptr(e, DAV_PANEL_R, 0); r.ldo = e->ldp; r.epilogue = 2;
   }
+  r.pin = e->tune.pg_pin;
   launch_panel_gemm(e->stream, r);
   // optionally the Gram block the first orthonormalisation pass needs, [V T]^T T with T = V[:, m:m+ncorr] just
   // written: it rides on the same reduction and the same fetch as the norms (one synchronisation less)
@@ -273,19 +275,20 @@ extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, i
       if (mlj == 0.0) continue;
       for (int i = 0; i < m; ++i) cm[(size_t)j * m + i] -= C[l * ldc + i] * mlj;
     }
-  SmallMat sm2[2] = {{M, ldm, kt, kt, nullptr, 0}, {cm.data(), std::max(m, 1), m, kt, nullptr, 0}};
+  SmallMat sm2[2] = {{M, ldm, kt, kt, nullptr, 0, true}, {cm.data(), std::max(m, 1), m, kt, nullptr, 0, true}};
   CHK(small_upload_multi(e, 1, sm2, m > 0 ? 2 : 1));
   const int64_t ld_m = sm2[0].ldm, ld_cm = m > 0 ? sm2[1].ldm : 4;
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
   PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.ldm1 = ld_m;
-  a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.ldm2 = ld_cm;
+  a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.tp1 = ld_m;
+  a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.tp2 = ld_cm;
   // in place where one workgroup covers all kt output columns (k_panel.hip: a wave has read its rows of every input column before
   // it stores the first output); wider blocks go through the scratch panel
   const bool in_place = kt <= PG_INPLACE_COLS;
   a.out = in_place ? panel_ptr(e, DAV_PANEL_V, m) : panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
   a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
+  a.pin = e->tune.pg_pin;
   launch_panel_gemm(e->stream, a);
   if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, m), e->ldp, e->nloc_pad, kt);
   CHK(timed_end(e, slot));
@@ -313,11 +316,11 @@ extern "C" int dav_panel_transform(dav_handle_t e, int src_panel, int s0, int p,
   if (p <= 0 || q <= 0 || ldm < p) return fail("dav_panel_transform: bad shape");
   if (q > e->cols_alloc) return fail("dav_panel_transform: too many output columns");
   int64_t ld_m;
-  CHK(small_upload(e, 3, M, ldm, p, q, &ld_m));
+  CHK(small_upload_image(e, 3, M, ldm, p, q, &ld_m));
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
   PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, src_panel, s0); a.ld1 = e->ldp; a.p1 = p; a.M1 = e->sm[3].dev; a.ldm1 = ld_m;
+  a.P1 = panel_ptr(e, src_panel, s0); a.ld1 = e->ldp; a.p1 = p; a.M1 = e->sm[3].dev; a.tp1 = ld_m;
   a.p2 = 0;
   a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = q; a.ldo = e->ldp;
   // source and destination in one panel: in place when the column ranges coincide and one workgroup covers all q output columns
@@ -327,6 +330,7 @@ extern "C" int dav_panel_transform(dav_handle_t e, int src_panel, int s0, int p,
   bool overlap = same && !in_place;
   a.out = overlap ? panel_ptr(e, DAV_PANEL_S, 0) : panel_ptr(e, dst_panel, d0);
   if (overlap && src_panel == DAV_PANEL_S) return fail("dav_panel_transform: scratch panel cannot be transformed in place");
+  a.pin = e->tune.pg_pin;
   launch_panel_gemm(e->stream, a);
   if (overlap) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, dst_panel, d0), e->ldp, e->nloc_pad, q);
   CHK(timed_end(e, slot));
@@ -336,18 +340,20 @@ extern "C" int dav_panel_transform(dav_handle_t e, int src_panel, int s0, int p,
 
 // V, W = A V and B V are contracted with the same keep columns (src/davidson.f90:218 contracts V and then re-applies the
 // operators to the whole basis, :223-226; W Y = A (V Y) holds to rounding, so no sweep of A or B follows a restart)
+// Mdev: operand image of the m x keep transform, ldm = its tiles per step
 int restart_contract(E* e, int m, int keep, const double* Mdev, int64_t ldm) {
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
   const int panels[3] = {DAV_PANEL_V, DAV_PANEL_W, DAV_PANEL_BV};
   for (int i = 0; i < (e->gev ? 3 : 2); ++i) {
     PanelGemmArgs a{};
-    a.P1 = panel_ptr(e, panels[i], 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = Mdev; a.ldm1 = ldm;
+    a.P1 = panel_ptr(e, panels[i], 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = Mdev; a.tp1 = ldm;
     a.p2 = 0;
     a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0; a.q = keep; a.ldo = e->ldp;
     const bool in_place = keep <= PG_INPLACE_COLS;      // the kept columns overwrite the leading columns of the panel they are made from
     a.out = in_place ? panel_ptr(e, panels[i], 0) : panel_ptr(e, DAV_PANEL_S, 0);
-    launch_panel_gemm(e->stream, a);
+    a.pin = e->tune.pg_pin;
+  launch_panel_gemm(e->stream, a);
     if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, panels[i], 0), e->ldp, e->nloc_pad, keep);
   }
   CHK(timed_end(e, slot));
@@ -361,7 +367,7 @@ extern "C" int dav_restart(dav_handle_t e, int m, int keep, const double* Yk, in
   CHK(bind(e));
   if (keep <= 0 || keep > m || m > e->cols_alloc || ldy < m) return fail("dav_restart: bad shape");
   int64_t ld_m;
-  CHK(small_upload(e, 3, Yk, ldy, m, keep, &ld_m));
+  CHK(small_upload_image(e, 3, Yk, ldy, m, keep, &ld_m));
   return restart_contract(e, m, keep, e->sm[3].dev, ld_m);
 }
 
@@ -420,6 +426,7 @@ extern "C" int dav_rr_ritz(dav_handle_t e, int m, int ncorr, int lowest, int met
   const int nq = method == DAV_METHOD_GJD ? ncorr : std::max(ncorr, lowest);
   launch_rr_pack(e->stream, e->rr_Y, e->rr_ld, e->rr_theta, m, nq, (int)roundup(m, 4), (int)roundup(nq, 64), e->rr_Ypk, e->rr_Y2pk, e->rr_thpk,
                  e->rr_info, e->rr_thpk + roundup(ncorr, 64));
+  e->rr_tp = roundup(nq, 64) / 16;
   CHK(timed_end(e, slot));
   double info = 0.0;
   CHK(ritz_impl(e, m, ncorr, lowest, nullptr, 0, nullptr, method, resnorm, C, ldc, G, ldg, theta_out, &info));
@@ -434,7 +441,8 @@ extern "C" int dav_rr_restart(dav_handle_t e, int m, int keep) {
   if (!e->rr_on || keep <= 0 || keep > m || m > e->rr_ld) return fail("dav_rr_restart: bad shape");
   launch_rr_pack(e->stream, e->rr_Y, e->rr_ld, e->rr_theta, m, keep, (int)roundup(m, 4), (int)roundup(keep, 64), e->rr_Ypk, e->rr_Y2pk,
                  e->rr_thpk, e->rr_info, nullptr);
-  return restart_contract(e, m, keep, e->rr_Ypk, roundup(m, 4));
+  e->rr_tp = roundup(keep, 64) / 16;
+  return restart_contract(e, m, keep, e->rr_Ypk, e->rr_tp);
 }
 
 // the device-resident eigenvectors (m x ncols) and Ritz values, for tests and for callers that want them on the host

@@ -10,7 +10,8 @@
 //   * the collapse restart V <- V*Y(:, 1:2L)               (src/davidson.f90:218, :438)
 //
 // The panels are column-major with the long dimension contiguous, so the MFMA A operand (16 rows x 4 columns, here 32 rows via
-// one 16-byte load per lane) is read straight from HBM in 256-byte row runs; the small matrix is the B operand, served by L2.
+// one 16-byte load per lane) is read straight from HBM in 256-byte row runs; the small matrix is the B operand, served by L2
+// from its operand image (kernels.h: one coalesced 512-byte load per step and column tile).
 // Accumulators: 32 rows x 16*QT columns per wave.  HBM-bound on the panel reads (m/8..m/4 flop/B), executed on
 // v_mfma_f64_16x16x4_f64.
 //
@@ -38,17 +39,18 @@ struct PgStep {      // operands of one step, as loaded
 // q0 + 16 t + c), then 2 QT MFMAs.  Steps whose four columns all exist run through a ring of U slots (operands of step s + U
 // requested behind the MFMAs of step s; past the last such step the last one is requested again: no branch, nothing masked);
 // a trailing step with fewer than four columns - and what does not fill a round of U - runs unpipelined behind them: a missing
-// column is replaced by the last valid one, which meets rows of the small matrix that are zero (the small matrices are zero
-// padded to multiples of 4 rows and 64 columns by small_upload / rr_pack), so its product vanishes whatever the panel holds.
-template <int QT, int U>
-__device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, const double* __restrict__ M, int64_t ldm, int64_t i0, int q0,
+// column is replaced by the last valid one, which meets rows of the small matrix that are zero (the operand images are zero
+// outside p x q: small_upload_image / rr_pack), so its product vanishes whatever the panel holds.
+template <int QT, int U, bool PIN>
+__device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, const double* __restrict__ M, int64_t tp, int64_t i0, int q0,
                                         int c, int g, f64x4 (&acc)[2][QT]) {
   const double* ap = P + i0 + 2 * c + (int64_t)g * ld;            // this lane's column of step 0
-  const double* bp = M + (int64_t)(q0 + c) * ldm + g;
+  const double* bp = M + (int64_t)(q0 >> 4) * 64 + c + 16 * g;    // this lane's entry of tile q0 / 16 of step 0 in the operand image
+  const int64_t bstep = tp * 64;
   auto fetch = [&](const double* a, const double* b, PgStep& st) {
     st.a = *reinterpret_cast<const f64x2*>(a);
 #pragma unroll
-    for (int t = 0; t < QT; ++t) st.b[t] = b[(int64_t)(16 * t) * ldm];
+    for (int t = 0; t < QT; ++t) st.b[t] = b[64 * t];             // 64 lanes x 8 B contiguous: one coalesced 512-byte load per tile
   };
   auto mfmas = [&](const PgStep& st) {
 #pragma unroll
@@ -66,14 +68,14 @@ __device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, cons
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       fetch(af, bf, ring[u]);
-      af += astep; bf += 4;
+      af += astep; bf += bstep;
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     for (int s0 = 0; s0 < nfull; s0 += U) {
       const bool more = s0 + U < nfull;                           // another round behind this one (uniform)
       const int64_t da = more ? astep : 0;
-      const int db = more ? 4 : 0;
-      if (!more) { af -= astep; bf -= 4; }                        // last round: the last pipelined step again and again
+      const int64_t db = more ? bstep : 0;
+      if (!more) { af -= astep; bf -= bstep; }                    // last round: the last pipelined step again and again
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // the MFMAs of step s first, then the requests for step s + U: the slot is dead by then (no second register set), and
@@ -84,19 +86,19 @@ __device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, cons
         // the order above IS the schedule: without the barrier the machine scheduler hoists a round's requests to its top and the
         // round's first MFMAs wait for loads issued just in front of them (seen in the ISA: vmcnt(28) behind 30 loads, vmcnt(0)
         // at the end of every round) - a latency per round instead of a pipeline
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
   for (int s = nfull; 4 * s < p; ++s) {
     const int col = min(4 * s + g, p - 1);
     PgStep st;
-    fetch(P + i0 + 2 * c + (int64_t)col * ld, bp + 4 * s, st);
+    fetch(P + i0 + 2 * c + (int64_t)col * ld, bp + (int64_t)s * bstep, st);
     mfmas(st);
   }
 }
 
-template <int QT, int U>
+template <int QT, int U, bool PIN>
 __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
   __shared__ double nrm[4][16 * QT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) acc[h][t] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  pg_term<QT, U>(A.P1, A.ld1, A.p1, A.M1, A.ldm1, i0, q0, c, g, acc);
-  if (A.p2 > 0) pg_term<QT, U>(A.P2, A.ld2, A.p2, A.M2, A.ldm2, i0, q0, c, g, acc);
+  pg_term<QT, U, PIN>(A.P1, A.ld1, A.p1, A.M1, A.tp1, i0, q0, c, g, acc);
+  if (A.p2 > 0) pg_term<QT, U, PIN>(A.P2, A.ld2, A.p2, A.M2, A.tp2, i0, q0, c, g, acc);
 
   // acc[h][t][reg] = OUT[i0 + 2*(g + 4*reg) + h][q0 + 16 t + c]
 #pragma unroll
@@ -168,15 +170,18 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
   }
 }
 
+// a.pin: the pinned schedule (MFMAs of step s, then the requests of step s + U) or the compiler's own order of a round
 void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a) {
   unsigned gx = (unsigned)(a.nrows_pad / PG_ROWS);
-  if (a.q <= 16) {
-    hipLaunchKernelGGL((panel_gemm_kernel<1, 8>), dim3(gx, (a.q + 15) / 16), dim3(256), 0, st, a);
-  } else if (a.q <= 32) {
-    hipLaunchKernelGGL((panel_gemm_kernel<2, 8>), dim3(gx, (a.q + 31) / 32), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((panel_gemm_kernel<4, 8>), dim3(gx, (a.q + 63) / 64), dim3(256), 0, st, a);
-  }
+#define DAV_PG_LAUNCH(QT, GY)                                                                                              \
+  do {                                                                                                                      \
+    if (a.pin) hipLaunchKernelGGL((panel_gemm_kernel<QT, 8, true>), dim3(gx, GY), dim3(256), 0, st, a);                    \
+    else hipLaunchKernelGGL((panel_gemm_kernel<QT, 8, false>), dim3(gx, GY), dim3(256), 0, st, a);                         \
+  } while (0)
+  if (a.q <= 16) DAV_PG_LAUNCH(1, (a.q + 15) / 16);
+  else if (a.q <= 32) DAV_PG_LAUNCH(2, (a.q + 31) / 32);
+  else DAV_PG_LAUNCH(4, (a.q + 63) / 64);
+#undef DAV_PG_LAUNCH
 }
 
 // out[j] = sum_b partial[b][j]: one wave per output column, lanes stride over the blocks, fixed

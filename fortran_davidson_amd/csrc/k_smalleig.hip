@@ -262,8 +262,11 @@ __global__ __launch_bounds__(256) void rr_pack_kernel(const double* __restrict__
                                                       int ldm, int qpad, double* __restrict__ Ypk, double* __restrict__ Y2pk,
                                                       double* __restrict__ theta_pk, const double* __restrict__ info,
                                                       double* __restrict__ result_tail) {
+  // MFMA-B operand images for panel_gemm_kernel (kernels.h: pg_image_index): entry e of the image = lane (c, g) of tile t of step s
+  const int tp = qpad / 16;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < ldm * qpad; e += gridDim.x * 256) {
-    const int i = e % ldm, j = e / ldm;
+    const int lane = e & 63, t = (e >> 6) % tp, s = (e >> 6) / tp;
+    const int i = 4 * s + (lane >> 4), j = 16 * t + (lane & 15);
     const double v = (i < m && j < q) ? Y[i + (int64_t)j * ld] : 0.0;
     Ypk[e] = v;
     Y2pk[e] = (i < m && j < q) ? -v * theta[j] : 0.0;

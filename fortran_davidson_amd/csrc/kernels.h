@@ -44,9 +44,14 @@ void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const doub
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
 
 // ---- K3/K4/K5: panel x small matrix ---------------------------------------------------------------
+// The small matrices are passed as MFMA-B OPERAND IMAGES (pg_image_index): for step s (panel columns 4 s .. 4 s + 3) and column
+// tile t (output columns 16 t .. 16 t + 15) the 64 values the lanes of a wave need - lane c + 16 g holds M[4 s + g][16 t + c] -
+// are contiguous, so a wave fetches them with ONE coalesced 512-byte load.  (Round 3 read M column-major: 16 lines of the cache
+// touched per 8-byte load, QT of them per step - what bound the kernel: 0.63 of 8 TB/s at QT = 1, 0.25 at QT = 4.)  tp = tiles
+// per step of the image (a multiple of 4, >= ceil(q / 16)); rows past p and columns past q are zero.
 struct PanelGemmArgs {
-  const double* P1; int64_t ld1; int p1; const double* M1; int64_t ldm1;   // term 1 (required)
-  const double* P2; int64_t ld2; int p2; const double* M2; int64_t ldm2;   // term 2 (p2 = 0: absent)
+  const double* P1; int64_t ld1; int p1; const double* M1; int64_t tp1;   // term 1 (required)
+  const double* P2; int64_t ld2; int p2; const double* M2; int64_t tp2;   // term 2 (p2 = 0: absent)
   double* out; int64_t ldo; int q;          // out[:, 0:q]
   int64_t nloc, nrows_pad;                  // valid rows / padded rows (multiple of 128)
   // epilogue: 0 = store; 1 = DPR: out = acc / (theta[col] * dB[row] - dA[row]) plus column norms;
@@ -57,7 +62,12 @@ struct PanelGemmArgs {
   // norm_out != nullptr: the LAST workgroup of the launch sums the partials into norm_out[0:nnorm] (fixed order; replaces the
   // launch of norm_finish_kernel); counter = a zeroed device word (dav_last_workgroup)
   double* norm_out; unsigned* counter;
+  int pin;                                  // 1: the pinned software pipeline of the k loop (k_panel.hip), 0: the compiler's order
 };
+// doubles of the operand image of a p x q matrix, its tiles per step, and the index of M[i][j] in it
+static inline int64_t pg_image_tiles(int q) { return ((int64_t)(q > 0 ? q : 1) + 63) / 64 * 4; }
+static inline int64_t pg_image_doubles(int p, int q) { return ((int64_t)(p > 0 ? p : 1) + 3) / 4 * pg_image_tiles(q) * 64; }
+static inline int64_t pg_image_index(int i, int j, int64_t tp) { return (((int64_t)(i >> 2) * tp + (j >> 4)) << 6) + (j & 15) + 16 * (i & 3); }
 constexpr int PG_ROWS = 128;
 constexpr int PG_INPLACE_COLS = 64;       // q <= this: one workgroup column (grid.y == 1), so OUT may alias P1 (see k_panel.hip)
 void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a);
