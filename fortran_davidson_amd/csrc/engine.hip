@@ -172,7 +172,6 @@ Tune tune_from_env() {
   t.mv_target = std::max(0, geti("DAV_MV_TARGET", 0));
   t.mv_nsplit = std::max(0, geti("DAV_MV_NSPLIT", 0));
   t.b_resident = geti("DAV_B_RESIDENT", t.b_resident);
-  t.gram_tile = geti("DAV_GRAM_TILE", t.gram_tile);
   t.pg_pin = geti("DAV_PG_PIN", t.pg_pin);
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
   return t;
@@ -221,8 +220,8 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   HIPCHK(hipMalloc(&e->gather_dev, sizeof(double) * (size_t)e->ncols_pad));
   HIPCHK(hipMalloc(&e->idx_dev, sizeof(int64_t) * e->cols_alloc));
   HIPCHK(hipMalloc(&e->norm_partial, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc));
-  HIPCHK(hipMalloc(&e->counters, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8 + MV_FUSE_ROWBLOCKS)));
-  HIPCHK(hipMemsetAsync(e->counters, 0, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8 + MV_FUSE_ROWBLOCKS), e->stream));
+  HIPCHK(hipMalloc(&e->counters, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8)));
+  HIPCHK(hipMemsetAsync(e->counters, 0, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8), e->stream));
   e->small_doubles = 3 * (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
   for (int i = 0; i < N_SMALL; ++i) {
     HIPCHK(hipMalloc(&e->sm[i].dev, sizeof(double) * e->small_doubles));

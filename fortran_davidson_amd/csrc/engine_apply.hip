@@ -326,19 +326,14 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     matvec_plan(e->nloc_pad, e->ncols_pad, ngroups, &nsplit, &jc, e->tune.mv_target, e->tune.mv_nsplit);
     if (matvec_slab_doubles(e->nloc_pad, ngroups, nsplit) > e->scratch_doubles) return fail("matvec scratch too small");
     if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->nloc * (double)e->n * kk, &kslot));
-    // stored row slab at the launch-bound sizes (<= MV_FUSE_ROWBLOCKS row blocks): the last workgroup of a row block sums the column
-    // chunks itself; elsewhere the second kernel
-    const bool fuse = o.kind == DAV_KIND_DENSE && e->nloc_pad / MV_ROWS <= MV_FUSE_ROWBLOCKS;
     if (o.kind == DAV_KIND_DENSE)
       launch_matvec_dense(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->ncols_pad, e->xt, e->xt_group_stride, ngroups,
-                          e->scratch, nsplit, jc,
-                          fuse ? MatvecFinish{e->counters + GRAM_MAX_COUNTERS + 8, dst + (int64_t)c * e->ldp, e->ldp, e->nloc, kk}
-                               : MatvecFinish{nullptr, nullptr, 0, 0, 0});
+                          e->scratch, nsplit, jc);
     else
       launch_matvec_free(e->stream, op_params(o), e->row0, e->nloc, e->n, e->nloc_pad, e->ncols_pad, e->xt,
                          e->xt_group_stride, ngroups, e->scratch, nsplit, jc);
     CHK(timed_end(e, kslot));               // inner pair: the block-matvec kernel alone
-    if (!fuse) launch_slab_reduce(e->stream, e->scratch, nsplit, e->nloc_pad, ngroups, e->nloc, kk, dst + (int64_t)c * e->ldp, e->ldp);
+    launch_slab_reduce(e->stream, e->scratch, nsplit, e->nloc_pad, ngroups, e->nloc, kk, dst + (int64_t)c * e->ldp, e->ldp);
     CHK(timed_end(e, slot));                // outer pair: pack + all-gather + kernel + reduction
     if (which == DAV_OP_A) {
       e->st.applies += 1;

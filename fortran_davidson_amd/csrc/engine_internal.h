@@ -146,7 +146,6 @@ struct Tune {
   int64_t mv_target = 0;  // DAV_MV_TARGET / DAV_MV_NSPLIT: grid of the row-slab kernel (0 = by the shape)
   int64_t mv_nsplit = 0;
   int pg_pin = 1;         // DAV_PG_PIN: the panel kernel's k loop in the pinned order (1) or the compiler's (0) (A/B runs)
-  int gram_tile = 0;      // DAV_GRAM_TILE: 1 = never the 64 x 32 register tile of the Gram kernel (A/B runs)
   int b_resident = 1;     // DAV_B_RESIDENT: keep what fits of a generated second operator resident as stored tiles (dav_set_operator_hashed, storage 1)
   bool gjd_trace = false; // DAV_GJD_TRACE
 };
@@ -174,7 +173,7 @@ struct dav_engine {
   double* gather_dev = nullptr;   // nranks*nslab staging for panel_get / diagonal gather
   int64_t* idx_dev = nullptr;
   double* norm_partial = nullptr;
-  unsigned* counters = nullptr;   // zeroed words of the last-workgroup finishes: [0, GRAM_MAX_COUNTERS) Gram tiles, [GRAM_MAX_COUNTERS] the panel norms, [GRAM_MAX_COUNTERS + 8, ...) the row blocks of the stored row-slab sweep
+  unsigned* counters = nullptr;   // zeroed words of the last-workgroup finishes: [0, GRAM_MAX_COUNTERS) Gram tiles, [GRAM_MAX_COUNTERS] the panel norms
   double* gjd_ws = nullptr;       // GJD inner-solver workspace (lazy)
   int storage = 0;                // storage mode for dense operators set after dav_set_storage
   int sym_nb = 0;                 // symmetric-tiled sweep: block rows of the whole matrix

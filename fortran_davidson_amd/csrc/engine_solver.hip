@@ -22,7 +22,7 @@ int gram_impl(E* e, const double* P, int p, const double* Q, int q) {
   if (gram_scratch_doubles(p, q, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
-  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, result_target(e), e->counters, e->tune.gram_tile);
+  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, result_target(e), e->counters);
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
   CHK(result_fetch(e, (size_t)p * q));
@@ -53,10 +53,10 @@ extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
   launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_W, c0), e->ldp, k, e->nloc_pad, e->scratch,
-              result_target(e), e->counters, e->tune.gram_tile);
+              result_target(e), e->counters);
   if (both)
     launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_BV, c0), e->ldp, k, e->nloc_pad,
-                e->scratch, result_target(e) + blk, e->counters, e->tune.gram_tile);
+                e->scratch, result_target(e) + blk, e->counters);
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
   if (e->rr_on) {
@@ -184,7 +184,8 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
   r.q = ncorr; r.nloc = e->nloc; r.nrows_pad = e->nloc_pad;
   r.theta = dTheta; r.dA = e->op[DAV_OP_A].diag; r.dB = e->gev ? e->op[DAV_OP_B].diag : nullptr;
   r.nnorm = lowest; r.norm_partial = e->norm_partial;
-  r.norm_out = result_target(e); r.counter = e->counters + GRAM_MAX_COUNTERS;      // the last workgroup sums the partial norms (no norm_finish launch)
+  const bool fuse_norms = e->nloc_pad / PG_ROWS <= PG_FUSE_BLOCKS;     // small grids: the last workgroup sums the partial norms itself
+  if (fuse_norms) { r.norm_out = result_target(e); r.counter = e->counters + GRAM_MAX_COUNTERS; }
   if (method == DAV_METHOD_DPR) {
     r.out = panel_ptr(e, DAV_PANEL_V, m); r.ldo = e->ldp; r.epilogue = 1;
   } else {
@@ -192,6 +193,7 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
   }
   r.pin = e->tune.pg_pin;
   launch_panel_gemm(e->stream, r);
+  if (!fuse_norms) launch_norm_finish(e->stream, e->norm_partial, (int)(e->nloc_pad / PG_ROWS), lowest, result_target(e));
   // optionally the Gram block the first orthonormalisation pass needs, [V T]^T T with T = V[:, m:m+ncorr] just
   // written: it rides on the same reduction and the same fetch as the norms (one synchronisation less)
   size_t count = (size_t)lowest;
@@ -201,7 +203,7 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
     if (goff + (size_t)p * ncorr > e->gram_doubles) return fail("gram result exceeds engine capacity");
     if (gram_scratch_doubles(p, ncorr, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
     launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, p, panel_ptr(e, DAV_PANEL_V, m), e->ldp, ncorr, e->nloc_pad,
-                e->scratch, result_target(e) + goff, e->counters, e->tune.gram_tile);
+                e->scratch, result_target(e) + goff, e->counters);
     count = goff + (size_t)p * ncorr;
   }
   CHK(timed_end(e, slot));

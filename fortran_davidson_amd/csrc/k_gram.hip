@@ -2,37 +2,46 @@
 // src/davidson.f90:131,223 outer; also the inner products of the block Gram-Schmidt that replaces
 // lapack_qr, src/lapack_wrapper.f90:176-236).
 //
-// The long dimension N is the MFMA contraction index.  Lane (c = lane & 15, g = lane >> 4) loads four
-// consecutive rows n0 + 4g .. 4g+3 of panel column c (two 16-byte loads: the 16 lanes of a column
-// group read one full 128-byte line per column), and MFMA step s uses element s of both fragments,
-// so A and B operands see the same permutation of the contraction index.  Each wave owns a
-// (16 PT) x (16 QT) tile of C over a 256-row chunk, the four waves of a workgroup are summed through
-// LDS, workgroup partials go to a slab, and the slabs are added in a fixed order - by a second small kernel, or
-// (few row chunks: the launch-bound sizes) by the workgroup that finishes last (dav_last_workgroup).
-//
-// Round 4: a "step" (16 rows of the wave's PT + QT panel columns = 2 (PT + QT) 16-byte loads per lane, 4 PT QT MFMAs) used to
-// wait for its own loads - a chain of memory latencies, with 2 x 16 PT QT accumulator copies between the register halves around
-// every step (N=200000, 64 x 32: 113 us for 296 MB = 0.33 of 8 TB/s).  The loop now runs through a static ring of U steps -
-// the loads of step s + U are requested behind the MFMAs of step s (2 (PT + QT) U KB in flight per wave) - and the file is
-// compiled with the accumulators in VGPRs (-amdgpu-mfma-vgpr-form, csrc/Makefile): no copies.
+// The long dimension N is the MFMA contraction index, and the panels are column-major: an MFMA operand wants "lane <-> panel
+// column" while a coalesced load wants "adjacent lanes <-> adjacent rows of one column".  Rounds 1-3 used v_mfma_f64_16x16x4_f64
+// with lane (c, g) loading rows 4 g .. 4 g + 3 of column c: SIXTEEN columns - sixteen cache lines, 64 bytes of each - per load
+// instruction, which is what bound the kernel (N=200000, 64 x 32: 0.33 of 8 TB/s; pipelining the loop changed nothing).  Round 4
+// runs the products on v_mfma_f64_4x4x4_4b_f64 - four independent 4 x 4 x 4 blocks per instruction, A lane = i + 4 blk + 16 k,
+// B lane = j + 4 blk + 16 k, D lane = j + 4 blk + 16 i (profiles/ubench/r02_mfma4x4.log), the same pipe time per flop - with the
+// blocks as four groups of ROWS: lane (i, blk, k) loads 16 bytes = rows 2 (blk + 4 k), + 1 of column 4 f + i of a step of 32
+// rows, so one load instruction reads FOUR columns x 256 contiguous bytes (the pattern of the block matvec's tile loads), P and
+// Q alike, and feeds two MFMAs per fragment pair.  A wave owns a (4 PF) x (4 QF) tile of C over its rows, as PF x QF accumulators
+// of one double per lane (the four blocks = four partial sums over disjoint rows); they are added across the blocks by two
+// row-rotate DPP steps, across the four waves through LDS, workgroup partials go to a slab, and the slabs are added in a fixed
+// order - by a second small kernel, or (few row chunks) by the workgroup that finishes last (dav_last_workgroup).
+// The loop runs through a static ring of U steps: the loads of step s + U are requested behind the MFMAs of step s.
 #include "kernels.h"
 
 namespace {
-template <int PT, int QT>
+template <int PF, int QF>
 struct GramStep {
-  f64x2 pf[PT][2], qf[QT][2];
+  f64x2 pf[PF], qf[QF];
 };
+__device__ __forceinline__ double mfma4_f64(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// value of the lane CTRL positions away inside its row of 16 lanes (DPP row rotate: 0x120 + n)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 }  // namespace
 
-template <int PT, int QT, int U>
+template <int PF, int QF, int U>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P, int64_t ldp, int p,
                                                    const double* __restrict__ Q, int64_t ldq, int q,
                                                    int64_t nrows_pad, int ptiles, int qtiles, int nchunks,
                                                    double* __restrict__ slab, int ppad, int qpad, int rows_per_wg,
                                                    double* __restrict__ out, unsigned* __restrict__ counters) {
-  __shared__ double red[4][PT * QT * 256];
+  __shared__ double red[4][PF * QF * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & 15, g = lane >> 4;
+  const int i4 = lane & 3, blk = (lane >> 2) & 3, kq = lane >> 4;
   // 1-D grid of ntiles x nchunks workgroups.  Consecutive workgroups go to consecutive XCDs (8, each with its
   // own L2), so inside a block of 8 row chunks the workgroup index runs over the chunks first: all output
   // tiles of one row chunk - which re-read the same panel rows - land on ONE XCD and share its L2.
@@ -48,112 +57,100 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
     tile = r % ntiles;
   }
   const int tp = tile / qtiles, tq = tile % qtiles;
-  const int pc0 = tp * 16 * PT, qc0 = tq * 16 * QT;
+  const int pc0 = tp * 4 * PF, qc0 = tq * 4 * QF;
   int64_t n0 = (int64_t)chunk * rows_per_wg + wave * (rows_per_wg / 4);
   int64_t n1 = n0 + rows_per_wg / 4;
   if (n1 > nrows_pad) n1 = nrows_pad;
 
-  // column pointers; columns past the panel width are clamped (their results are discarded)
-  const double* pp[PT];
-  const double* qp[QT];
+  // column pointers of this lane (rows 2 (blk + 4 k), + 1 of a step); columns past the panel width are clamped (their results
+  // are discarded)
+  const int roff = 2 * (blk + 4 * kq);
+  const double* pp[PF];
+  const double* qp[QF];
 #pragma unroll
-  for (int t = 0; t < PT; ++t) {
-    int col = pc0 + 16 * t + c;
+  for (int f = 0; f < PF; ++f) {
+    int col = pc0 + 4 * f + i4;
     if (col >= p) col = p - 1;
-    pp[t] = P + (int64_t)col * ldp + 4 * g;
+    pp[f] = P + (int64_t)col * ldp + roff;
   }
 #pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    int col = qc0 + 16 * t + c;
+  for (int f = 0; f < QF; ++f) {
+    int col = qc0 + 4 * f + i4;
     if (col >= q) col = q - 1;
-    qp[t] = Q + (int64_t)col * ldq + 4 * g;
+    qp[f] = Q + (int64_t)col * ldq + roff;
   }
 
-  // NC accumulator chains per output tile so that consecutive MFMAs never depend on each other: a dependent
-  // f64 MFMA issued fewer than ~4 slots behind its producer stalls the matrix pipe
-  constexpr int NC = PT * QT >= 4 ? 1 : (PT * QT == 2 ? 2 : 4);
-  f64x4 acc[PT][QT][NC];
+  double acc[PF][QF];
 #pragma unroll
-  for (int a = 0; a < PT; ++a)
+  for (int a = 0; a < PF; ++a)
 #pragma unroll
-    for (int b = 0; b < QT; ++b)
-#pragma unroll
-      for (int ch = 0; ch < NC; ++ch) acc[a][b][ch] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < QF; ++b) acc[a][b] = 0.0;
 
-  auto fetch = [&](int64_t n, GramStep<PT, QT>& st) {
+  auto fetch = [&](int64_t n, GramStep<PF, QF>& st) {
 #pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      st.pf[t][0] = *reinterpret_cast<const f64x2*>(pp[t] + n);
-      st.pf[t][1] = *reinterpret_cast<const f64x2*>(pp[t] + n + 2);
-    }
+    for (int f = 0; f < PF; ++f) st.pf[f] = *reinterpret_cast<const f64x2*>(pp[f] + n);
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-      st.qf[t][0] = *reinterpret_cast<const f64x2*>(qp[t] + n);
-      st.qf[t][1] = *reinterpret_cast<const f64x2*>(qp[t] + n + 2);
-    }
+    for (int f = 0; f < QF; ++f) st.qf[f] = *reinterpret_cast<const f64x2*>(qp[f] + n);
   };
-  auto mfmas = [&](const GramStep<PT, QT>& st) {
+  // the two rows a lane holds = two MFMAs per fragment pair; an accumulator is touched once per PF QF MFMAs
+  auto mfmas = [&](const GramStep<PF, QF>& st) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int a = 0; a < PF; ++a)
 #pragma unroll
-      for (int a = 0; a < PT; ++a)
+      for (int b = 0; b < QF; ++b) acc[a][b] = mfma4_f64(st.pf[a].x, st.qf[b].x, acc[a][b]);
 #pragma unroll
-        for (int b = 0; b < QT; ++b) {
-          const double pa = (s & 1) ? st.pf[a][s >> 1].y : st.pf[a][s >> 1].x;
-          const double qb = (s & 1) ? st.qf[b][s >> 1].y : st.qf[b][s >> 1].x;
-          acc[a][b][s % NC] = mfma_f64(pa, qb, acc[a][b][s % NC]);
-        }
+    for (int a = 0; a < PF; ++a)
+#pragma unroll
+      for (int b = 0; b < QF; ++b) acc[a][b] = mfma4_f64(st.pf[a].y, st.qf[b].y, acc[a][b]);
   };
 
-  // steps of 16 rows: full rounds of U through the ring (the loads of step s + U behind the MFMAs of step s; in the last round
+  // steps of 32 rows: full rounds of U through the ring (the loads of step s + U behind the MFMAs of step s; in the last round
   // the last step is requested again - no branch), the rest unpipelined
-  const int64_t nsteps = n1 > n0 ? (n1 - n0) / 16 : 0;
+  const int64_t nsteps = n1 > n0 ? (n1 - n0) / 32 : 0;
   const int64_t nring = nsteps / U * U;
   if (nring > 0) {
-    GramStep<PT, QT> ring[U];
+    GramStep<PF, QF> ring[U];
     int64_t nf = n0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { fetch(nf, ring[u]); nf += 16; }
+    for (int u = 0; u < U; ++u) { fetch(nf, ring[u]); nf += 32; }
     __builtin_amdgcn_sched_barrier(0);
     for (int64_t s0 = 0; s0 < nring; s0 += U) {
       const bool more = s0 + U < nring;
-      const int64_t dn = more ? 16 : 0;
-      if (!more) nf -= 16;
+      const int64_t dn = more ? 32 : 0;
+      if (!more) nf -= 32;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         mfmas(ring[u]);
         fetch(nf, ring[u]);
         nf += dn;
-        __builtin_amdgcn_sched_barrier(0);      // this order is the schedule (see k_panel.hip): MFMAs of step s, then the requests for step s + U
+        __builtin_amdgcn_sched_barrier(0);      // this order is the schedule (see k_panel.hip)
       }
     }
   }
-  for (int64_t n = n0 + 16 * nring; n < n1; n += 16) {
-    GramStep<PT, QT> st;
+  for (int64_t n = n0 + 32 * nring; n < n1; n += 32) {
+    GramStep<PF, QF> st;
     fetch(n, st);
     mfmas(st);
   }
 
-  // cross-wave sum through LDS, then one partial tile per workgroup
+  // sum over the four blocks (lanes i + 4 blk' + 16 i' of a row of 16: two rotate-and-add steps leave the sum in every lane),
+  // then over the four waves through LDS: one partial tile per workgroup
 #pragma unroll
-  for (int a = 0; a < PT; ++a)
+  for (int a = 0; a < PF; ++a)
 #pragma unroll
-    for (int b = 0; b < QT; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double v = acc[a][b][0][r];
-#pragma unroll
-        for (int ch = 1; ch < NC; ++ch) v += acc[a][b][ch][r];
-        red[wave][((a * QT + b) * 4 + r) * 64 + lane] = v;
-      }
+    for (int b = 0; b < QF; ++b) {
+      double v = acc[a][b];
+      v += dpp_row<0x128>(v);                   // row_ror:8
+      v += dpp_row<0x124>(v);                   // row_ror:4
+      if (blk == 0) red[wave][(a * QF + b) * 16 + kq * 4 + i4] = v;     // D lane = j + 4 blk + 16 i: kq is the row i of C, i4 its column j
+    }
   __syncthreads();
   double* part = slab + (int64_t)chunk * ppad * qpad;
-  for (int e = threadIdx.x; e < PT * QT * 256; e += 256) {
-    double v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
-    int l = e & 63, r = (e >> 6) & 3, ab = e >> 8;
-    int a = ab / QT, b = ab % QT;
-    int prow = pc0 + 16 * a + (l >> 4) + 4 * r;   // index into P columns  (row of C)
-    int qcol = qc0 + 16 * b + (l & 15);           // index into Q columns  (column of C)
+  for (int e = threadIdx.x; e < PF * QF * 16; e += 256) {
+    const double v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    const int ab = e >> 4, a = ab / QF, b = ab % QF;
+    const int prow = pc0 + 4 * a + ((e >> 2) & 3);   // index into P columns  (row of C)
+    const int qcol = qc0 + 4 * b + (e & 3);          // index into Q columns  (column of C)
     if (prow < p && qcol < q) part[(int64_t)qcol * ppad + prow] = v;
   }
   if (counters) {
@@ -161,8 +158,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
     // with eight interleaved partial sums (a fixed order: reproducible run to run; not the order of gram_reduce_kernel)
     if (dav_last_workgroup(counters + tile, (unsigned)nchunks)) {
       const int64_t stride = (int64_t)ppad * qpad;
-      for (int e = threadIdx.x; e < PT * QT * 256; e += 256) {
-        const int prow = pc0 + (e & (16 * PT - 1)), qcol = qc0 + e / (16 * PT);
+      for (int e = threadIdx.x; e < PF * QF * 16; e += 256) {
+        const int prow = pc0 + e % (4 * PF), qcol = qc0 + e / (4 * PF);
         if (prow >= p || qcol >= q) continue;
         const double* src = slab + (int64_t)qcol * ppad + prow;
         double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -216,10 +213,10 @@ size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
   return (size_t)nchunks * pad16(p) * pad16(q);
 }
 
-template <int PT, int QT, int U>
+template <int PF, int QF, int U>
 static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
                               int64_t nrows_pad, double* scratch, int ppad, int qpad, double* out_dev, unsigned* counters) {
-  const int ptiles = (p + 16 * PT - 1) / (16 * PT), qtiles = (q + 16 * QT - 1) / (16 * QT);
+  const int ptiles = (p + 4 * PF - 1) / (4 * PF), qtiles = (q + 4 * QF - 1) / (4 * QF);
   // rows per workgroup: as tall as possible (fewer partial tiles) while the grid still fills the chip
   int rows_per_wg = GRAM_ROWS;
   while (rows_per_wg > GRAM_MIN_ROWS && (int64_t)ptiles * qtiles * ((nrows_pad + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg /= 2;
@@ -227,7 +224,7 @@ static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int 
   // last-workgroup finish where the sum over the chunks is short and a second launch is what costs (<= GRAM_FUSE_CHUNKS row
   // chunks, one counter per output tile); the two-kernel route where hundreds of chunks want more than one workgroup per tile
   const bool fuse = counters && nchunks <= GRAM_FUSE_CHUNKS && ptiles * qtiles <= GRAM_MAX_COUNTERS;
-  hipLaunchKernelGGL((gram_kernel<PT, QT, U>), dim3(ptiles * qtiles * nchunks), dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, ptiles,
+  hipLaunchKernelGGL((gram_kernel<PF, QF, U>), dim3(ptiles * qtiles * nchunks), dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, ptiles,
                      qtiles, nchunks, scratch, ppad, qpad, rows_per_wg, out_dev, fuse ? counters : (unsigned*)nullptr);
   if (!fuse) {
     const int total = p * q;
@@ -235,19 +232,15 @@ static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int 
   }
 }
 
-// counters: GRAM_MAX_COUNTERS zeroed device words (nullptr: always the two-kernel route); tile_mode: 0 = by the shape,
-// 1 = never the 64 x 32 register tile (A/B runs)
+// counters: GRAM_MAX_COUNTERS zeroed device words (nullptr: always the two-kernel route)
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters, int tile_mode) {
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters) {
   int ppad = pad16(p), qpad = pad16(q);
-  // register tile of a wave: 64 x 32 for wide blocks (every output tile re-reads its panel columns through L2: 128 x 64 as eight
-  // 32 x 32 tiles moves 819 MB through L2 for 307 MB of panels), 32 x 32 down to 16 x 16 below
-  if (p > 32 && q > 16 && tile_mode != 1)
-    launch_gram_tiles<4, 2, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
-  else if (p > 16 && q > 16)
-    launch_gram_tiles<2, 2, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
+  // register tile of a wave: 32 x 32 (64 accumulators), 32 x 16, 16 x 16 columns
+  if (p > 16 && q > 16)
+    launch_gram_tiles<8, 8, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
   else if (p > 16)
-    launch_gram_tiles<2, 1, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
+    launch_gram_tiles<8, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
   else
-    launch_gram_tiles<1, 1, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
+    launch_gram_tiles<4, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
 }

@@ -42,13 +42,11 @@ void launch_pack_xt(hipStream_t st, const double* src, int64_t ld, int64_t nloc,
 //   A loads:  rows r0 + 2c, r0 + 2c + 1 (+32 for the second load) of column j + 4u + g
 //   B loads:  Xt[group t][j + 4u + g][c]
 //   acc[rt][t]: rt = 2*half + parity -> rows r0 + 32*half + 2*(g + 4*reg) + parity, column 16 t + c
-// fin.counters != nullptr: the workgroup that finishes a row block LAST (of the gridDim.y column chunks) adds the partial tiles of
-// all chunks for its 256 rows - the sum slab_reduce_kernel makes (same order, same bits), without its launch
 template <int NT>
 __global__ __launch_bounds__(256) void matvec_dense_kernel(const double* __restrict__ A, int64_t lda,
                                                            int64_t ncols_pad, const double* __restrict__ xt,
                                                            int64_t group_stride, double* __restrict__ slab,
-                                                           int64_t nrows_pad, int jc, MatvecFinish fin) {
+                                                           int64_t nrows_pad, int jc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * MV_ROWS + wave * 64;
@@ -100,39 +98,6 @@ __global__ __launch_bounds__(256) void matvec_dense_kernel(const double* __restr
       for (int reg = 0; reg < 4; ++reg) {
         int64_t row = r0 + 32 * half + 2 * (g + 4 * reg) + par;
         out[(int64_t)(16 * t + c) * nrows_pad + row] = acc[rt][t][reg];
-      }
-    }
-  }
-  if (fin.counters) {
-    if (dav_last_workgroup(fin.counters + blockIdx.x, gridDim.y)) {
-      const int nsplit = gridDim.y;
-      const int64_t stride = (int64_t)(NT * 16) * nrows_pad;
-      const int64_t rb = (int64_t)blockIdx.x * MV_ROWS;
-      for (int e = threadIdx.x; e < (MV_ROWS / 2) * fin.k; e += 256) {
-        const int64_t i = rb + 2 * (e % (MV_ROWS / 2));
-        const int col = e / (MV_ROWS / 2);
-        const double* p = slab + (int64_t)col * nrows_pad + i;
-        f64x2 part[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-        int sp = 0;
-        for (; sp + 4 <= nsplit; sp += 4) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            f64x2 v = *reinterpret_cast<const f64x2*>(p + (sp + u) * stride);
-            part[u].x += v.x;
-            part[u].y += v.y;
-          }
-        }
-        for (int u = 0; sp < nsplit; ++sp, ++u) {
-          f64x2 v = *reinterpret_cast<const f64x2*>(p + sp * stride);
-          part[u].x += v.x;
-          part[u].y += v.y;
-        }
-        f64x2 sum;
-        sum.x = (part[0].x + part[1].x) + (part[2].x + part[3].x);
-        sum.y = (part[0].y + part[1].y) + (part[2].y + part[3].y);
-        if (i >= fin.nloc) sum.x = 0.0;
-        if (i + 1 >= fin.nloc) sum.y = 0.0;
-        *reinterpret_cast<f64x2*>(fin.dst + (int64_t)col * fin.ldd + i) = sum;
       }
     }
   }
@@ -268,12 +233,12 @@ size_t matvec_slab_doubles(int64_t nrows_pad, int ngroups, int nsplit) {
 }
 
 void launch_matvec_dense(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad,
-                         const double* xt, int64_t xt_group_stride, int ngroups, double* slab, int nsplit, int jc, MatvecFinish fin) {
+                         const double* xt, int64_t xt_group_stride, int ngroups, double* slab, int nsplit, int jc) {
   dim3 grid((unsigned)(nrows_pad / MV_ROWS), nsplit);
   switch (ngroups) {
-    case 1: hipLaunchKernelGGL(matvec_dense_kernel<1>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc, fin); break;
-    case 2: hipLaunchKernelGGL(matvec_dense_kernel<2>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc, fin); break;
-    default: hipLaunchKernelGGL(matvec_dense_kernel<4>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc, fin); break;
+    case 1: hipLaunchKernelGGL(matvec_dense_kernel<1>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    case 2: hipLaunchKernelGGL(matvec_dense_kernel<2>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
+    default: hipLaunchKernelGGL(matvec_dense_kernel<4>, grid, dim3(256), 0, st, A, lda, ncols_pad, xt, xt_group_stride, slab, nrows_pad, jc); break;
   }
 }
 

@@ -6,20 +6,14 @@
 // ---- K1: block matvec ---------------------------------------------------------------------------
 // Row tile of one workgroup (4 waves x 64 rows).  Panels and A are padded to a multiple of it.
 constexpr int MV_ROWS = 256;
-constexpr int MV_FUSE_ROWBLOCKS = 512;    // row blocks up to which the stored row-slab sweep finishes its own column-chunk sum
 // Pack k columns of a column-major panel into the transposed MFMA-B layout Xt[group][row][16]
 // (zero padded) for rows [0, nloc_pad) of this rank, written at row offset `row_off`.
 void launch_pack_xt(hipStream_t st, const double* src, int64_t ld, int64_t nloc, int64_t nslab, int k,
                     double* xt, int64_t xt_group_stride, int64_t row_off);
 // slab[s][col][row] = A[rows, chunk s] * X[chunk s, col]; ngroups = ceil(k/16) in {1,2,4}.
-// fin.counters != nullptr (one zeroed word per 256-row block): the last workgroup of every row block also sums the chunks into
-// fin.dst[:, 0:k] (what launch_slab_reduce does otherwise)
-struct MatvecFinish {
-  unsigned* counters; double* dst; int64_t ldd; int64_t nloc; int k;
-};
 void launch_matvec_dense(hipStream_t st, const double* A, int64_t lda, int64_t nrows_pad, int64_t ncols_pad,
                          const double* xt, int64_t xt_group_stride, int ngroups, double* slab,
-                         int nsplit, int jc, MatvecFinish fin = MatvecFinish{nullptr, nullptr, 0, 0, 0});
+                         int nsplit, int jc);
 void launch_matvec_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t n,
                         int64_t nrows_pad, int64_t ncols_pad, const double* xt, int64_t xt_group_stride,
                         int ngroups, double* slab, int nsplit, int jc);
@@ -40,7 +34,7 @@ constexpr int GRAM_MIN_ROWS = 256; // ... and at least (small problems: more, sh
 constexpr int GRAM_FUSE_CHUNKS = 24;
 constexpr int GRAM_MAX_COUNTERS = 256;
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr, int tile_mode = 0);
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr);
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
 
 // ---- K3/K4/K5: panel x small matrix ---------------------------------------------------------------
@@ -60,7 +54,9 @@ struct PanelGemmArgs {
   const double* theta; const double* dA; const double* dB;   // dB == nullptr: B diagonal = 1
   int nnorm; double* norm_partial;          // [gridDim.x][nnorm] partial sums of acc^2 (cols < nnorm)
   // norm_out != nullptr: the LAST workgroup of the launch sums the partials into norm_out[0:nnorm] (fixed order; replaces the
-  // launch of norm_finish_kernel); counter = a zeroed device word (dav_last_workgroup)
+  // launch of norm_finish_kernel); counter = a zeroed device word (dav_last_workgroup).  For small grids only (PG_FUSE_BLOCKS): the
+  // device-scope fence every workgroup pays for the pattern writes its XCD's L2 back - measured at +0.15 ms on the 1563
+  // workgroups of N=200000 (and +0.28 ms per sweep when the row-slab block matvec summed its column chunks this way: removed)
   double* norm_out; unsigned* counter;
   int pin;                                  // 1: the pinned software pipeline of the k loop (k_panel.hip), 0: the compiler's order
 };
@@ -69,6 +65,7 @@ static inline int64_t pg_image_tiles(int q) { return ((int64_t)(q > 0 ? q : 1) +
 static inline int64_t pg_image_doubles(int p, int q) { return ((int64_t)(p > 0 ? p : 1) + 3) / 4 * pg_image_tiles(q) * 64; }
 static inline int64_t pg_image_index(int i, int j, int64_t tp) { return (((int64_t)(i >> 2) * tp + (j >> 4)) << 6) + (j & 15) + 16 * (i & 3); }
 constexpr int PG_ROWS = 128;
+constexpr int PG_FUSE_BLOCKS = 48;         // row blocks up to which the Ritz kernel finishes its own norms (N <= 6144)
 constexpr int PG_INPLACE_COLS = 64;       // q <= this: one workgroup column (grid.y == 1), so OUT may alias P1 (see k_panel.hip)
 void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a);
 // out[j] = sqrt(sum_b partial[b][j])
