@@ -173,6 +173,7 @@ Tune tune_from_env() {
   t.mv_nsplit = std::max(0, geti("DAV_MV_NSPLIT", 0));
   t.b_resident = geti("DAV_B_RESIDENT", t.b_resident);
   t.pg_pin = geti("DAV_PG_PIN", t.pg_pin);
+  t.gram_wgs = geti("DAV_GRAM_WGS", t.gram_wgs);
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
   return t;
 }

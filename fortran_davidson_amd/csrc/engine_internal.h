@@ -145,6 +145,7 @@ struct Tune {
   int sym_mfma4 = 1;      // DAV_SYM_MFMA4: the 4x4x4 MFMA at k <= 8
   int64_t mv_target = 0;  // DAV_MV_TARGET / DAV_MV_NSPLIT: grid of the row-slab kernel (0 = by the shape)
   int64_t mv_nsplit = 0;
+  int gram_wgs = 0;       // DAV_GRAM_WGS: workgroups the Gram kernel's grid aims at (0 = default)
   int pg_pin = 1;         // DAV_PG_PIN: the panel kernel's k loop in the pinned order (1) or the compiler's (0) (A/B runs)
   int b_resident = 1;     // DAV_B_RESIDENT: keep what fits of a generated second operator resident as stored tiles (dav_set_operator_hashed, storage 1)
   bool gjd_trace = false; // DAV_GJD_TRACE

@@ -22,7 +22,7 @@ int gram_impl(E* e, const double* P, int p, const double* Q, int q) {
   if (gram_scratch_doubles(p, q, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
-  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, result_target(e), e->counters);
+  launch_gram(e->stream, P, e->ldp, p, Q, e->ldp, q, e->nloc_pad, e->scratch, result_target(e), e->counters, e->tune.gram_wgs);
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
   CHK(result_fetch(e, (size_t)p * q));
@@ -53,10 +53,10 @@ extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
   launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_W, c0), e->ldp, k, e->nloc_pad, e->scratch,
-              result_target(e), e->counters);
+              result_target(e), e->counters, e->tune.gram_wgs);
   if (both)
     launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, mt, panel_ptr(e, DAV_PANEL_BV, c0), e->ldp, k, e->nloc_pad,
-                e->scratch, result_target(e) + blk, e->counters);
+                e->scratch, result_target(e) + blk, e->counters, e->tune.gram_wgs);
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
   if (e->rr_on) {
@@ -203,7 +203,7 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
     if (goff + (size_t)p * ncorr > e->gram_doubles) return fail("gram result exceeds engine capacity");
     if (gram_scratch_doubles(p, ncorr, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
     launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, p, panel_ptr(e, DAV_PANEL_V, m), e->ldp, ncorr, e->nloc_pad,
-                e->scratch, result_target(e) + goff, e->counters);
+                e->scratch, result_target(e) + goff, e->counters, e->tune.gram_wgs);
     count = goff + (size_t)p * ncorr;
   }
   CHK(timed_end(e, slot));

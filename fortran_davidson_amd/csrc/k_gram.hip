@@ -16,6 +16,7 @@
 // order - by a second small kernel, or (few row chunks) by the workgroup that finishes last (dav_last_workgroup).
 // The loop runs through a static ring of U steps: the loads of step s + U are requested behind the MFMAs of step s.
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 template <int PF, int QF>
@@ -215,11 +216,16 @@ size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
 
 template <int PF, int QF, int U>
 static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                              int64_t nrows_pad, double* scratch, int ppad, int qpad, double* out_dev, unsigned* counters) {
+                              int64_t nrows_pad, double* scratch, int ppad, int qpad, double* out_dev, unsigned* counters, int wg_target) {
   const int ptiles = (p + 4 * PF - 1) / (4 * PF), qtiles = (q + 4 * QF - 1) / (4 * QF);
-  // rows per workgroup: as tall as possible (fewer partial tiles) while the grid still fills the chip
-  int rows_per_wg = GRAM_ROWS;
-  while (rows_per_wg > GRAM_MIN_ROWS && (int64_t)ptiles * qtiles * ((nrows_pad + rows_per_wg - 1) / rows_per_wg) < 512) rows_per_wg /= 2;
+  // rows per workgroup: ONE workgroup per CU where the panels are long enough (wg_target = 256 workgroups over all output tiles:
+  // a workgroup costs several microseconds of prologue, cross-wave sum and partial-tile write whatever its length - measured at
+  // N=200000, 64 x 32: 782 workgroups of 512 rows 80 us, 392 of 1024 rows 59 us, 196 of 2048 rows 48 us), never below
+  // GRAM_MIN_ROWS; a multiple of 128 (four waves x steps of 32 rows)
+  const int64_t want_chunks = std::max<int64_t>(1, wg_target / ((int64_t)ptiles * qtiles));
+  int64_t rows = (nrows_pad + want_chunks - 1) / want_chunks;
+  rows = std::max<int64_t>(GRAM_MIN_ROWS, (rows + 127) / 128 * 128);
+  const int rows_per_wg = (int)rows;
   const int nchunks = (int)((nrows_pad + rows_per_wg - 1) / rows_per_wg);
   // last-workgroup finish where the sum over the chunks is short and a second launch is what costs (<= GRAM_FUSE_CHUNKS row
   // chunks, one counter per output tile); the two-kernel route where hundreds of chunks want more than one workgroup per tile
@@ -234,13 +240,14 @@ static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int 
 
 // counters: GRAM_MAX_COUNTERS zeroed device words (nullptr: always the two-kernel route)
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters) {
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters, int wg_target) {
   int ppad = pad16(p), qpad = pad16(q);
+  if (wg_target <= 0) wg_target = 256;
   // register tile of a wave: 32 x 32 (64 accumulators), 32 x 16, 16 x 16 columns
   if (p > 16 && q > 16)
-    launch_gram_tiles<8, 8, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
+    launch_gram_tiles<8, 8, 3>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters, wg_target);
   else if (p > 16)
-    launch_gram_tiles<8, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
+    launch_gram_tiles<8, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters, wg_target);
   else
-    launch_gram_tiles<4, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters);
+    launch_gram_tiles<4, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters, wg_target);
 }

@@ -25,7 +25,6 @@ size_t matvec_slab_doubles(int64_t nrows_pad, int ngroups, int nsplit);
 void matvec_plan(int64_t nrows_pad, int64_t ncols_pad, int ngroups, int* nsplit, int* jc, int64_t target = 0, int64_t forced_nsplit = 0);
 
 // ---- K2: tall-skinny Gram ------------------------------------------------------------------------
-constexpr int GRAM_ROWS = 1024;   // rows per workgroup at most (4 waves x 256) ...
 constexpr int GRAM_MIN_ROWS = 256; // ... and at least (small problems: more, shorter workgroups)
 // out (p x q, column-major ld = p) = P^T Q over nrows_pad rows (multiple of 16; pad rows are zero).
 // scratch must hold gram_scratch_doubles(...) doubles.  Deterministic two-stage reduction.
@@ -34,7 +33,7 @@ constexpr int GRAM_MIN_ROWS = 256; // ... and at least (small problems: more, sh
 constexpr int GRAM_FUSE_CHUNKS = 24;
 constexpr int GRAM_MAX_COUNTERS = 256;
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr);
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr, int wg_target = 0);
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
 
 // ---- K3/K4/K5: panel x small matrix ---------------------------------------------------------------
