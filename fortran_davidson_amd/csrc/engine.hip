@@ -92,8 +92,17 @@ int small_upload_multi(E* e, int i, SmallMat* mats, int n) {
     double* dst = b.host + off;
     if (mt.image) {
       mt.ldm = pg_image_tiles(mt.q);
-      for (int j = 0; j < mt.q; ++j)
-        for (int r = 0; r < mt.p; ++r) dst[pg_image_index(r, j, mt.ldm)] = mt.src[j * mt.ld + r];
+      // in the order of the image: per step (4 rows) and tile (16 columns) the 64 entries a wave loads are contiguous
+      const int nstep = (mt.p + 3) / 4, ntile = (mt.q + 15) / 16;
+      for (int s = 0; s < nstep; ++s)
+        for (int t = 0; t < ntile; ++t) {
+          double* blk = dst + ((int64_t)s * mt.ldm + t) * 64;
+          const int gmax = std::min(4, mt.p - 4 * s), cmax = std::min(16, mt.q - 16 * t);
+          for (int g = 0; g < gmax; ++g) {
+            const double* col = mt.src + (int64_t)(16 * t) * mt.ld + 4 * s + g;
+            for (int c = 0; c < cmax; ++c) blk[16 * g + c] = col[(int64_t)c * mt.ld];
+          }
+        }
     } else {
       mt.ldm = roundup(std::max(mt.p, 1), 4);
       for (int j = 0; j < mt.q; ++j) std::memcpy(dst + j * mt.ldm, mt.src + j * mt.ld, sizeof(double) * mt.p);
