@@ -63,6 +63,13 @@ def generate(n, sparsity, seed=1, diag_val=None):
     return a
 
 
+def stream_sum(a):
+    """sum of all entries under OpenMP (ref_driver.f90: ref_stream_sum) - a parallel read of the matrix, for its GB/s"""
+    out = C.c_double(0.0)
+    lib().ref_stream_sum(C.c_int(a.shape[0]), _p(a), C.byref(out))
+    return out.value
+
+
 def free_solve_harness(n, lowest, max_it=1000, tol=1e-8, max_dim=20):
     """Reference matrix-free solve with its own test operators (tests/test_utils.f90:11-116)."""
     evals = np.zeros(lowest)

@@ -229,3 +229,25 @@ subroutine ref_generate(n, sparsity, seed, has_diag, diag_val, a) bind(C)
   end do
   !$omp end parallel do
 end subroutine ref_generate
+
+
+!> What the host memory system delivers to a plain parallel read of the same matrix (sum of all entries under OpenMP, the
+!> static schedule that first touched it): the yardstick next to MKL's DGEMV rate in bench.py's cpu_baseline.  Not reference code.
+subroutine ref_stream_sum(n, a, total) bind(C)
+  use iso_c_binding
+  implicit none
+  integer(c_int), value :: n
+  real(c_double), intent(in) :: a(n, n)
+  real(c_double), intent(out) :: total
+  real(c_double) :: s
+  integer :: i, j
+  s = 0.0_c_double
+  !$omp parallel do schedule(static) private(i) reduction(+:s)
+  do j = 1, n
+     do i = 1, n
+        s = s + a(i, j)
+     end do
+  end do
+  !$omp end parallel do
+  total = s
+end subroutine ref_stream_sum
