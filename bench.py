@@ -164,6 +164,30 @@ print("CPU_BASELINE " + json.dumps(out))
 """
 
 
+def cpu_share():
+    """CPUs this process may really use: the affinity mask, cut down by the cgroup's CPU quota (the GPU boxes hand a job a share of
+    the host - 16 CPUs per GPU - while os.cpu_count() and MKL still see all 256 hardware threads: 128 MKL threads on a 16-CPU
+    quota is what made the round-3 baseline crawl at 30-40 GB/s)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, per = float(f1.read()), float(f2.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(n_list, lowest, tol, sparsity):
     """The reference's own CPU+LAPACK path (oracle/_ref = the reference compiled with flang + MKL) on generate_diagonal_dominant
     inputs, timed in a child process that never touches the GPU, never imports torch (its libgomp breaks threaded MKL) and never
@@ -173,10 +197,16 @@ def cpu_baseline(n_list, lowest, tol, sparsity):
         code = CPU_CHILD.format(root=ROOT, lowest=lowest, tol=tol, sparsity=sparsity, n_list=list(n_list))
         env = dict(os.environ)
         env["HIP_VISIBLE_DEVICES"] = ""
+        share, quota = cpu_share()
+        for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):              # as many threads as CPUs the job really has
+            env[var] = str(share)
         res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1200, env=env)
         for line in res.stdout.splitlines():
             if line.startswith("CPU_BASELINE "):
-                return json.loads(line[len("CPU_BASELINE "):])
+                out = json.loads(line[len("CPU_BASELINE "):])
+                out["cpu_share"] = share
+                out["cgroup_cpu_quota"] = quota
+                return out
         return {"error": (res.stderr or res.stdout)[-400:]}
     except Exception as exc:       # noqa: BLE001
         return {"error": repr(exc)}
@@ -205,6 +235,28 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
         return row["hbm_bytes_per_launch_corrected"], prov
     except Exception:      # noqa: BLE001
         return None, None
+
+
+def scaling_model(n, lowest, world):
+    """Predicted milliseconds per configs[2] solve on `world` GPUs for both storages of the operator (nothing in
+    it has been measured on more than one GPU).  One-GPU inputs (round 4, N=200000, lowest=16: one 32- and one 64-column block per
+    solve): symmetric sweeps end to end 122.0 ms per solve (kernel 116.5 + pack / fixed-order reduction 5.5) - their tiles are
+    dealt out to within 0.1 %, so they divide by the rank count; a full row slab streams 8 N^2 / P bytes per sweep at the K1
+    rates measured at N=20000 (k = 32: 0.624 of 8 TB/s end to end; k = 64: bound by the fp64 matrix pipe, 57.8 TFLOP/s);
+    Gram / panel phases + host 2.9 ms of which 1.0 ms does not shrink; collectives priced as rings at 70 GB/s per xGMI link and
+    direction (7 links per GPU), small all-reduces 50 us each."""
+    scale = (n / 200000.0) ** 2
+    P = max(world, 1)
+    sym_sweeps = 122.0 * scale / P
+    full32 = 8.0 * n * n / P / (0.624 * 8.0e12) * 1e3
+    full64 = max(8.0 * n * n / P / (0.66 * 8.0e12), 2.0 * n * n * 64 / P / 57.8e12) * 1e3
+    block_bytes = 8.0 * n * (32 + 64)
+    ring = 0.0 if P == 1 else block_bytes * (P - 1) / P / 70.0e9 * 1e3          # one all-gather (or one reduce-scatter) of the blocks
+    other = 1.0 + 1.9 * scale ** 0.5 / P + (0.0 if P == 1 else 0.05 * 10)
+    return {"symmetric_ms": round(sym_sweeps + 2 * ring + other, 2), "symmetric_overlapped_ms": round(sym_sweeps + 2 * ring / 3 + other, 2),
+            "full_ms": round(full32 + full64 + ring + other, 2),
+            "note": "model, not a measurement: symmetric = dealt-out tiles (all-gather + reduce-scatter per block), overlapped = their "
+                    "collectives on a second stream (about two thirds hidden under the 64-column block), full = row slabs (all-gather only, twice the bytes per sweep)"}
 
 
 def self_launch(args):
@@ -343,7 +395,15 @@ def main():
     hbm_measured = measured_stream() if rank == 0 or world > 1 else None
     stream_gbps = max(hbm_measured.get("copy_GBps", 0.0), hbm_measured.get("triad_GBps", 0.0)) if hbm_measured else 0.0
 
-    storage = args.storage if args.storage != "auto" else "symmetric"
+    # auto: the storage the model of DESIGN section 6 predicts to be the faster one for this rank count (symmetric tiles for every
+    # P up to 8 at the timed size; the full row slabs of north_star's partition are `--storage full`)
+    if args.storage != "auto":
+        storage = args.storage
+    else:
+        mdl = scaling_model(args.n, args.lowest, world)
+        storage = "symmetric" if world == 1 or min(mdl["symmetric_ms"], mdl["symmetric_overlapped_ms"]) <= mdl["full_ms"] else "full"
+        if storage == "full" and 8.0 * args.n * args.n / world > 200e9:
+            storage = "symmetric"          # a full row slab of this size does not fit the GPU
     storage_words = {"symmetric": "symmetric-tiled (lower block triangle, N(N+1)/2 entries" +
                                   (f", dealt out over the {world} ranks by groups of 4 block rows" if world > 1 else "") + ")",
                      "full": "full row slabs"}[storage]
@@ -442,6 +502,7 @@ def main():
             "reduce_scatter_ms_per_solve": round(sc.reduce_scatter_ms, 3), "reduce_scatter_MB_per_solve": round(sc.reduce_scatter_bytes / 1e6, 2),
             "allreduce_ms_per_solve": round(sc.allreduce_ms, 3), "allreduce_MB_per_solve": round(sc.allreduce_bytes / 1e6, 3),
             "sweep_kernel_ms_per_solve": round(sc.apply_kernel_ms, 3), "apply_ms_end_to_end_per_solve": round(sc.apply_ms, 3),
+            "model_ms_per_solve": scaling_model(n, lowest, world),
             "note": "rank 0's view of one solve; payload per rank (all-gather: bytes received, reduce-scatter: bytes contributed); with "
                     "overlapped collectives their time runs under the sweeps and is not additive to apply_ms"}
     if not args.headline_only:
@@ -685,11 +746,13 @@ def main():
                         "kind": raw["kind"], "seconds": round(r0["seconds"], 3), "iters": r0["iters"],
                         "seconds_first_call": round(r0.get("seconds_first_call", r0["seconds"]), 3),
                         "sockets": raw.get("sockets"), "numa_nodes": raw.get("numa_nodes"), "logical_cpus": raw.get("logical_cpus"),
+                        "cpus_available_to_this_job": raw.get("cpu_share"), "cgroup_cpu_quota": raw.get("cgroup_cpu_quota"),
                         "cpu_model": raw.get("cpu_model"),
                         "sample": f"one full solve (the second of two: the first warms MKL up) at N={cn}, lowest=8, DPR, tol={args.tol} (the configs[1] problem - the timed "
                                   "N=200000 matrix needs 320 GB in the reference's full storage and (m+1) sweeps of it per iteration) "
-                                  "by the reference built with flang+MKL (oracle/_ref), all host threads; the matrix is generated in the child under "
-                                  "OpenMP (parallel first touch: its pages are spread over the NUMA nodes)",
+                                  "by the reference built with flang+MKL (oracle/_ref) on as many MKL / OpenMP threads as this job has CPUs (cores: the "
+                                  "affinity mask cut down by the cgroup quota - the box shows 256 hardware threads, a one-GPU job gets a share of "
+                                  "them); the matrix is generated in the child under OpenMP (parallel first touch)",
                         "max_abs_eigenvalue_diff_vs_gpu": float(np.abs(np.array(r0["evals"][:3]) - np.array(extras["small"]["eigenvalues"])).max())
                         if cn == args.small_n and "eigenvalues" in extras.get("small", {}) else None}
                     cb = extras["cpu_baseline"]

@@ -1,0 +1,32 @@
+#!/bin/bash
+# rocprofv3 passes of the timed workload (bench.py --headline-only): kernel stats, FETCH_SIZE, WRITE_SIZE, MFMA busy - separate runs;
+# and the same three for the configs[1] shape (N=20000, full storage) as the headline of a second set
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r04
+rm -rf $O && mkdir -p $O
+cd $R
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o headline -- python3 bench.py --headline-only --steps 3 --warmup 1 > $O/stats.log 2>&1
+echo stats done
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- python3 bench.py --headline-only --steps 1 --warmup 0 > $O/fetch.log 2>&1
+echo fetch done
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- python3 bench.py --headline-only --steps 1 --warmup 0 > $O/write.log 2>&1
+echo write done
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/mfma -o m -- python3 bench.py --headline-only --steps 1 --warmup 0 > $O/mfma.log 2>&1
+echo mfma done
+S="--headline-only --order 20000 --lowest 8 --max-dim 80 --storage full"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/s_stats -o small -- python3 bench.py $S --steps 20 --warmup 3 > $O/s_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/s_fetch -o f -- python3 bench.py $S --steps 3 --warmup 0 > $O/s_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/s_write -o w -- python3 bench.py $S --steps 3 --warmup 0 > $O/s_write.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/s_mfma -o m -- python3 bench.py $S --steps 3 --warmup 0 > $O/s_mfma.log 2>&1
+echo small done
+du -sh $O
+# K2 / K3 on their own (the microbenchmark of profiles/tools/small_kernels.py at N=200000): kernel stats + the two traffic passes
+K="profiles/tools/small_kernels.py 200000"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k_stats -o k -- python3 $K > $O/k_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/k_fetch -o f -- python3 $K > $O/k_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/k_write -o w -- python3 $K > $O/k_write.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/k_mfma -o m -- python3 $K > $O/k_mfma.log 2>&1
+echo k2k3 done
+du -sh $O
