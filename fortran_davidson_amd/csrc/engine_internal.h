@@ -231,6 +231,7 @@ struct dav_engine {
   bool ev_done[N_EVPAIRS];        // end event recorded (a call that fails between begin and end leaves a pair without one)
   int ev_used = 0, ev_open = 0;
   int timing_level = 1;           // 0 = nothing, 1 = block matvec only, 2 = every phase
+  bool lazy_x = false;            // dav_set_lazy_ritz_vectors: the Ritz phases compute X only for GJD
 };
 typedef dav_engine E;
 

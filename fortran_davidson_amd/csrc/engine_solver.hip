@@ -168,15 +168,18 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
 
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
-  // X = V * Y(:, 1:nx)
+  // X = V * Y(:, 1:nx) - unless the caller asked for the Ritz vectors only at the end (dav_set_lazy_ritz_vectors) and the
+  // correction does not read them (DPR, or no correction at all)
   int nx = method == DAV_METHOD_GJD ? ncorr : lowest;
-  PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = dY; a.tp1 = ldm_y;
-  a.p2 = 0;
-  a.out = panel_ptr(e, DAV_PANEL_X, 0); a.ldo = e->ldp; a.q = nx;
-  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
-  a.pin = e->tune.pg_pin;
-  launch_panel_gemm(e->stream, a);
+  if (!(e->lazy_x && method != DAV_METHOD_GJD && !dev)) {
+    PanelGemmArgs a{};
+    a.P1 = panel_ptr(e, DAV_PANEL_V, 0); a.ld1 = e->ldp; a.p1 = m; a.M1 = dY; a.tp1 = ldm_y;
+    a.p2 = 0;
+    a.out = panel_ptr(e, DAV_PANEL_X, 0); a.ldo = e->ldp; a.q = nx;
+    a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
+    a.pin = e->tune.pg_pin;
+    launch_panel_gemm(e->stream, a);
+  }
   // R = W*Y + Z*(-Y*diag(theta)), norms, (DPR) T
   PanelGemmArgs r{};
   r.P1 = panel_ptr(e, DAV_PANEL_W, 0); r.ld1 = e->ldp; r.p1 = m; r.M1 = dY; r.tp1 = ldm_y;
@@ -232,6 +235,16 @@ int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, 
   }
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+extern "C" int dav_set_lazy_ritz_vectors(dav_handle_t e, int on) {
+  e->lazy_x = on != 0;
+  return 0;
+}
+
+extern "C" int dav_ritz_vectors(dav_handle_t e, int m, int nx, const double* Y, int64_t ldy) {
+  if (m <= 0 || nx <= 0 || nx > m || ldy < m) return fail("dav_ritz_vectors: bad shape");
+  return dav_panel_transform(e, DAV_PANEL_V, 0, m, Y, ldy, nx, DAV_PANEL_X, 0);
 }
 
 extern "C" int dav_ritz_residual_correction(dav_handle_t e, int m, int lowest, const double* Y, int64_t ldy,

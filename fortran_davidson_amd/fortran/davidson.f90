@@ -403,7 +403,7 @@ contains
     integer(c_int64_t), allocatable :: idx(:)
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
     logical, allocatable :: has_converged(:)
-    logical :: host_ops, done
+    logical :: host_ops, done, lazy_x
     real(dp) :: t0, t1, phase_s(8)
 
     phase_s = 0.0_dp
@@ -436,6 +436,11 @@ contains
     drr = .false.
     if (present(device_rr)) drr = device_rr .and. cap <= 128
     call check_dav(dav_rr_enable(h, merge(1_c_int, 0_c_int, drr)), "dav_rr_enable")
+    ! The Ritz vectors are what the caller gets back at the end (src/davidson.f90:186-187); the DPR correction never reads them:
+    ! they are made once, when the loop stops (finish_ritz_vectors), not in every iteration.  GJD needs x_k for its correction
+    ! solves and the device-side Rayleigh-Ritz keeps Y on the device: both compute X in the Ritz phase as before.
+    lazy_x = (.not. drr) .and. meth /= DAV_METHOD_GJD
+    call check_dav(dav_set_lazy_ritz_vectors(h, merge(1_c_int, 0_c_int, lazy_x)), "dav_set_lazy_ritz_vectors")
 
     ! 1. initial basis: unit vectors at the lowest diagonal entries; W0 = A*V0
     m = initial_dimension
@@ -495,6 +500,7 @@ contains
              if (done) then
                 eigenvalues = theta(1:lowest)
                 iters = i
+                call finish_ritz_vectors()
                 exit outer_loop
              end if
           end if
@@ -553,6 +559,7 @@ contains
        ! results) - enforced, so that a diverged rank stops with a message instead of hanging its peers
        call check_dav(dav_ranks_agree(h, [real(i, dp), real(m, dp), merge(1.0_dp, 0.0_dp, done), &
             merge(1.0_dp, 0.0_dp, expand_now), real(ncorr, dp)], 5_c_int), "dav_ranks_agree")
+       if (done .or. i == max_iterations) call finish_ritz_vectors()     ! the last Ritz pairs are what a non-converged solve returns
        if (done) then
           iters = i
           exit outer_loop
@@ -565,7 +572,10 @@ contains
              ! left: with m + kt > n the reference stops in DORGQR (src/lapack_wrapper.f90:176-236); here the
              ! leading n - m corrections complete the basis and the next Ritz problem is exact
              kt = min(m, n - m)
-             if (kt <= 0) exit outer_loop                ! V already spans everything (unreachable: exact Ritz pairs converge)
+             if (kt <= 0) then                           ! V already spans everything (unreachable: exact Ritz pairs converge)
+                call finish_ritz_vectors()
+                exit outer_loop
+             end if
              if (meth == DAV_METHOD_GJD) then
                 ! the wanted pairs are solved to 1e-10 (what makes the outer iteration count equal to the
                 ! reference's exact solves); the other m - lowest corrections only enrich the basis
@@ -580,7 +590,10 @@ contains
           else
              ! only the wanted pairs that have not converged: keep their columns, drop the others
              kt = min(count(errors >= tolerance), n - m, cap - m)   ! cap - m: max_dim_sub < 2*lowest leaves cap = 2*lowest
-             if (kt <= 0) exit outer_loop
+             if (kt <= 0) then
+                call finish_ritz_vectors()
+                exit outer_loop
+             end if
              if (allocated(sel)) deallocate(sel, theta_sel)
              allocate(sel(kt), theta_sel(kt))
              kt = 0
@@ -673,8 +686,15 @@ contains
             " ms[setup rr ritz ortho apply project restart gjd]=", phase_s * 1.0e3_dp
     end if
     if (present(phase_seconds)) phase_seconds = phase_s
+    call check_dav(dav_set_lazy_ritz_vectors(h, 0_c_int), "dav_set_lazy_ritz_vectors")
 
   contains
+
+    !> X(:, 1:lowest) = V(:, 1:m) * Y(:, 1:lowest) for the Ritz pairs of this iteration (see lazy_x above)
+    subroutine finish_ritz_vectors()
+      if (lazy_x) call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), y, int(size(y, 1), c_int64_t)), &
+           "dav_ritz_vectors")
+    end subroutine finish_ritz_vectors
 
     subroutine lap(slot)
       integer, intent(in) :: slot

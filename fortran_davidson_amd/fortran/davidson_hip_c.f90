@@ -205,6 +205,20 @@ module davidson_hip_c
        real(c_double), intent(out) :: resnorm(*), c(*), g(*)
        integer(c_int) :: ierr
      end function
+     function dav_set_lazy_ritz_vectors(h, on) bind(C, name="dav_set_lazy_ritz_vectors") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: on
+       integer(c_int) :: ierr
+     end function
+     function dav_ritz_vectors(h, m, nx, y, ldy) bind(C, name="dav_ritz_vectors") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, nx
+       real(c_double), intent(in) :: y(*)
+       integer(c_int64_t), value :: ldy
+       integer(c_int) :: ierr
+     end function
      function dav_panel_select(h, panel, c0, nsel, sel) bind(C, name="dav_panel_select") result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: h

@@ -196,6 +196,13 @@ int dav_panel_select(dav_handle_t h, int panel, int c0, int nsel, const int* sel
  * same fetch as the residual norms: one host-device round trip less per iteration. */
 int dav_ritz_residual_correction_g(dav_handle_t h, int m, int ncorr, int lowest, const double* Y, int64_t ldy,
                                    const double* theta, double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg);
+/* The Ritz vectors X = V*Y(:, 0:lowest) are what the caller gets back at the END (src/davidson.f90:186-187); the DPR correction
+ * never reads them.  dav_set_lazy_ritz_vectors(h, 1): the Ritz phases above leave X alone unless the method is GJD (whose
+ * correction solve needs x_k), and the driver asks for them once, when it stops: dav_ritz_vectors(h, m, nx, Y, ldy) makes
+ * X[:, 0:nx] = V[:, 0:m] * Y(:, 0:nx).  One panel product (m + nx columns of N rows) and one launch less per outer iteration.
+ * Default 0: every Ritz phase computes X, as documented above. */
+int dav_set_lazy_ritz_vectors(dav_handle_t h, int on);
+int dav_ritz_vectors(dav_handle_t h, int m, int nx, const double* Y, int64_t ldy);
 /* K7 - replaces compute_GJD_generalized_dense (src/davidson.f90:700-734): solves
  * (I - x x^T)(A - theta_k B)(I - x x^T) t_k = -r_k for all m Ritz pairs at once with a block
  * preconditioned MINRES whose operator is the K1 block matvec; T goes to V[:, m:2m]. */
