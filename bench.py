@@ -151,6 +151,12 @@ if ref.available():
         for _ in range(5):
             ref.stream_sum(A)
         run["openmp_read_GBps"] = 8.0 * n * n * 5 / (time.perf_counter() - t) / 1e9
+        yo = ref.gemv_omp(A, x)
+        t = time.perf_counter()
+        for _ in range(5):
+            yo = ref.gemv_omp(A, x)
+        run["openmp_gemv_GBps"] = 8.0 * n * n * 5 / (time.perf_counter() - t) / 1e9
+        run["openmp_gemv_max_rel_diff_vs_mkl"] = float(np.abs(yo - y).max() / np.abs(y).max())
         out["runs"].append(run)
         print("CPU_BASELINE_PROGRESS", n, round(dt, 2), flush=True)
         del A
@@ -767,22 +773,26 @@ def main():
                                       "GBps_if_all_time_were_sweeps": round(sweeps * 8.0 * r["n"] * r["n"] / r["seconds"] / 1e9, 1),
                                       "dgemv_sweep_GBps": round(r.get("dgemv_sweep_GBps", 0.0), 1),
                                       "dgemv_transposed_GBps": round(r.get("dgemv_transposed_GBps", 0.0), 1),
-                                      "openmp_read_GBps": round(r.get("openmp_read_GBps", 0.0), 1), "generate_seconds": r.get("generate_seconds")})
+                                      "openmp_read_GBps": round(r.get("openmp_read_GBps", 0.0), 1),
+                                      "openmp_gemv_GBps": round(r.get("openmp_gemv_GBps", 0.0), 1), "generate_seconds": r.get("generate_seconds")})
                     cb["by_order"] = per_n
                     if "dgemv_sweep_GBps" in r0:
                         cb["dgemv_sweep_GBps"] = round(r0["dgemv_sweep_GBps"], 1)
                         cb["dgemv_note"] = ("MKL DGEMV 'N' (what lapack_matrix_vector calls, src/lapack_wrapper.f90:362) on a matrix whose pages were first "
-                                            "touched in parallel; by_order also carries the transposed form and a plain OpenMP read of the same "
-                                            "matrix: the gap between them and the 'N' rate is MKL's threading of that call, not page placement")
+                                            "touched in parallel, on the job's CPUs; by_order also carries the transposed form, a plain OpenMP read and a "
+                                            "plain OpenMP matrix-vector product of the same matrix: where the last two are several times the DGEMV "
+                                            "rate, what holds the reference back on this host is MKL's DGEMV itself, not page placement or the thread count")
                         bw = max(r.get("dgemv_sweep_GBps", 0.0) for r in runs)
                         w2 = [2 * lowest * 2 ** i for i in range(total_iters // args.steps)]
                         s2 = sum(m + 1 for m in w2)
                         est = s2 * 8.0 * float(n) * float(n) / (bw * 1e9)
+                        bw_omp = max(r.get("openmp_gemv_GBps", 0.0) for r in runs)
                         cb["extrapolation_to_timed_workload"] = {
                             "N": n, "lowest": lowest, "basis_widths": w2, "sweeps_of_A": s2, "bytes_per_sweep": 8.0 * float(n) * float(n),
                             "dgemv_rate_used_GBps": round(bw, 1),
                             "seconds_per_solve_at_measured_dgemv_rate": round(est, 1),
                             "iterations_per_s": round((total_iters // args.steps) / est, 5),
+                            "seconds_per_solve_if_the_sweeps_ran_at_the_openmp_gemv_rate": round(s2 * 8.0 * float(n) * float(n) / (bw_omp * 1e9), 1) if bw_omp > 0 else None,
                             "assumption": "the reference's (m+1) sweeps of A per iteration (m DGEMVs for the residues + 1 DGEMM, src/davidson.f90:163-170,223) "
                                           "at the best DGEMV rate measured above on these cores, full storage (320 GB - would have to fit host memory); "
                                           "QR and the small eigenproblem not counted; by_order shows how the measured solves compare with that sweep model"}

@@ -70,6 +70,13 @@ def stream_sum(a):
     return out.value
 
 
+def gemv_omp(a, x):
+    """y = A x under OpenMP (ref_driver.f90: ref_gemv_omp): the yardstick next to MKL's DGEMV in the CPU baseline"""
+    y = np.zeros(a.shape[0])
+    lib().ref_gemv_omp(C.c_int(a.shape[0]), _p(a), _p(np.ascontiguousarray(x, dtype=np.float64)), _p(y))
+    return y
+
+
 def free_solve_harness(n, lowest, max_it=1000, tol=1e-8, max_dim=20):
     """Reference matrix-free solve with its own test operators (tests/test_utils.f90:11-116)."""
     evals = np.zeros(lowest)

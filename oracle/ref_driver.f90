@@ -251,3 +251,30 @@ subroutine ref_stream_sum(n, a, total) bind(C)
   !$omp end parallel do
   total = s
 end subroutine ref_stream_sum
+
+
+!> y = A x for a column-major n x n matrix under OpenMP (every thread owns a contiguous range of rows and walks all columns):
+!> what a sweep of A costs on these cores when the BLAS does not get in the way - the second yardstick next to MKL's DGEMV in
+!> bench.py's cpu_baseline (on the AMD hosts of the GPU boxes MKL's DGEMV runs at a seventh of the rate a plain parallel read
+!> of the same matrix reaches).  Not reference code.
+subroutine ref_gemv_omp(n, a, x, y) bind(C)
+  use iso_c_binding
+  implicit none
+  integer(c_int), value :: n
+  real(c_double), intent(in) :: a(n, n), x(n)
+  real(c_double), intent(out) :: y(n)
+  integer :: i, j, i0, i1, t, nt
+  integer, external :: omp_get_thread_num, omp_get_num_threads
+  !$omp parallel private(i, j, i0, i1, t, nt)
+  t = omp_get_thread_num()
+  nt = omp_get_num_threads()
+  i0 = int(int(n, 8) * t / nt) + 1
+  i1 = int(int(n, 8) * (t + 1) / nt)
+  y(i0:i1) = 0.0_c_double
+  do j = 1, n
+     do i = i0, i1
+        y(i) = y(i) + a(i, j) * x(j)
+     end do
+  end do
+  !$omp end parallel
+end subroutine ref_gemv_omp
