@@ -576,9 +576,11 @@ int sym_resident_split(E* e, int which) {
   const double tile_bytes = 8.0 * SYM_TB * SYM_TB;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  // what the sweeps may still allocate: slabs of the widest launch (four column groups of the two-block-row schedule), the fp32 copy
+  // what the sweeps may still allocate: the slabs of a paired 32-column launch of the two-block-row schedule (a 64-column launch
+  // that then finds no room for its four column groups runs as two paired launches - 1 % slower on that sweep, which is far less
+  // than what the extra resident block rows save on every sweep of this operator), the fp32 copy
   const SymPlan& p2 = e->sym.plan[0];
-  const double slabs = 4.0 * 8.0 * 16.0 * SYM_TB * ((double)p2.nitems * 2 + (double)p2.zslots);
+  const double slabs = 2.0 * 8.0 * 16.0 * SYM_TB * ((double)p2.nitems * 2 + (double)p2.zslots);
   double reserve = std::max(0.0, slabs - 8.0 * (double)e->sym_slab_doubles) + 0.01 * (double)total_b + 2.0e9;
   const OpDesc& a = e->op[DAV_OP_A];
   if (e->inner_bits == 32 && a.kind == DAV_KIND_DENSE && a.storage == 1 && !a.a32) reserve += 4.0 * SYM_TB * SYM_TB * (double)e->sym.ntiles;
