@@ -511,6 +511,9 @@ def main():
             "model_ms_per_solve": scaling_model(n, lowest, world),
             "note": "rank 0's view of one solve; payload per rank (all-gather: bytes received, reduce-scatter: bytes contributed); with "
                     "overlapped collectives their time runs under the sweeps and is not additive to apply_ms"}
+        # the scalars also inside `roofline` (the driver's record keeps the scalars of that object)
+        roofline.update({"comm_" + k_: v_ for k_, v_ in extras["comm"].items() if isinstance(v_, (int, float, bool, str)) and k_ != "note"})
+        roofline.update({"comm_model_" + k_: v_ for k_, v_ in extras["comm"]["model_ms_per_solve"].items() if k_ != "note"})
     if not args.headline_only:
         # opt-in correction policy (not the reference's, so never part of `value`)
         eng.set_correction_policy("unconverged")

@@ -172,3 +172,78 @@ def test_buffer_descriptors_are_not_fresh_from_the_valu(kernels):
                 if b.startswith(("v_readfirstlane", "v_readlane", "v_cmp")):
                     _, bops = _operands(b)
                     assert not (sregs(bops[0]) & read), (name, b, c)
+
+
+def test_small_kernels_keep_their_accumulators_in_place_and_their_loops_pipelined():
+    """K2 / K3 (plain-HIP MFMA kernels, k_gram.hip / k_panel.hip) as the Makefile builds them: (1) the panel kernel moves nothing
+    between the register halves (the compiler's default form copied all 64 accumulators around every 8 MFMAs: round 3); (2) in
+    the pinned variant of its k loop the first wait of a round lets more loads stay in flight than one step issues - the loads
+    of later steps are NOT waited for, i.e. the loop is a software pipeline; (3) its small-matrix operand comes in as 8-byte
+    loads at a common stride (the operand image) - one per column tile and step; (4) no scratch anywhere."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    mk = open(os.path.join(ROOT, "fortran_davidson_amd", "csrc", "Makefile")).read()
+    flags = re.search(r"FLAGS_k_panel\s*=\s*(.*)", mk).group(1).split()
+    assert "-amdgpu-mfma-vgpr-form=1" in flags and re.search(r"FLAGS_k_gram\s*=\s*(.*)", mk).group(1).split() == flags
+    for src, kernel_prefix in (("k_panel.hip", "_Z17panel_gemm_kernel"), ("k_gram.hip", "_Z11gram_kernel")):
+        res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), *flags, "-S",
+                              "--cuda-device-only", os.path.join(ROOT, "fortran_davidson_amd", "csrc", src), "-o", "-"],
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        asm = res.stdout
+        kernels = {}
+        cur = None
+        for ln in asm.splitlines():
+            m = re.match(r"^(" + kernel_prefix + r"\w+):", ln)
+            if m:
+                cur = kernels.setdefault(m.group(1), [])
+                continue
+            if cur is not None:
+                cur.append(ln)
+                if "s_endpgm" in ln:
+                    cur = None
+        assert len(kernels) >= 3, list(kernels)
+        for name, body in kernels.items():
+            text = "\n".join(body)
+            assert "scratch_" not in text, name
+            if src == "k_panel.hip":
+                assert "v_accvgpr" not in text, name
+        assert ".private_segment_fixed_size: 0" in asm and not re.search(r"\.private_segment_fixed_size:\s+[1-9]", asm)
+    # the pinned QT = 4 panel kernel: find its main loop (the inner loop with the most MFMAs)
+    name = next(k for k in kernels_of_panel(ROOT, flags) if "ILi4ELi8ELb1" in k)
+    body = kernels_of_panel(ROOT, flags)[name]
+    loops, cur = [], None
+    for ln in body:
+        if "Inner Loop Header" in ln:
+            cur = []
+        if cur is not None:
+            cur.append(ln)
+            if re.search(r"s_cbranch_\w+\s+\.LBB", ln):
+                loops.append(cur)
+                cur = None
+    main = max(loops, key=lambda l: sum("v_mfma_f64_16x16x4" in x for x in l))
+    assert sum("v_mfma_f64_16x16x4" in x for x in main) == 64          # a round of 8 steps x 8 MFMAs
+    assert sum("global_load_dwordx4" in x for x in main) == 8 and sum("global_load_dwordx2" in x for x in main) == 32
+    waits = [int(m.group(1)) for x in main for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
+    assert waits and min(waits) >= 20, waits                           # never a drain: >= 4 steps of loads stay in flight
+
+
+_PANEL_CACHE = {}
+
+
+def kernels_of_panel(root, flags):
+    if not _PANEL_CACHE:
+        res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"), *flags, "-S",
+                              "--cuda-device-only", os.path.join(root, "fortran_davidson_amd", "csrc", "k_panel.hip"), "-o", "-"],
+                             capture_output=True, text=True, timeout=600)
+        cur = None
+        for ln in res.stdout.splitlines():
+            m = re.match(r"^(_Z17panel_gemm_kernel\w+):", ln)
+            if m:
+                cur = _PANEL_CACHE.setdefault(m.group(1), [])
+                continue
+            if cur is not None:
+                cur.append(ln)
+                if "s_endpgm" in ln:
+                    cur = None
+    return _PANEL_CACHE
