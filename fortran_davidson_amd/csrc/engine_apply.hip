@@ -88,6 +88,11 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     e->ov_ready = true;
   }
   const int64_t total_rows = (int64_t)e->nranks * e->nslab;
+  // Test transports (loopback threads / shared-memory processes on one GPU, DAV_SYM_OVERLAP=1): the same pipeline - buffers, chunk
+  // parities, layouts, counts, with SEVERAL ranks - with its collectives executed by the transport on the engine's own stream
+  // (they synchronise the host); what the multi-rank RCCL run cannot be rehearsed for on a one-GPU box is only the overlap itself
+  const bool tt = has_test_transport(e);
+  hipStream_t cs = tt ? e->stream : e->comm_stream;
   const bool use32 = false;                            // chunks of 32 columns: the fp64 tiles on the wide kernel (see apply_ptr)
   const int R = 2;                                     // 32-column chunks: the paired two-block-row schedule
   const SymPlan* pl = &e->sym.plan[0];
@@ -102,15 +107,16 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     const int p = i & 1, kk = cols(i), ng = (kk + 15) / 16;
     launch_pack_xt(e->stream, src + (int64_t)i * step * e->ldp, e->ldp, e->nloc, e->nslab, kk, xt_of(i), e->xt_group_stride, e->row0);
     HIPCHK(hipEventRecord(e->ov_packed[p], e->stream));
-    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_packed[p], 0));
+    HIPCHK(hipStreamWaitEvent(cs, e->ov_packed[p], 0));
     CollGroup grp(e);
-    CHK(grp.begin(5, 8.0 * (double)e->nslab * 16 * ng * e->nranks, e->comm_stream));
+    CHK(grp.begin(5, 8.0 * (double)e->nslab * 16 * ng * e->nranks, cs));
     for (int g = 0; g < ng; ++g) {
       double* base = xt_of(i) + (size_t)g * e->xt_group_stride;
-      NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, e->comm_stream));
+      if (tt) CHK(test_allgather(e, base + e->row0 * 16, base, (size_t)e->nslab * 16));
+      else NCCLCHK(g_rccl.AllGather(base + e->row0 * 16, base, (size_t)e->nslab * 16, ncclDouble, e->comm, cs));
     }
-    CHK(grp.end("all-gather of a column chunk (second stream)", e->comm_stream));
-    HIPCHK(hipEventRecord(e->ov_gathered[p], e->comm_stream));
+    CHK(grp.end("all-gather of a column chunk (second stream)", cs));
+    HIPCHK(hipEventRecord(e->ov_gathered[p], cs));
     return 0;
   };
   auto to_panel = [&](int i) -> int {
@@ -139,16 +145,20 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
                          e->sym_nb, e->nloc, std::min(16, kk - 16 * g), e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->ldp,
                          e->nslab, total_rows);
     HIPCHK(hipEventRecord(e->ov_reduced[p], e->stream));
-    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ov_reduced[p], 0));
+    HIPCHK(hipStreamWaitEvent(cs, e->ov_reduced[p], 0));
     {
       CollGroup grp(e);
-      CHK(grp.begin(6, 8.0 * (double)e->nslab * kk * e->nranks, e->comm_stream));
-      for (int g = 0; g < npair; ++g)
-        NCCLCHK(g_rccl.ReduceScatter(e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16,
-                                     (size_t)e->nslab * std::min(16, kk - 16 * g), ncclDouble, ncclSum, e->comm, e->comm_stream));
-      CHK(grp.end("reduce-scatter of a column chunk (second stream)", e->comm_stream));
+      CHK(grp.begin(6, 8.0 * (double)e->nslab * kk * e->nranks, cs));
+      for (int g = 0; g < npair; ++g) {
+        const double* send = e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16;
+        double* recv = e->sym_wrecv2[p] + (size_t)g * (size_t)e->nslab * 16;
+        const size_t count = (size_t)e->nslab * std::min(16, kk - 16 * g);
+        if (tt) CHK(test_reduce_scatter(e, send, recv, count));
+        else NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, cs));
+      }
+      CHK(grp.end("reduce-scatter of a column chunk (second stream)", cs));
     }
-    HIPCHK(hipEventRecord(e->ov_scattered[p], e->comm_stream));
+    HIPCHK(hipEventRecord(e->ov_scattered[p], cs));
     if (i >= 1) CHK(to_panel(i - 1));                      // the previous chunk's rows of W, while this chunk's reduce-scatter runs
     if (which == DAV_OP_A) { e->st.applies += 1; e->st.apply_cols += kk; }
   }
@@ -189,7 +199,8 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
       // stream under the sweeps.  All collectives of the pipeline are issued on that ONE stream in the same order on every rank,
       // ordered against the engine's stream by events, so no two collectives of the communicator are ever in flight together.
       const bool overlap = e->tune.sym_overlap < 0 ? e->nranks > 1 : e->tune.sym_overlap != 0;
-      if (overlap && !partial && e->comm && step == 32 && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
+      if (overlap && !partial && (e->comm || (has_test_transport(e) && e->tune.sym_overlap == 1)) && step == 32 && k > 32 &&
+          o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
         const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
         if (rc != 2) return rc;                        // 2: its streams / buffers / slabs could not be set up - serial path below
       }

@@ -22,8 +22,8 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_bench(nproc, extra):
-    env = dict(os.environ, DAVIDSON_TRANSPORT="shm")
+def run_bench(nproc, extra, env_extra=None):
+    env = dict(os.environ, DAVIDSON_TRANSPORT="shm", **(env_extra or {}))
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
     else:
@@ -73,3 +73,17 @@ def test_bench_single_gpu_default_shape_of_the_line():
     assert 0 < line["roofline_hbm"]["frac"] <= line["roofline_hbm"]["frac_kernel_only"] < 1
     assert line["configs3_gjd"]["sweeps_of_A"] > line["configs3_gjd"]["iters"]
     assert line["dropin"]["iters"] == line["small"]["iters_per_solve"]
+
+
+def test_bench_multi_rank_flow_with_the_chunked_pipeline_of_wide_blocks():
+    """the same launch with the pipeline several GPUs run by default for blocks wider than 32 columns (DAV_SYM_OVERLAP=1 over the
+    shared-memory transport: its collectives on the engine's stream, everything else as over RCCL; two-block-row schedule forced
+    at this small order): lowest = 16 makes the 64-column expansion; same eigenvalues and iteration count as one rank"""
+    extra = ["--steps", "1", "--warmup", "1", "--order", "6000", "--lowest", "16", "--storage", "symmetric", "--headline-only"]
+    env = {"DAV_SYM_R": "2", "DAV_SYM_OVERLAP": "1"}
+    one = run_bench(1, extra, env)
+    for nproc in (2, 3):
+        many = run_bench(nproc, extra, env)
+        assert many["n_gpus"] == nproc and many["config"]["iters_per_solve"] == one["config"]["iters_per_solve"]
+        assert np.abs(np.array(many["eigenvalues"]) - np.array(one["eigenvalues"])).max() < 1e-10
+        assert many["comm"]["collectives_per_solve"] > 0 and many["roofline"]["comm_world_size"] == nproc

@@ -535,6 +535,42 @@ def test_symmetric_sweep_over_several_ranks(nranks, sched, monkeypatch):
                 assert np.array_equal(a, b)              # every rank gathers the same bits
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_overlapped_pipeline_of_the_symmetric_sweep_with_several_ranks(nranks, monkeypatch):
+    """The chunked pipeline that several GPUs run by default for blocks wider than 32 columns (all-gather of chunk i + 1 and
+    reduce-scatter of chunk i - 1 around the sweep of chunk i; Xt groups, partial-product and receive buffers alternating with
+    the chunk parity) with SEVERAL ranks: over the loopback transport its collectives run on the engine's stream, everything
+    else - layouts, counts, parities, the rows every rank receives - is what the RCCL run executes.  Same product as A X, the
+    same bits as the serial path of the same ranks, ragged orders and widths, a rank without tiles."""
+    monkeypatch.setenv("DAV_SYM_R", "2")
+    out = {}
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("DAV_SYM_OVERLAP", overlap)
+        for n, k in [(2500, 40), (2305, 64), (1300, 33), (700, 48)]:
+            rng = np.random.default_rng(n + k)
+            A = rng.standard_normal((n, n)); A = A + A.T
+            X = rng.standard_normal((n, k))
+
+            def work(r, e):
+                e.set_storage(1)
+                e.set_dense_host(OP_A, A)
+                e.panel_put(PANEL_V, 0, X)
+                e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+                W = e.panel_get(PANEL_W, 0, k)
+                e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
+                assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
+                return W
+
+            res = _run_ranks(nranks, lambda r: fd.CEngine(n=n, max_cols=64, rank=r, nranks=nranks), work)
+            for W in res:
+                assert relerr(W, A @ X) < RTOL * n
+                assert np.array_equal(W, res[0])
+            out[(overlap, n, k)] = res[0]
+    for (overlap, n, k), W in out.items():
+        if overlap == "1":
+            assert np.array_equal(W, out[("0", n, k)]), (n, k)       # the pipeline changes the order of launches, not a single sum
+
+
 def test_ranks_that_disagree_on_a_control_decision_stop_with_a_message():
     """dav_ranks_agree: what the multi-rank driver loop calls once per iteration with its decisions; identical words pass,
     different words are an error ON EVERY RANK (nobody is left alone in the next collective)."""
