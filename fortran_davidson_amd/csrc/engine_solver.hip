@@ -104,6 +104,8 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
     all.resize(keep);
     e->basis_order.swap(all);
   }
+  // the tickets of the last-workgroup finishes start every solve from zero (a launch that died half-way must not leave a count behind)
+  HIPCHK(hipMemsetAsync(e->counters, 0, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8), e->stream));
   std::vector<int64_t> order(e->basis_order.begin(), e->basis_order.begin() + ncols);
   HIPCHK(hipMemcpyAsync(e->idx_dev, order.data(), sizeof(int64_t) * ncols, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
