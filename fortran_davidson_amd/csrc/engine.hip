@@ -260,7 +260,6 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->xt);
   hipFree(e->scratch);
   hipFree(e->gram_dev);
-  if (e->gram_event) hipEventDestroy(e->gram_event);
   if (e->gram_host) hipHostFree(e->gram_host);
   hipFree(e->gather_dev);
   hipFree(e->idx_dev);

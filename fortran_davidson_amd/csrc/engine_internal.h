@@ -171,8 +171,6 @@ struct dav_engine {
   double* gram_host = nullptr;    // pinned, device-visible (zero-copy target of the reduction kernels)
   double* gram_host_dev = nullptr;  // device address of gram_host
   size_t gram_doubles = 0;
-  hipEvent_t gram_event = nullptr;  // dav_ortho_gram_begin / _end: the host waits for the Gram blocks only, not for what was enqueued behind them
-  bool gram_pending = false;
   double* gather_dev = nullptr;   // nranks*nslab staging for panel_get / diagonal gather
   int64_t* idx_dev = nullptr;
   double* norm_partial = nullptr;

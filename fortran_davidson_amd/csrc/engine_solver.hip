@@ -281,50 +281,8 @@ extern "C" int dav_ortho_gram(dav_handle_t e, int m, int kt, double* C, int64_t 
   return 0;
 }
 
-// The Gram blocks of a pass WITHOUT waiting for them: begin launches the kernels (several ranks: the all-reduce and the copy to the
-// host too) and records an event; end waits for that event only.  What the driver puts in between - the block sweep of the new
-// columns (dav_expand) - runs on the device while the host fetches the blocks, factors them and uploads the transform of the
-// pass (block_orthonormalise in fortran/davidson.f90): the one round trip of an iteration that does not have to stall the GPU.
-extern "C" int dav_ortho_gram_begin(dav_handle_t e, int m, int kt) {
+extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm) {
   CHK(bind(e));
-  if (m < 0 || kt <= 0) return fail("dav_ortho_gram_begin: bad shape");
-  CHK(check_panel(e, DAV_PANEL_V, 0, m + kt));
-  const int p = m + kt;
-  if ((size_t)p * kt > e->gram_doubles) return fail("gram result exceeds engine capacity");
-  if (gram_scratch_doubles(p, kt, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
-  if (!e->gram_event) HIPCHK(hipEventCreateWithFlags(&e->gram_event, hipEventDisableTiming));
-  int slot;
-  CHK(timed_begin(e, 1, 0, &slot));
-  launch_gram(e->stream, panel_ptr(e, DAV_PANEL_V, 0), e->ldp, p, panel_ptr(e, DAV_PANEL_V, m), e->ldp, kt, e->nloc_pad, e->scratch,
-              result_target(e), e->counters, e->tune.gram_wgs);
-  CHK(timed_end(e, slot));
-  if (e->nranks > 1) CHK(need_comm(e));
-  if (has_comm(e)) {
-    CHK(coll_allreduce(e, e->gram_dev, (size_t)p * kt));
-    HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * (size_t)p * kt, hipMemcpyDeviceToHost, e->stream));
-  }
-  HIPCHK(hipEventRecord(e->gram_event, e->stream));
-  e->gram_pending = true;
-  return 0;
-}
-
-extern "C" int dav_ortho_gram_end(dav_handle_t e, int m, int kt, double* C, int64_t ldc, double* G, int64_t ldg) {
-  CHK(bind(e));
-  if (!e->gram_pending) return fail("dav_ortho_gram_end: no dav_ortho_gram_begin before it");
-  if (m < 0 || kt <= 0 || ldg < kt || (m > 0 && ldc < m)) return fail("dav_ortho_gram_end: bad shape");
-  e->gram_pending = false;
-  HIPCHK(hipEventSynchronize(e->gram_event));
-  const int p = m + kt;
-  for (int j = 0; j < kt; ++j) {
-    for (int i = 0; i < m; ++i) C[j * ldc + i] = e->gram_host[(size_t)j * p + i];
-    for (int i = 0; i < kt; ++i) G[j * ldg + i] = e->gram_host[(size_t)j * p + m + i];
-  }
-  return 0;
-}
-
-// panel[:, m:m+kt] <- panel[:, m:m+kt] * M + panel[:, 0:m] * (-(C*M)) for the basis V and, images != 0, for its images W = A V
-// (and B V) as well: when the new columns were already swept, the transform of a later pass carries over to A T by linearity
-static int ortho_apply_impl(E* e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm, int images) {
   if (m < 0 || kt <= 0 || ldm < kt) return fail("dav_ortho_apply: bad shape");
   CHK(check_panel(e, DAV_PANEL_V, 0, m + kt));
   std::vector<double> cm((size_t)std::max(m, 1) * kt, 0.0);       // -(C*M)
@@ -339,36 +297,20 @@ static int ortho_apply_impl(E* e, int m, int kt, const double* C, int64_t ldc, c
   const int64_t ld_m = sm2[0].ldm, ld_cm = m > 0 ? sm2[1].ldm : 4;
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
-  const int panels[3] = {DAV_PANEL_V, DAV_PANEL_W, DAV_PANEL_BV};
-  const int npanels = images ? (e->gev ? 3 : 2) : 1;
-  for (int i = 0; i < npanels; ++i) {
-    const int pn = panels[i];
-    PanelGemmArgs a{};
-    a.P1 = panel_ptr(e, pn, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.tp1 = ld_m;
-    a.P2 = panel_ptr(e, pn, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.tp2 = ld_cm;
-    // in place where one workgroup covers all kt output columns (k_panel.hip: a wave has read its rows of every input column
-    // before it stores the first output); wider blocks go through the scratch panel
-    const bool in_place = kt <= PG_INPLACE_COLS;
-    a.out = in_place ? panel_ptr(e, pn, m) : panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
-    a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
-    a.pin = e->tune.pg_pin;
-    launch_panel_gemm(e->stream, a);
-    if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, pn, m), e->ldp, e->nloc_pad, kt);
-  }
+  PanelGemmArgs a{};
+  a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.tp1 = ld_m;
+  a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.tp2 = ld_cm;
+  // in place where one workgroup covers all kt output columns (k_panel.hip: a wave has read its rows of every input column before
+  // it stores the first output); wider blocks go through the scratch panel
+  const bool in_place = kt <= PG_INPLACE_COLS;
+  a.out = in_place ? panel_ptr(e, DAV_PANEL_V, m) : panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
+  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
+  a.pin = e->tune.pg_pin;
+  launch_panel_gemm(e->stream, a);
+  if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, m), e->ldp, e->nloc_pad, kt);
   CHK(timed_end(e, slot));
   HIPCHK(hipGetLastError());
   return 0;
-}
-
-extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm) {
-  CHK(bind(e));
-  return ortho_apply_impl(e, m, kt, C, ldc, M, ldm, 0);
-}
-
-extern "C" int dav_ortho_apply_swept(dav_handle_t e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm) {
-  CHK(bind(e));
-  if (e->op[DAV_OP_A].kind == DAV_KIND_HOST) return fail("dav_ortho_apply_swept: host operators (the driver moves their images itself)");
-  return ortho_apply_impl(e, m, kt, C, ldc, M, ldm, 1);
 }
 
 extern "C" int dav_expand(dav_handle_t e, int m, int kt) {

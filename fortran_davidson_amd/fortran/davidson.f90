@@ -403,7 +403,7 @@ contains
     integer(c_int64_t), allocatable :: idx(:)
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
     logical, allocatable :: has_converged(:)
-    logical :: host_ops, done, lazy_x, swept
+    logical :: host_ops, done, lazy_x
     real(dp) :: t0, t1, phase_s(8)
 
     phase_s = 0.0_dp
@@ -621,16 +621,14 @@ contains
                 end if
              end if
           end if
-          ! device operators: the sweep of the new columns goes out under the second pass's round trip (see block_orthonormalise)
-          swept = .false.
           if (have_pre) then
-             call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt), sweep_under_pass=.not. host_ops, swept=swept)
+             call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt))
           else
-             call block_orthonormalise(h, n, m, kt, sweep_under_pass=.not. host_ops, swept=swept)
+             call block_orthonormalise(h, n, m, kt)
           end if
           call lap(4)
-          ! 6. one block sweep of A over the new columns (unless it already went out), then the new rows/columns of H (and S)
-          if (.not. swept) call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+          ! 6. one block sweep of A over the new columns, then the new rows/columns of H (and S)
+          call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
           if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
           call lap(5)
           if (drr) then
@@ -760,42 +758,25 @@ contains
   !> rounding; a direction that is numerically dependent (e.g. the correction of an already converged
   !> pair) is replaced by a deterministic pseudo-random vector, as Householder QR would complete the
   !> basis with an arbitrary direction.
-  subroutine block_orthonormalise(h, n, m, kt, c_first, g_first, sweep_under_pass, swept)
+  subroutine block_orthonormalise(h, n, m, kt, c_first, g_first)
     type(c_ptr), intent(in) :: h
     integer, intent(in) :: n, m, kt
     !> Gram blocks V^T T and T^T T of the block as it stands (first pass), when the caller already has them
     real(dp), intent(in), optional :: c_first(:, :), g_first(:, :)
-    !> .true.: behind the first pass the block sweep of the new columns (dav_expand) is enqueued UNDER the round trip of the second
-    !> pass - its Gram is launched first, the host waits for that Gram only (dav_ortho_gram_begin / _end) - and the second pass's
-    !> transform is applied to V and to the swept images W = A V (and B V) alike: A (T M - V C M) = (A T) M - W C M.  The device
-    !> runs the sweep while the host fetches, factors and uploads the k x k block.  swept = .true. on return: W (and B V) hold the
-    !> images of the orthonormalised columns and the caller must not sweep them again; .false.: the block needed more than the
-    !> usual two passes (or a replaced column) after the sweep went out - the caller sweeps as usual.
-    logical, intent(in), optional :: sweep_under_pass
-    logical, intent(out), optional :: swept
     integer, parameter :: max_pass = 6
     real(dp), parameter :: floor_rel = 1.0e-14_dp
     real(dp), allocatable :: c(:, :), g(:, :), gp(:, :), d(:), w(:), u(:, :), mm(:, :), vec(:)
     integer :: pass, j, l, nrep, info
     logical :: chol_ok
     real(dp) :: wmax, wmin, dev
-    logical :: clean, want_sweep, gram_launched, images_follow, images_valid
+    logical :: clean
 
     allocate(c(max(m, 1), kt), g(kt, kt), gp(kt, kt), d(kt), w(kt), u(kt, kt), mm(kt, kt))
     clean = .false.
-    want_sweep = .false.
-    if (present(sweep_under_pass)) want_sweep = sweep_under_pass
-    gram_launched = .false.         ! the Gram of this pass was launched at the end of the previous one (with the sweep behind it)
-    images_follow = .false.         ! the sweep has gone out: the transform of this pass goes to W (and B V) too
-    images_valid = .false.
     do pass = 1, max_pass
        if (pass == 1 .and. present(c_first)) then
           if (m > 0) c(1:m, :) = c_first
           g = g_first
-       else if (gram_launched) then
-          call check_dav(dav_ortho_gram_end(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
-               int(kt, c_int64_t)), "dav_ortho_gram_end")
-          gram_launched = .false.
        else
           call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
                int(kt, c_int64_t)), "dav_ortho_gram")
@@ -820,11 +801,7 @@ contains
              deallocate(vec)
           end if
        end do
-       if (nrep > 0) then
-          images_follow = .false.      ! a replaced column has no image: whatever was swept is stale
-          images_valid = .false.
-          cycle
-       end if
+       if (nrep > 0) cycle
        do j = 1, kt
           d(j) = 1.0_dp / sqrt(gp(j, j))
        end do
@@ -894,35 +871,18 @@ contains
              end do
           end if
        end if
-       if (images_follow .and. wmin > 0.5_dp .and. wmax < 2.0_dp) then
-          ! the usual second pass (a nearly orthonormal block): its transform carries over to the swept images
-          call check_dav(dav_ortho_apply_swept(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
-               int(kt, c_int64_t)), "dav_ortho_apply_swept")
-          images_valid = .true.
-       else
-          call check_dav(dav_ortho_apply(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
-               int(kt, c_int64_t)), "dav_ortho_apply")
-          images_valid = .false.       ! an ill-conditioned pass behind the sweep: the caller sweeps again (rare)
-       end if
-       images_follow = .false.
+       call check_dav(dav_ortho_apply(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
+            int(kt, c_int64_t)), "dav_ortho_apply")
        ! a pass that started from a nearly orthonormal block (all scaled Gram eigenvalues close to 1
        ! and negligible overlap with V) leaves it orthonormal to rounding
        if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) then
           clean = .true.
           exit
        end if
-       if (want_sweep .and. pass == 1) then
-          ! the Gram of the next pass, then the sweep of the block as it stands now, then wait for that Gram only
-          call check_dav(dav_ortho_gram_begin(h, int(m, c_int), int(kt, c_int)), "dav_ortho_gram_begin")
-          call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
-          gram_launched = .true.
-          images_follow = .true.
-       end if
     end do
     if (.not. clean) then
        print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
     end if
-    if (present(swept)) swept = images_valid .and. clean
   end subroutine block_orthonormalise
 
   !> yk (m x kt) <- yk * M with M = G^(-1/2)-like (Cholesky R^-1, or the eigen-decomposition route with an eigenvalue

@@ -272,28 +272,6 @@ module davidson_hip_c
        integer(c_int64_t), value :: ldc, ldm
        integer(c_int) :: ierr
      end function
-     function dav_ortho_gram_begin(h, m, kt) bind(C, name="dav_ortho_gram_begin") result(ierr)
-       import :: c_ptr, c_int
-       type(c_ptr), value :: h
-       integer(c_int), value :: m, kt
-       integer(c_int) :: ierr
-     end function
-     function dav_ortho_gram_end(h, m, kt, c, ldc, g, ldg) bind(C, name="dav_ortho_gram_end") result(ierr)
-       import :: c_ptr, c_int, c_int64_t, c_double
-       type(c_ptr), value :: h
-       integer(c_int), value :: m, kt
-       real(c_double), intent(out) :: c(*), g(*)
-       integer(c_int64_t), value :: ldc, ldg
-       integer(c_int) :: ierr
-     end function
-     function dav_ortho_apply_swept(h, m, kt, c, ldc, mm, ldm) bind(C, name="dav_ortho_apply_swept") result(ierr)
-       import :: c_ptr, c_int, c_int64_t, c_double
-       type(c_ptr), value :: h
-       integer(c_int), value :: m, kt
-       real(c_double), intent(in) :: c(*), mm(*)
-       integer(c_int64_t), value :: ldc, ldm
-       integer(c_int) :: ierr
-     end function
      function dav_expand(h, m, kt) bind(C, name="dav_expand") result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: h

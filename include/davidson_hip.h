@@ -220,14 +220,6 @@ int dav_gjd_correction_n(dav_handle_t h, int m, int ncols, const double* theta, 
 int dav_ortho_gram(dav_handle_t h, int m, int kt, double* C, int64_t ldc, double* G, int64_t ldg);
 int dav_ortho_apply(dav_handle_t h, int m, int kt, const double* C, int64_t ldc,
                     const double* M, int64_t ldm);
-/* The same pass with the block sweep of the new columns UNDER its round trip: dav_ortho_gram_begin launches the Gram of
- * dav_ortho_gram and records an event, the driver enqueues dav_expand(h, m, kt) (A*T and B*T of the block as it stands after
- * the previous pass), dav_ortho_gram_end waits for the event only and returns C and G; dav_ortho_apply_swept then applies the
- * pass's transform to the new columns of V AND of W = A*V (and B*V): A*(T*M - V*C*M) = (A*T)*M - W*C*M, so no second sweep is
- * needed.  The GPU runs the sweep while the host factors the k x k block. */
-int dav_ortho_gram_begin(dav_handle_t h, int m, int kt);
-int dav_ortho_gram_end(dav_handle_t h, int m, int kt, double* C, int64_t ldc, double* G, int64_t ldg);
-int dav_ortho_apply_swept(dav_handle_t h, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm);
 /* Commit T as basis columns m..m+kt-1 and apply the operators to them (device operators only):
  * W[:, m:m+kt] = A*T (one block sweep of A - the only one per iteration), BV likewise. */
 int dav_expand(dav_handle_t h, int m, int kt);
