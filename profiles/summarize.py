@@ -24,6 +24,13 @@ def per_kernel(path, counters):
             key = (name, int(row["Grid_Size"]), int(row["Workgroup_Size"]))
             acc[key][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"]),
                                                   int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    # a kernel launched with dozens of different grids (the set-up kernel that generates the tiles block row by block row: 782
+    # grids at N=200000) is one line, not 782: its launches are pooled under grid size 0
+    grids = collections.Counter(k[0] for k in acc)
+    for key in [k for k in acc if grids[k[0]] > 16]:
+        pooled = acc[(key[0], 0, key[2])]
+        for cname, vals in acc.pop(key).items():
+            pooled[cname].extend(vals)
     return acc
 
 
