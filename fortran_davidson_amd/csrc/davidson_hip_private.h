@@ -29,6 +29,10 @@ int dav_apply_inner(dav_handle_t h, int which, int src_panel, int c0, int k, int
 /* Fraction of the block rows of a generated second operator that is kept resident as stored tiles (configs[3]); 0 when nothing is. */
 int dav_resident_fraction(dav_handle_t h, int which, double* fraction);
 
+/* The host-side packing of a small matrix into the MFMA-B operand image the panel kernel reads (csrc/kernels.h: pg_image_index:
+ * entry (i, j) at ((i / 4) * tiles_per_step + j / 16) * 64 + (j % 16) + 16 * (i % 4)); no GPU needed.  out == NULL: sizes only. */
+int dav_pack_operand_image(const double* src, int64_t ld, int p, int q, double* out, int64_t* doubles_out, int64_t* tiles_per_step_out);
+
 /* ---- TEST build only ---------------------------------------------------------------------------------------------- */
 /* Test transport: the n engines (created with rank r of n, same process, same GPU) exchange through
  * device copies and thread barriers instead of RCCL; each rank must then be driven by its own thread. */

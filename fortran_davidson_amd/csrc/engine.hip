@@ -73,6 +73,33 @@ int timed_end_on(E* e, int slot, hipStream_t stream) {
   return 0;
 }
 
+// MFMA-B operand image of a p x q column-major matrix into dst (pg_image_doubles(p, q) doubles, zeroed by the caller), written in
+// the order of the image: per step (4 rows) and tile (16 columns) the 64 entries a wave loads are contiguous
+static void pack_operand_image(const double* src, int64_t ld, int p, int q, double* dst) {
+  const int64_t tp = pg_image_tiles(q);
+  const int nstep = (p + 3) / 4, ntile = (q + 15) / 16;
+  for (int s = 0; s < nstep; ++s)
+    for (int t = 0; t < ntile; ++t) {
+      double* blk = dst + ((int64_t)s * tp + t) * 64;
+      const int gmax = std::min(4, p - 4 * s), cmax = std::min(16, q - 16 * t);
+      for (int g = 0; g < gmax; ++g) {
+        const double* col = src + (int64_t)(16 * t) * ld + 4 * s + g;
+        for (int c = 0; c < cmax; ++c) blk[16 * g + c] = col[(int64_t)c * ld];
+      }
+    }
+}
+// the same for tests on a host without a GPU (csrc/davidson_hip_private.h): out must hold *doubles_out doubles
+extern "C" int dav_pack_operand_image(const double* src, int64_t ld, int p, int q, double* out, int64_t* doubles_out, int64_t* tiles_per_step_out) {
+  if (p <= 0 || q <= 0 || ld < p) return fail("dav_pack_operand_image: bad shape");
+  if (doubles_out) *doubles_out = pg_image_doubles(p, q);
+  if (tiles_per_step_out) *tiles_per_step_out = pg_image_tiles(q);
+  if (out) {
+    std::memset(out, 0, sizeof(double) * (size_t)pg_image_doubles(p, q));
+    pack_operand_image(src, ld, p, q, out);
+  }
+  return 0;
+}
+
 // several small matrices in ONE staging buffer and ONE host-to-device copy (each H2D command costs ~10 us of launch latency,
 // which is what the small phases are made of).  Plain: zero padded to pad4(p) x pad64(q), column-major (ldm out); image: the
 // MFMA-B operand image panel_gemm_kernel reads (tiles per step out) - the same number of doubles.
@@ -92,17 +119,7 @@ int small_upload_multi(E* e, int i, SmallMat* mats, int n) {
     double* dst = b.host + off;
     if (mt.image) {
       mt.ldm = pg_image_tiles(mt.q);
-      // in the order of the image: per step (4 rows) and tile (16 columns) the 64 entries a wave loads are contiguous
-      const int nstep = (mt.p + 3) / 4, ntile = (mt.q + 15) / 16;
-      for (int s = 0; s < nstep; ++s)
-        for (int t = 0; t < ntile; ++t) {
-          double* blk = dst + ((int64_t)s * mt.ldm + t) * 64;
-          const int gmax = std::min(4, mt.p - 4 * s), cmax = std::min(16, mt.q - 16 * t);
-          for (int g = 0; g < gmax; ++g) {
-            const double* col = mt.src + (int64_t)(16 * t) * mt.ld + 4 * s + g;
-            for (int c = 0; c < cmax; ++c) blk[16 * g + c] = col[(int64_t)c * mt.ld];
-          }
-        }
+      pack_operand_image(mt.src, mt.ld, mt.p, mt.q, dst);
     } else {
       mt.ldm = roundup(std::max(mt.p, 1), 4);
       for (int j = 0; j < mt.q; ++j) std::memcpy(dst + j * mt.ldm, mt.src + j * mt.ld, sizeof(double) * mt.p);

@@ -51,6 +51,27 @@ def test_stats_mirror_has_the_size_of_the_c_structure():
     assert int(size) == ctypes.sizeof(fd.engine_c.Stats) and int(ver) == fd.engine_c.ABI_VERSION
 
 
+@pytest.mark.parametrize("p,q", [(1, 1), (3, 5), (6, 16), (17, 33), (64, 64), (130, 100), (128, 64)])
+def test_operand_image_of_a_small_matrix(p, q):
+    """The layout the panel kernel reads its small-matrix operand in (round 4): for step s = i / 4 and tile t = j / 16 the 64 values
+    lane c + 16 g <-> M[4 s + g][16 t + c] are contiguous; zero outside p x q; tiles per step a multiple of 4."""
+    lib = fd.hip_lib()
+    rng = np.random.default_rng(p * 1000 + q)
+    ld = p + 3
+    M = np.asfortranarray(rng.standard_normal((ld, q)))
+    n, tp = ctypes.c_int64(), ctypes.c_int64()
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert lib.dav_pack_operand_image(M.ctypes.data_as(dp), ctypes.c_int64(ld), p, q, None, ctypes.byref(n), ctypes.byref(tp)) == 0
+    assert tp.value % 4 == 0 and tp.value * 16 >= q and n.value == (p + 3) // 4 * tp.value * 64
+    out = np.full(n.value, np.nan)
+    assert lib.dav_pack_operand_image(M.ctypes.data_as(dp), ctypes.c_int64(ld), p, q, out.ctypes.data_as(dp), None, None) == 0
+    ref = np.zeros(n.value)
+    for i in range(p):
+        for j in range(q):
+            ref[((i // 4) * tp.value + j // 16) * 64 + (j % 16) + 16 * (i % 4)] = M[i, j]
+    assert np.array_equal(out, ref)
+
+
 def test_fortran_host_exports_api_doors():
     lib = fd.fortran_lib()
     for name in ["fd_dense_solve", "fd_free_solve", "fd_engine_create", "fd_engine_solve", "fd_engine_destroy",
