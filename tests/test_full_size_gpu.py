@@ -217,6 +217,50 @@ def test_config5_n1000000_matrix_free_four_ranks(storage):
     assert out[0][1] == 4
 
 
+# lowest eigenvalues of configs[2] (seed 1) from the one-rank run: bench.py headline, profiles/r04_bench_default.log
+ONE_RANK_CONFIG3_LAM = [0.9999951655277628, 1.9999960491572697, 2.9999969540010114]
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_config3_n200000_two_ranks_dealt_tiles(overlap, monkeypatch):
+    """configs[2] at its full order on TWO ranks (threads on the one GPU, loopback transport): the 160 GB triangle dealt out by groups
+    of four block rows (80 GB per rank), all-gather of each new block, sweep of the rank's tiles, reduce-scatter of the partial
+    products - serial (overlap 0) and as the chunked pipeline of the wide blocks (overlap 1).  64-bit tile offsets, slab
+    boundaries and the reduce-scatter layout at the size the first multi-GPU run will have; eigenpairs verified on the device
+    against the generator on every rank, iteration count and eigenvalues against the one-rank run."""
+    import ctypes as C
+    monkeypatch.setenv("DAV_SYM_OVERLAP", overlap)
+    n, L, sp, nranks = 200000, 16, 1e-3, 2
+    engs = [fd.DavidsonEngine(n, L, 80, rank=r, nranks=nranks, storage="symmetric") for r in range(nranks)]
+    handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+    assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            engs[r].generate_diagonal_dominant(1, sp, seed=1)
+            lam, _, iters = engs[r].solve("DPR", 1000, TOL, want_vectors=False)
+            verify_on_device(engs[r], lam, False, n, sp, anchor={"A": (1, None)})
+            st = engs[r].c.stats()
+            out[r] = (lam, iters, st.apply_bytes / st.applies)
+        except Exception as exc:      # noqa: BLE001
+            err[r] = exc
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in threads]
+    [t.join(timeout=600) for t in threads]
+    for e in engs:
+        e.close()
+    assert all(x is None for x in err), err
+    assert all(o is not None for o in out)
+    for lam, iters, nbytes in out:
+        assert np.array_equal(lam, out[0][0]) and iters == out[0][1]
+        assert 0.55e11 < nbytes < 0.9e11                         # every rank swept its half of the triangle
+    # the one-rank run of this problem (test_config3_n200000_one_gpu / bench.py headline, same seed)
+    assert out[0][1] == 3
+    assert np.abs(out[0][0][:3] - np.array(ONE_RANK_CONFIG3_LAM[:3])).max() < 1e-10
+
+
 def test_config3_n200000_restart_forcing_variant():
     """configs[2] with a denser coupling (sparsity 2e-2 instead of 1e-3): the basis passes max_dim_sub = 80 before the
     pairs converge, so the solve goes through collapse restarts at full size (src/davidson.f90:215-220) - 32-, 64-column
