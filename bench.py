@@ -18,11 +18,11 @@ Objects in the JSON line besides the contract's fields:
                  columns per launch - bound by the fp64 matrix pipe), HIP-event timed inside the solves; its hbm_* keys
                  (and the nested `hbm` object) carry the NORTH-STAR measurement - A*V at N=200000, k=8 on the same resident
                  matrix, END TO END (operand packing + sweep kernel + fixed-order reduction) and the sweep kernel alone,
-                 against 8 TB/s and against the copy / triad rate measured in the same run - and k=16 beside it
+                 against 8 TB/s, against the copy / triad rate and against the read-only rate measured in the same run - and k=16 beside it
   roofline_hbm   the same north-star object at top level (kept for readers of earlier rounds)
   comm           several GPUs: ranks RCCL reports, storage mode, per-solve all-gather / reduce-scatter / all-reduce ms and bytes
   apply          the same for k = 8, 16, 32
-  hbm_measured   device copy / triad rate of this box (what 8 TB/s amount to in practice); HBM fractions are quoted against both
+  hbm_measured   device copy / triad / read-only rate of this box (what 8 TB/s amount to in practice); HBM fractions are quoted against them too
   configs2_restart  configs[2] with a denser coupling: the solve goes through collapse restarts at full size
   configs3_gjd   BASELINE configs[3]: N=200000 generalized (A, B), GJD correction, lowest=8
   configs4_free  BASELINE configs[4]: matrix-free hashed diagonal-dominant operator, lowest=8, DPR
@@ -258,8 +258,11 @@ def scaling_model(n, lowest, world):
     full64 = max(8.0 * n * n / P / (0.66 * 8.0e12), 2.0 * n * n * 64 / P / 57.8e12) * 1e3
     block_bytes = 8.0 * n * (32 + 64)
     ring = 0.0 if P == 1 else block_bytes * (P - 1) / P / 70.0e9 * 1e3          # one all-gather (or one reduce-scatter) of the blocks
+    # W0 = A * V0 of the 32 unit columns: gathered from the dealt-out tiles and reduce-scattered (no sweep; dav_init_basis)
+    ring0 = 0.0 if P == 1 else 8.0 * n * 32 * (P - 1) / P / 70.0e9 * 1e3
     other = 1.0 + 1.9 * scale ** 0.5 / P + (0.0 if P == 1 else 0.05 * 10)
-    return {"symmetric_ms": round(sym_sweeps + 2 * ring + other, 2), "symmetric_overlapped_ms": round(sym_sweeps + 2 * ring / 3 + other, 2),
+    return {"symmetric_ms": round(sym_sweeps + 2 * ring + ring0 + other, 2),
+            "symmetric_overlapped_ms": round(sym_sweeps + 2 * ring / 3 + ring0 + other, 2),
             "full_ms": round(full32 + full64 + ring + other, 2),
             "note": "model, not a measurement: symmetric = dealt-out tiles (all-gather + reduce-scatter per block), overlapped = their "
                     "collectives on a second stream (about two thirds hidden under the 64-column block), full = row slabs (all-gather only, twice the bytes per sweep)"}
@@ -391,15 +394,17 @@ def main():
         sheet amount to in practice."""
         try:
             with fd.CEngine(n=1024, max_cols=16, device=device) as e0:
-                cp, tr = e0.bench_stream(0, 5)
-            return {"copy_GBps": round(cp, 1), "triad_GBps": round(tr, 1), "bytes_per_array": 8 * (1 << 28),
+                cp, tr, rd = e0.bench_stream3(0, 5)
+            return {"copy_GBps": round(cp, 1), "triad_GBps": round(tr, 1), "read_GBps": round(rd, 1), "bytes_per_array": 8 * (1 << 28),
                     "note": "dav_bench_stream: plain streaming kernels (16 B per lane, 8 accesses in flight, contiguous 32 KiB pieces, 2048 workgroups) on 2 GiB float64 arrays, "
-                            "read + written bytes, HIP events, this run"}
+                            "read + written bytes, HIP events, this run; read_GBps: the same pattern reading two of the arrays and writing one partial sum "
+                            "per workgroup - the practical roof of a sweep that reads 8*S bytes and writes 8*N*k"}
         except Exception as exc:       # noqa: BLE001
             return {"error": repr(exc)[:200]}
 
     hbm_measured = measured_stream() if rank == 0 or world > 1 else None
     stream_gbps = max(hbm_measured.get("copy_GBps", 0.0), hbm_measured.get("triad_GBps", 0.0)) if hbm_measured else 0.0
+    read_gbps = hbm_measured.get("read_GBps", 0.0) if hbm_measured else 0.0
 
     # auto: the storage the model of DESIGN section 6 predicts to be the faster one for this rank count (symmetric tiles for every
     # P up to 8 at the timed size; the full row slabs of north_star's partition are `--storage full`)
@@ -480,6 +485,9 @@ def main():
         "hbm_GBps_end_to_end": a8["GBps_end_to_end"], "hbm_GBps_kernel_only": a8["GBps_kernel_only"],
         "hbm_frac": a8["frac_of_8TBps_end_to_end"], "hbm_frac_kernel_only": a8["frac_of_8TBps_kernel_only"],
         "hbm_measured_stream_GBps": stream_gbps or None, "hbm_frac_of_measured_stream": a8["frac_of_measured_stream_end_to_end"],
+        "hbm_measured_read_GBps": read_gbps or None,
+        "hbm_frac_of_measured_read": round(a8["GBps_end_to_end"] / read_gbps, 4) if read_gbps > 0 else None,
+        "hbm_frac_of_measured_read_kernel_only": round(a8["GBps_kernel_only"] / read_gbps, 4) if read_gbps > 0 else None,
         "hbm_traffic": tr_k8[0],
         "hbm_k16_ms_end_to_end": a16["ms_end_to_end"], "hbm_k16_ms_kernel_only": a16["ms_kernel_only"],
         "hbm_k16_algorithmic_bytes": a16["algorithmic_bytes"], "hbm_k16_GBps_end_to_end": a16["GBps_end_to_end"],

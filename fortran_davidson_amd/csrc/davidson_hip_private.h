@@ -23,6 +23,9 @@ int dav_bench_apply2(dav_handle_t h, int which, int k, int reps, double* avg_ms,
  * three arrays of `doubles` entries (0 = 2^28, i.e. 2 GiB each), read + written GB/s - the measured counterpart of the data
  * sheet's 8 TB/s that every HBM fraction of bench.py is also quoted against. */
 int dav_bench_stream(dav_handle_t h, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps);
+/* The same, plus the rate of a kernel that only READS (two of the arrays, same access pattern, one partial sum per workgroup
+ * written): the practical roof of the operator sweeps, which read 8*S bytes and write 8*N*k. */
+int dav_bench_stream3(dav_handle_t h, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps, double* read_GBps);
 /* dav_apply as the GJD correction solve calls it (an "inner" sweep: may read the fp32 copy of the stored tiles,
  * dav_set_inner_precision) - so that the parity tests can compare that sweep with the oracle directly. */
 int dav_apply_inner(dav_handle_t h, int which, int src_panel, int c0, int k, int dst_panel, int d0);

@@ -355,6 +355,38 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
   return 0;
 }
 
+// W0 = Op * V0 for the unit columns V0 = e_idx of dav_init_basis over SEVERAL ranks of dealt-out symmetric tiles, without a sweep:
+// column p of the operator lies in the tiles of many ranks (rows at or below p's block row: the owners of those block rows, column
+// p of their tiles; rows above: the owner of p's block row, row p of its tiles); every rank writes what it holds in the
+// reduce-scatter layout of the sweeps and the same reduce-scatter leaves every rank its row slab.  One owner per entry, so the sum
+// is exact and equals the sweep's result (products with the zeros of e_p add nothing).  A sweep of 32 columns costs 42 ms / P at
+// N=200000 - a third of a configs[2] solve on several GPUs; this costs the reduce-scatter of 2 x N x 16 doubles.
+int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst) {
+  CHK(need_comm(e));
+  if (!e->sym_wpart) {
+    HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
+    HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
+  }
+  const int64_t total_rows = (int64_t)e->nranks * e->nslab;
+  for (int c = 0; c < ncols; c += 32) {
+    const int kk = std::min(32, ncols - c), npair = (kk + 15) / 16;
+    for (int g = 0; g < npair; ++g)
+      launch_gather_columns_sym_rs(e->stream, o.a, e->sym.row_off, e->n, e->nslab, total_rows, e->idx_dev + c + 16 * g, std::min(16, kk - 16 * g),
+                                   e->sym_wpart + (size_t)g * (size_t)total_rows * 16);
+    CollGroup grp(e);
+    CHK(grp.begin(6, 8.0 * (double)e->nslab * kk * e->nranks));
+    for (int g = 0; g < npair; ++g)
+      CHK(coll_reduce_scatter(e, e->sym_wpart + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16,
+                              (size_t)e->nslab * std::min(16, kk - 16 * g)));
+    CHK(grp.end("reduce-scatter of the gathered columns", e->stream));
+    for (int g = 0; g < npair; ++g)
+      launch_chunk_to_panel(e->stream, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad, std::min(16, kk - 16 * g),
+                            dst + (int64_t)(c + 16 * g) * e->ldp, e->ldp, false);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int apply_impl(E* e, int which, int src_panel, int c0, int k, int dst_panel, int d0, bool timed) {
   CHK(check_panel(e, src_panel, c0, k));
   CHK(check_panel(e, dst_panel, d0, k));
@@ -421,7 +453,7 @@ extern "C" int dav_bench_apply2(dav_handle_t e, int which, int k, int reps, doub
 // What the HBM of THIS box delivers to a plain streaming kernel: device copy (a = b) and triad (a = b + s c) over arrays of
 // `doubles` entries each (0 = 2^28: 2 GiB per array), read + written bytes per second ("re-measure achievable BW
 // with a stream-triad on the box and report fraction of both").  Allocates and frees its three arrays.
-extern "C" int dav_bench_stream(dav_handle_t e, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps) {
+extern "C" int dav_bench_stream3(dav_handle_t e, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps, double* read_GBps) {
   CHK(bind(e));
   const int64_t n = doubles > 0 ? doubles / 2 * 2 : (int64_t)1 << 28;
   if (reps <= 0) reps = 5;
@@ -437,12 +469,12 @@ extern "C" int dav_bench_stream(dav_handle_t e, int64_t doubles, int reps, doubl
     cleanup();
     return fail("dav_bench_stream: could not allocate three arrays of " + std::to_string(n) + " doubles");
   }
-  double out[2] = {0.0, 0.0};
+  double out[3] = {0.0, 0.0, 0.0};
   int rc = 0;
   auto run = [&]() -> int {
     HIPCHK(hipMemsetAsync(b, 0, sizeof(double) * n, e->stream));
     HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * n, e->stream));
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {                                        // copy, triad, reads only (two arrays)
       launch_stream(e->stream, mode, a, b, c, 0.5, n);                        // warm-up
       HIPCHK(hipEventRecord(ev[0], e->stream));
       for (int r = 0; r < reps; ++r) launch_stream(e->stream, mode, a, b, c, 0.5, n);
@@ -450,7 +482,7 @@ extern "C" int dav_bench_stream(dav_handle_t e, int64_t doubles, int reps, doubl
       HIPCHK(hipEventSynchronize(ev[1]));
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-      out[mode] = (mode == 0 ? 2.0 : 3.0) * 8.0 * (double)n * reps / (ms * 1e-3) / 1e9;
+      out[mode] = (mode == 1 ? 3.0 : 2.0) * 8.0 * (double)n * reps / (ms * 1e-3) / 1e9;
     }
     return 0;
   };
@@ -459,5 +491,9 @@ extern "C" int dav_bench_stream(dav_handle_t e, int64_t doubles, int reps, doubl
   if (rc != 0) return rc;
   if (copy_GBps) *copy_GBps = out[0];
   if (triad_GBps) *triad_GBps = out[1];
+  if (read_GBps) *read_GBps = out[2];
   return 0;
+}
+extern "C" int dav_bench_stream(dav_handle_t e, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps) {
+  return dav_bench_stream3(e, doubles, reps, copy_GBps, triad_GBps, nullptr);
 }

@@ -359,6 +359,7 @@ void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const SymPlan* pl, con
 int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner);
 int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner = false);
 int apply_impl(E* e, int which, int src_panel, int c0, int k, int dst_panel, int d0, bool timed);
+int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst);
 // ---- engine_solver.hip -----------------------------------------------------------------------------------
 double* result_target(E* e);
 int result_fetch(E* e, size_t count);

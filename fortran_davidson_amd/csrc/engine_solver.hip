@@ -115,8 +115,13 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
     int dst = w == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
     if (o.kind == DAV_KIND_DENSE && o.storage == 1 && e->nranks == 1)
       launch_gather_columns_sym(e->stream, o.a, e->sym.row_off, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
+    else if (o.kind == DAV_KIND_DENSE && o.storage == 1)
+      CHK(gather_columns_sym_multi(e, o, ncols, panel_ptr(e, dst, 0)));           // several ranks: one reduce-scatter instead of a sweep
     else if (o.kind == DAV_KIND_DENSE && o.storage == 0)
       launch_gather_columns(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
+    else if (o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS || o.kind == DAV_KIND_IDENTITY)
+      // a generated operator's columns are generated: N x ncols entries instead of a sweep of N^2 / 2 (configs[4]: one sweep in five)
+      launch_gather_columns_free(e->stream, op_params(o), e->row0, e->nloc, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
     else if (o.kind == DAV_KIND_HOST) {
       /* the driver fills W / BV through dav_panel_put */
     } else

@@ -389,6 +389,23 @@ void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_
                      nrows_pad, idx_dev, dst, ldd);
 }
 
+// The same columns from the tiles of SEVERAL ranks: every rank writes what its block rows hold of columns idx[0:k] (zero where
+// another rank stores the entry) over all `total_rows` rows, in the reduce-scatter layout of the sweeps
+// ([rank][column][row of the rank's slab], chunk_rows = rows per slab); the sum over the ranks is exact - one owner per entry
+__global__ void gather_columns_sym_rs_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off, int64_t n,
+                                             int64_t chunk_rows, int64_t total_rows, const int64_t* __restrict__ idx, int k,
+                                             double* __restrict__ dst) {
+  int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int c = blockIdx.y;
+  if (row < total_rows)
+    dst[(row / chunk_rows) * (chunk_rows * k) + (int64_t)c * chunk_rows + row % chunk_rows] = row < n ? sym_entry(tiles, row_off, row, idx[c]) : 0.0;
+}
+void launch_gather_columns_sym_rs(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t chunk_rows,
+                                  int64_t total_rows, const int64_t* idx_dev, int k, double* dst) {
+  hipLaunchKernelGGL(gather_columns_sym_rs_kernel, dim3((unsigned)((total_rows + 255) / 256), k), dim3(256), 0, st, tiles, row_off, n,
+                     chunk_rows, total_rows, idx_dev, k, dst);
+}
+
 // Upload path of a host matrix into symmetric tiles: block column J arrives as ONE panel (rows J*256 .. n of its <= 256
 // columns, column-major with leading dimension ldp - a 2-D copy with long rows, which is what PCIe moves at full rate; a
 // tile-by-tile copy has 2 KB rows and runs at a third of it) and is cut into the tiles (I >= J, J) this rank stores.

@@ -66,6 +66,27 @@ void launch_gather_columns(hipStream_t st, const double* A, int64_t lda, int64_t
                      nrows_pad, idx_dev, dst, ldd);
 }
 
+// columns idx[0:k] of a generated operator (rows of this rank's slab): what Op * e_p is, without a sweep
+__global__ void gather_columns_free_kernel(OpParams op, int64_t row0, int64_t nloc, int64_t nrows_pad, const int64_t* __restrict__ idx,
+                                           double* __restrict__ dst, int64_t ldd) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int c = blockIdx.y;
+  if (i >= nrows_pad) return;
+  double v = 0.0;
+  if (i < nloc) {
+    const int64_t gi = row0 + i, gj = idx[c];
+    if (op.kind == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
+    else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op.e_table, op.trig, gi, gj);
+    else v = gi == gj ? 1.0 : 0.0;
+  }
+  dst[(int64_t)c * ldd + i] = v;
+}
+void launch_gather_columns_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t nrows_pad, const int64_t* idx_dev, int k,
+                                double* dst, int64_t ldd) {
+  hipLaunchKernelGGL(gather_columns_free_kernel, dim3((unsigned)((nrows_pad + 255) / 256), k), dim3(256), 0, st, op, row0, nloc, nrows_pad,
+                     idx_dev, dst, ldd);
+}
+
 __global__ void unit_columns_kernel(const int64_t* __restrict__ idx, int64_t row0, int64_t nloc, int64_t nrows_pad,
                                     double* __restrict__ dst, int64_t ldd) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -139,7 +160,33 @@ __global__ __launch_bounds__(256) void stream_kernel(double* __restrict__ a, con
     }
   }
 }
+// MODE 2 of the microbenchmark: reads only (b and c, 16 B per lane, the same access pattern), one partial sum per workgroup written
+// to a[blockIdx.x] - the roof of a kernel that, like the operator sweeps, reads far more than it writes
+__global__ __launch_bounds__(256) void stream_read_kernel(double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c,
+                                                          int64_t n2) {
+  constexpr int U = 8;
+  const int64_t piece = 256 * U, stride = (int64_t)gridDim.x * piece;
+  f64x2 acc = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * piece + threadIdx.x; i + (U - 1) * 256 < n2; i += stride) {
+    f64x2 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(b) + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(c) + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = acc + x[u] + y[u];
+  }
+  __shared__ double part[256];
+  part[threadIdx.x] = acc[0] + acc[1];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int l = 0; l < 256; ++l) t += part[l];
+    a[blockIdx.x] = t;
+  }
+}
 void launch_stream(hipStream_t st, int mode, double* a, const double* b, const double* c, double s, int64_t n) {
+  if (mode == 2) { hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, st, a, b, c, n / 2); return; }
   if (mode == 0) hipLaunchKernelGGL(stream_kernel<0>, dim3(2048), dim3(256), 0, st, a, b, c, s, n / 2);
   else hipLaunchKernelGGL(stream_kernel<1>, dim3(2048), dim3(256), 0, st, a, b, c, s, n / 2);
 }

@@ -144,6 +144,10 @@ void launch_generate_sym_tiles(hipStream_t st, double* tiles, const int64_t* row
 void launch_retile_panel(hipStream_t st, const double* panel, int64_t ldp, int64_t nrows, int ncols, int J, int nb,
                          const int64_t* row_off, double* tiles);
 void launch_diag_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows, double* diag);
+void launch_gather_columns_sym_rs(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t chunk_rows,
+                                  int64_t total_rows, const int64_t* idx_dev, int k, double* dst);
+void launch_gather_columns_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t nrows_pad, const int64_t* idx_dev, int k,
+                                double* dst, int64_t ldd);
 void launch_gather_columns_sym(hipStream_t st, const double* tiles, const int64_t* row_off, int64_t n, int64_t nrows_pad,
                                const int64_t* idx_dev, int k, double* dst, int64_t ldd);
 // dst[i, c] = i < nloc ? src[c * lds + i] : 0 for i < nrows_pad (the received chunk of a reduce-scatter -> panel columns)

@@ -295,6 +295,12 @@ class CEngine:
         self._chk(self.lib.dav_bench_stream(self.h, C.c_int64(doubles), C.c_int(reps), C.byref(cp), C.byref(tr)))
         return cp.value, tr.value
 
+    def bench_stream3(self, doubles=0, reps=5):
+        """(copy, triad, read-only GB/s): bench_stream plus a kernel that only reads (two arrays, one partial sum per workgroup written)"""
+        cp, tr, rd = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.dav_bench_stream3(self.h, C.c_int64(doubles), C.c_int(reps), C.byref(cp), C.byref(tr), C.byref(rd)))
+        return cp.value, tr.value, rd.value
+
     def bench_apply2(self, k, reps, which=OP_A):
         """(ms per apply end to end, ms of the block-matvec kernel alone, algorithmic bytes, flops) per apply"""
         ms, kms, nbytes, flops = C.c_double(), C.c_double(), C.c_double(), C.c_double()

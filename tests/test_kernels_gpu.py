@@ -535,6 +535,44 @@ def test_symmetric_sweep_over_several_ranks(nranks, sched, monkeypatch):
                 assert np.array_equal(a, b)              # every rank gathers the same bits
 
 
+@pytest.mark.parametrize("nranks", [1, 2, 3, 5])
+def test_first_block_of_the_basis_is_gathered_not_swept(nranks):
+    """dav_init_basis: W0 = A V0 (and B V0) for the unit columns V0 = e_p of the lowest diagonal entries are COLUMNS of the operator
+    (src/davidson.f90:128-135 applies the matrix to them).  Symmetric tiles dealt out over several ranks: every rank contributes what
+    its tiles hold of those columns, one reduce-scatter (40 columns: two rounds of it); generated operators: the columns are generated.
+    Bit for bit the operator's entries, no sweep counted; ragged orders, a scrambled diagonal, more ranks than groups of block rows."""
+    for n, ncols in [(300, 6), (1300, 16), (2305, 40), (700, 33)]:
+        rng = np.random.default_rng(n)
+        A = rng.standard_normal((n, n)); A = A + A.T
+        A[np.arange(n), np.arange(n)] = rng.permutation(n) + 1.0
+        G = O.generate_diagonal_dominant(n, 1e-2, seed=13)
+        GB = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=14)
+
+        def work(r, e):
+            res = []
+            e.set_storage(1)
+            e.set_dense_host(OP_A, A)
+            e.set_operator_hashed(OP_B, 14, 1e-2, 1.0)
+            e.reset_stats()
+            idx = e.init_basis(ncols)
+            assert e.stats().applies == 0
+            res += [idx, e.panel_get(PANEL_W, 0, ncols), e.panel_get(PANEL_BV, 0, ncols)]
+            e.set_operator_hashed(OP_A, 13, 1e-2)
+            e.set_operator_identity(OP_B)
+            idx2 = e.init_basis(ncols)
+            res += [idx2, e.panel_get(PANEL_W, 0, ncols), e.panel_get(PANEL_BV, 0, ncols), e.panel_get(PANEL_V, 0, ncols)]
+            return res
+
+        out = _run_ranks(nranks, lambda r: fd.CEngine(n=n, max_cols=max(ncols, 16), gev=True, rank=r, nranks=nranks), work)
+        for idx, W, BV, idx2, W2, BV2, V2 in out:
+            assert np.array_equal(idx - 1, O.lowest_diagonal_indices(np.diag(A), ncols))
+            assert np.array_equal(W, A[:, idx - 1])
+            assert np.array_equal(BV, GB[:, idx - 1])
+            assert np.array_equal(idx2, np.arange(1, ncols + 1))
+            assert np.array_equal(W2, G[:, :ncols])
+            assert np.array_equal(BV2, V2) and np.array_equal(V2, np.eye(n)[:, :ncols])
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_overlapped_pipeline_of_the_symmetric_sweep_with_several_ranks(nranks, monkeypatch):
     """The chunked pipeline that several GPUs run by default for blocks wider than 32 columns (all-gather of chunk i + 1 and
