@@ -694,7 +694,7 @@ def main():
                 f = make_engine(fn, 8, 80, fstorage, gev=True)
                 f.set_hashed_operator(1, args.sparsity, seed=1)
                 f.set_identity(2)                                        # B = I as src/benchmark_free.f90:65-76
-                f.c.bench_apply2(16, 1)                                  # untimed: lazy workspace (partial-sum slabs) allocated
+                f.c.bench_apply2(32, 1)                                  # untimed: lazy workspace (partial-sum slabs of a 32-column launch) allocated
                 f.c.synchronize(); f.c.reset_stats()
                 dt_f, it_f, lam_f = timed_solves(f, "DPR", 1, args.tol)
                 sf = f.c.stats()
@@ -708,14 +708,23 @@ def main():
                     "sweeps": int(sf.applies), "launches": int(sf.apply_launches), "ms_per_launch": round(per_launch_ms, 2),
                     "entries_of_A_per_s_per_rank": round(entries / (per_launch_ms * 1e-3), 0) if per_launch_ms > 0 else None,
                     "eigenvalues": [float(x) for x in lam_f[:3]]}
-                # issue-port roofline of the generated sweep (GEN_CYCLES_PER_WAVE_EVALUATION above)
+                # issue-port roofline of the generated sweeps (GEN_CYCLES_PER_WAVE_EVALUATION above): a launch generates every entry of
+                # the rank's part once and feeds it to 2 MFMAs per 16 columns - 16 columns per launch (232 cycles per wave-evaluation)
+                # or 32 (the generating variant of the wide kernel: 26 x 4 + 4 x 64 = 360); frac = model time / measured time
                 evals = entries * (0.5 if fstorage == "symmetric" else 1.0)
-                peak_evals = 1024 * 2.4e9 * 64 / GEN_CYCLES_PER_WAVE_EVALUATION
+                launches = max(int(sf.apply_launches), 1)
+                n32 = min(max((int(sf.apply_cols) - 16 * launches) // 16, 0), launches) if fstorage == "symmetric" else 0
+                n16 = launches - n32
+                rate = 1024 * 2.4e9 * 64
+                model_ms = evals * (n16 * GEN_CYCLES_PER_WAVE_EVALUATION + n32 * (26 * 4 + 4 * 64)) / rate * 1e3
+                peak_evals = rate / GEN_CYCLES_PER_WAVE_EVALUATION
                 if per_launch_ms > 0:
                     extras["configs4_free"]["roofline"] = {
                         "bound": "valu-int + mfma on one issue port", "unit": "hash evaluations/s", "achieved": round(evals / (per_launch_ms * 1e-3), 0),
-                        "peak": round(peak_evals, 0), "frac": round(evals / (per_launch_ms * 1e-3) / peak_evals, 4),
-                        "model": GEN_MODEL}
+                        "peak": round(evals * launches / (model_ms * 1e-3), 0), "frac": round(model_ms / sf.apply_kernel_ms, 4),
+                        "launches_of_16_columns": n16, "launches_of_32_columns": n32,
+                        "peak_16_columns": round(peak_evals, 0), "peak_32_columns": round(rate / (26 * 4 + 4 * 64), 0),
+                        "model": GEN_MODEL + "; a 32-column launch (matvec_symw_kernel<2, GEN>) pays the 26 VALU instructions once for 4 MFMAs: 360 cycles"}
                 f.close()
             except Exception as exc:       # noqa: BLE001
                 extras["configs4_free"] = {"error": repr(exc)[:300]}

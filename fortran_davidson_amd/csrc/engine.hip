@@ -192,6 +192,7 @@ Tune tune_from_env() {
   t.sym_overlap = geti("DAV_SYM_OVERLAP", t.sym_overlap);
   t.sym_r = geti("DAV_SYM_R", t.sym_r);
   t.sym_tall = geti("DAV_SYM_TALL", t.sym_tall);
+  t.sym_gen_wide = geti("DAV_SYM_GEN_WIDE", 1);
   t.sym_run = std::max(0, geti("DAV_SYM_RUN", 0));
   t.sym_run9 = std::max(0, geti("DAV_SYM_RUN9", 0));
   t.sym_mfma4 = geti("DAV_SYM_MFMA4", t.sym_mfma4);

@@ -37,6 +37,13 @@ void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const SymSet& set, con
                        (npair + nbw - 1) / nbw, e->xt_group_stride, dstride, tstride);
     return;
   }
+  // the hashed operator at 17-32 columns per launch: the wide kernel's generating variant - one generated entry feeds the MFMAs of
+  // both 16-column groups (Tune::sym_gen_wide = 0: two groups of the 16-column kernel, every entry generated twice)
+  if (o.kind == DAV_KIND_HASHED && R == 2 && kk > 16 && wide > 0 && e->tune.sym_gen_wide) {
+    launch_matvec_symw_generated(e->stream, op_params(o), e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
+                                 (npair + 1) / 2, e->xt_group_stride, dstride, tstride);
+    return;
+  }
   // fp32 tiles (mixed-precision inner sweeps, up to 16 columns): the wide kernel's fp32 variant; Tune::sym_wide32 = 0: the two-wave kernel
   if (o.kind == DAV_KIND_DENSE && use32 && wide > 1 && e->tune.sym_wide32 && R == 2 && kk <= 16) {
     launch_matvec_symw(e->stream, 1, false, true, o.a32, set.row_off, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
@@ -179,11 +186,14 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
     // Several ranks: each sweeps the block rows it stores against the all-gathered block and holds a partial of the
     // WHOLE product; one reduce-scatter per 16 columns sums the partials and leaves every rank its row slab.
     // pairing shares the READS of stored tiles: nothing to share when the entries are generated
-    int step = (e->tune.sym_pair && !e->sym_no_pair && o.kind == DAV_KIND_DENSE) ? 32 : 16;
+    // ... except where the generating variant of the wide kernel shares the GENERATED entries between two groups (hashed operator,
+    // two-block-row schedule)
+    const bool gen_wide = o.kind == DAV_KIND_HASHED && e->tune.sym_gen_wide && e->tune.sym_wide > 0 && sym_schedule(e, 32, false) == 2;
+    int step = (e->tune.sym_pair && !e->sym_no_pair && (o.kind == DAV_KIND_DENSE || gen_wide)) ? 32 : 16;
     // 64 columns (the widest expansion of the doubling policy below a basis of 128) as FOUR column groups in one launch on
     // the super-row kernels: the four workgroups of a work item share every tile read through their XCD's L2.  Same box,
     // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  Tune::sym_quad = 0: off.
-    if (e->tune.sym_quad && step == 32 && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2 && !has_comm(e)) step = 64;
+    if (e->tune.sym_quad && step == 32 && o.kind == DAV_KIND_DENSE && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2 && !has_comm(e)) step = 64;
     // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
     // reduce-scatter of this path through RCCL on a one-GPU box)
     const bool multi = e->nranks > 1 || has_comm(e);

@@ -140,6 +140,7 @@ struct Tune {
   int sym_overlap = -1;   // DAV_SYM_OVERLAP: collectives of wide blocks on a second stream; -1 = default (on over a real multi-rank communicator)
   int sym_r = 0;          // DAV_SYM_R: 1 | 2 | 4 forces the block rows per workgroup
   int sym_tall = 1;       // DAV_SYM_TALL: four block rows per workgroup at 9-16 columns
+  int sym_gen_wide = 1;   // DAV_SYM_GEN_WIDE: the hashed operator at more than 16 columns generates its entries once per 32 columns (0: once per 16)
   int sym_run = 0;        // DAV_SYM_RUN / DAV_SYM_RUN9: run length of the work items (0 = by the tile count)
   int sym_run9 = 0;
   int sym_mfma4 = 1;      // DAV_SYM_MFMA4: the 4x4x4 MFMA at k <= 8

@@ -104,13 +104,23 @@ __device__ __forceinline__ i32x4 symw_desc(const void* p, int bytes) {
 // 4-slot ring of raw fp32 pairs), a burst of 8 v_cvt_f64_f32 in front of a half-step's MFMAs widens the NEXT half-step's
 // sub-block into ordinary registers, and from there on everything is fp64: the direct product's A operand and the LDS
 // transposition take those registers instead of the ring, products and sums are the fp64 kernel's.
-template <int NB, bool TALL, bool F32>
+// GEN (NB = 2, two block rows; the hashed matrix-free operator at more than 16 columns): no tiles at all - every half-step the wave
+// GENERATES the next half-step's 32 x 16 sub-block (8 entries per lane: one splitmix64 each, the layout of the tile loads) into
+// ordinary registers, as one burst of VALU work in front of the half-step's MFMAs, and from there on it is the fp32-tile
+// variant's data path: the direct product's A operand and the LDS transposition take those registers.  What it buys: a generated
+// entry feeds 2 NB = 4 MFMAs instead of the 2 of the 16-column kernels (matvec_sym9_kernel<2, GEN>), whose 32- and 64-column
+// blocks regenerate the whole operator per 16 columns - the generator (26 VALU instructions per 64 entries, on the issue port the
+// MFMAs use) is paid once per 32 columns.
+template <int NB, bool TALL, bool F32, bool GEN>
 __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restrict__ tiles_any, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items, const int* __restrict__ zslot_begin,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
                                                              double* __restrict__ slabT, int kcols, int nwg, int64_t xt_gstride,
-                                                             int64_t slabD_gstride, int64_t slabT_gstride, int nb) {
+                                                             int64_t slabD_gstride, int64_t slabT_gstride, int nb, OpParams op, int64_t n) {
   static_assert(!TALL || NB == 1, "two slices per wave: 16 columns per workgroup");
+  static_assert(!GEN || (NB == 2 && !TALL && !F32), "generated entries: 32 columns, two block rows per workgroup");
+  constexpr bool REGT = F32 || GEN;     // the sub-blocks reach the MFMAs and the transposition through ordinary registers
+  (void)op; (void)n;
   static_assert(!F32 || (NB == 1 && !TALL), "fp32 tiles: 16 columns, two block rows per workgroup");
   using TileT = std::conditional_t<F32, float, double>;
   const TileT* __restrict__ tiles = static_cast<const TileT*>(tiles_any);
@@ -212,12 +222,12 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
   // (a scalar instruction costs ~5 cycles of matrix-pipe time here, profiles/ubench/r03_fatwave_vgpr_acc.log).
   constexpr int64_t UNIT_BYTES = 16 * SYM_TB * (int64_t)sizeof(TileT);
   const int64_t unit0 = (int64_t)J0 * UPJ * UNIT_BYTES;
-  const char* const trow_max = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
+  const char* const trow_max = GEN ? nullptr : symw_uniform(reinterpret_cast<const char*>(tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
   const char* trow_own[NSL];
   unsigned qlim_d[NSL];              // units whose tile is stored for this wave's slice (J <= I): q < qlim_d
 #pragma unroll
   for (int sl = 0; sl < NSL; ++sl) {
-    trow_own[sl] = symw_uniform(reinterpret_cast<const char*>(tiles + row_off[have_row[sl] ? Is[sl] : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
+    trow_own[sl] = GEN ? nullptr : symw_uniform(reinterpret_cast<const char*>(tiles + row_off[have_row[sl] ? Is[sl] : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
     qlim_d[sl] = symw_uniform(have_row[sl] ? (Is[sl] >= J0 ? (unsigned)(Is[sl] - J0 + 1) * UPJ : 0u) : 0u);
   }
   // position i of the sequence: unit i / NSL, slice i % NSL
@@ -293,7 +303,48 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
                  :: "v"(wa), "i"(SYMW_RING(SLOT, U)), "i"(SYMW_RING(SLOT, U) + 3), "i"(4 * U * TRS * (int)sizeof(double)) : "memory");
   };
   // F32: the widened sub-blocks, [half-step parity][column quad] = rows 2c, 2c + 1 of tile column 4u + g
-  f64x2 wide[F32 ? 2 : 1][4];
+  f64x2 wide[REGT ? 2 : 1][4];
+  // GEN: step st = 4 q + hs of the run -> rows 2c, 2c + 1 of tile columns 4u + g of its sub-block, generated (the entries
+  // matvec_sym9_kernel<2, GEN> generates: strictly below the diagonal and inside the matrix one splitmix64 per entry on a
+  // key that is linear in row and column; the diagonal tile, the last ragged block row and tiles that are "not there" for this
+  // wave - masked like stored ones - through dav_hashed_entry with its bounds).  All conditions are wave-uniform.
+  const uint64_t seedmix = op.seed * 0x9E3779B97F4A7C15ull;
+  const double gscale = op.sparsity * (1.0 / 9007199254740992.0);
+  auto generate = [&](unsigned st, f64x2 (&wv)[4]) {
+    if constexpr (GEN) {
+      st = st < 4 * nunits ? st : 4 * nunits - 1;
+      const unsigned q = st >> 2, hs = st & 3;
+      const int J = J0 + (int)(q / UPJ);
+      const int Ie = (have_row[0] && q < qlim_d[0]) ? Is[0] : Imax;
+      const int64_t gi = (int64_t)Ie * SYM_TB + 128 * rhalf + 32 * hs + 2 * c;
+      const int64_t gj = (int64_t)J * SYM_TB + 16 * (q % UPJ) + g;
+      if (J < Ie && ((int64_t)Ie + 1) * SYM_TB <= n) {
+        const uint64_t k0 = (uint64_t)gi + seedmix;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint64_t kc = ((uint64_t)(gj + 4 * u) << 32) + k0;
+          const uint64_t m0 = dav_splitmix64(kc) >> 11, m1 = dav_splitmix64(kc + 1) >> 11;
+          wv[u].x = __builtin_fma((double)(uint32_t)(m0 >> 32), 4294967296.0, (double)(uint32_t)m0) * gscale;
+          wv[u].y = __builtin_fma((double)(uint32_t)(m1 >> 32), 4294967296.0, (double)(uint32_t)m1) * gscale;
+        }
+      } else {
+        // branch-free (the code of this path is executed for a few tiles per run but sits in the loop sixteen times)
+        auto entry = [&](int64_t i, int64_t j) {
+          const uint64_t lo = (uint64_t)(i < j ? i : j), hi = (uint64_t)(i < j ? j : i);
+          const uint64_t m = dav_splitmix64((lo << 32) + hi + seedmix) >> 11;
+          const double off = __builtin_fma((double)(uint32_t)(m >> 32), 4294967296.0, (double)(uint32_t)m) * gscale;
+          const double dg = op.use_diag ? op.diag_val : (double)(i + 1);
+          const double v = i == j ? dg : off;
+          return (i < n && j < n) ? v : 0.0;
+        };
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          wv[u].x = entry(gi, gj + 4 * u);
+          wv[u].y = entry(gi + 1, gj + 4 * u);
+        }
+      }
+    }
+  };
   auto ds_w_reg = [&](auto uc, const f64x2& v) {
     constexpr int U = decltype(uc)::value;
     const unsigned wa = tw_wr;
@@ -387,17 +438,23 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
   // tile loads of step s - 1 and its X_J half.  X_J(q) is older than the 8 tile loads of steps 4 q - 2, 4 q - 1.
   static_assert(DEPTH == 3 && NSLOT == 4, "the counts below hold for a 4-slot ring with 3 half-steps of lookahead");
   constexpr auto younger = [](int hs) { return 4 + (NBL / 2) * (hs == 0 ? 0 : hs == 2 ? 2 : 1); };
-  i32x4 ud[3] = {unit_desc(0), unit_desc(1), unit_desc(2)};     // descriptors of units q, q + 1, q + 2
+  i32x4 ud[3];                                                  // descriptors of units q, q + 1, q + 2
+  if constexpr (!GEN) { ud[0] = unit_desc(0); ud[1] = unit_desc(1); ud[2] = unit_desc(2); }
   symw_static_for<NB>([&](auto bc) {
     const i32x4 d = x_desc(0, decltype(bc)::value);
     symw_static_for<4>([&](auto uc) { x_load(std::integral_constant<int, 0>{}, uc, bc, d, std::true_type{}); });
   });
-  symw_static_for<DEPTH>([&](auto sc) {
-    constexpr int st = decltype(sc)::value;
-    symw_static_for<4>([&](auto uc) { t_load(std::integral_constant<int, st % NSLOT>{}, uc, ud[st / 4], st % 4, std::true_type{}); });
-  });
-  asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
-  if constexpr (F32) {
+  if constexpr (!GEN) {
+    symw_static_for<DEPTH>([&](auto sc) {
+      constexpr int st = decltype(sc)::value;
+      symw_static_for<4>([&](auto uc) { t_load(std::integral_constant<int, st % NSLOT>{}, uc, ud[st / 4], st % 4, std::true_type{}); });
+    });
+    asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
+  }
+  if constexpr (GEN) {
+    generate(0, wide[0]);
+    symw_static_for<4>([&](auto uc) { ds_w_reg(uc, wide[0][decltype(uc)::value]); });
+  } else if constexpr (F32) {
     widen(std::integral_constant<int, 0>{}, wide[0]);
     symw_static_for<4>([&](auto uc) { ds_w_reg(uc, wide[0][decltype(uc)::value]); });
   } else {
@@ -421,7 +478,8 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
     i32x4 xd[NB];                                      // X_J of unit q + 1
 #pragma unroll
     for (int bcb = 0; bcb < NB; ++bcb) xd[bcb] = x_desc(q + 1, bcb);
-    const i32x4 udn = unit_desc(q + 3);
+    i32x4 udn;
+    if constexpr (!GEN) udn = unit_desc(q + 3);
     // the sums of strip st (units 4 st .. 4 st + 3) were staged by position NSL (4 st + 3) + NSL + 1 of the sequence; the barrier
     // of the next even position publishes them: 4 st + 6 (TALL: 8 st + 10)
     constexpr unsigned FP = 4 * NSL, F0 = TALL ? 10 : 6;
@@ -444,12 +502,23 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
       unsigned long long w0, w1;
       STAMP(w0);
 #endif
-      asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" :: "i"(younger(hs)) : "memory");
+      // GEN: the only vector-memory loads of the loop are X_J of unit q + 1, issued in half-steps 0 and 1 of unit q: all landed
+      // long before the next unit's half-step 0 asks for them
+      if constexpr (!GEN) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" :: "i"(younger(hs)) : "memory");
+      else if constexpr (hs == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if DAV_SYMW_STAMPS > 1
       STAMP(w1);
       st_vm += w1 - w0;
 #endif
       if constexpr (F32) widen(std::integral_constant<int, (hs + 1) % NSLOT>{}, wide[(hs + 1) & 1]);   // ONE VALU burst per half-step
+      if constexpr (GEN) {
+        // the generator of step s + 1, pinned as ONE burst in front of this half-step's MFMAs (VALU instructions between MFMAs
+        // cost 12.5 + 4 n cycles per gap, profiles/ubench/r03_valucost.log; the scheduler would spread them)
+        __builtin_amdgcn_sched_barrier(0);
+        generate(4 * q + hs + 1, wide[(hs + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // The memory operations of the half-step, one slot behind every second MFMA: the transposition of step s + 1 (ring slot
       // -> LDS -> Gram operands of the other parity; its reads are 16 NB MFMAs old when the next half-step starts), the tile
       // loads of step s + DEPTH (their ring slot held step s - 1, whose MFMAs and DS reads have been issued), X_J of unit q + 1
@@ -462,10 +531,13 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
         using XS = std::integral_constant<int, 1 - SET>;
         constexpr std::false_type old{};                // descriptors of the loop are scalar-ALU results: no wait states needed
         if constexpr (NB == 2) {
-          if constexpr (k < 4) ds_w(WS{}, std::integral_constant<int, k>{});
-          else if constexpr (k < 8) ds_r(NP{}, std::integral_constant<int, k - 4>{});
-          else if constexpr (k < 12) t_load(LS{}, std::integral_constant<int, k - 8>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4, old);
-          else if constexpr (hs < 2) x_load(XS{}, std::integral_constant<int, k - 12>{}, std::integral_constant<int, hs>{}, xd[hs < 2 ? hs : 0], old);
+          if constexpr (k < 4) {
+            if constexpr (REGT) ds_w_reg(std::integral_constant<int, k>{}, wide[(hs + 1) & 1][k]);
+            else ds_w(WS{}, std::integral_constant<int, k>{});
+          } else if constexpr (k < 8) ds_r(NP{}, std::integral_constant<int, k - 4>{});
+          else if constexpr (k < 12) {
+            if constexpr (!GEN) t_load(LS{}, std::integral_constant<int, k - 8>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4, old);
+          } else if constexpr (hs < 2) x_load(XS{}, std::integral_constant<int, k - 12>{}, std::integral_constant<int, hs>{}, xd[hs < 2 ? hs : 0], old);
           // the exchange (compiler-visible LDS operations: the asm statements around them keep them in their slots)
           if constexpr (SET == 0 && hs == 0 && k < 8) z_write(zcs[1 - PP], (q >> 1) - 1, k);
           if constexpr (hs == 1 && k >= 8 && k < 12) sum_issue(q - 2, k - 8);
@@ -508,8 +580,8 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
           f64x4 &d0 = acc[SL][hs][0][bcb], &d1 = acc[SL][hs][1][bcb], &zz = zc[bcb];
           const double x0 = xI[SL][hs][ib][j][0][bcb], x1 = xI[SL][hs][ib][j][1][bcb];
           // two MFMAs per statement: direct (rows of parity 0 / 1), transposed (the row pair's first / second row)
-          if constexpr (F32) {
-            // the direct product's A operand is the widened sub-block (ordinary registers) instead of the ring
+          if constexpr (REGT) {
+            // the direct product's A operand is the widened / generated sub-block (ordinary registers) instead of the ring
             const double a0 = wide[hs & 1][u].x, a1 = wide[hs & 1][u].y;
             if constexpr (hs == 0 && u == 0)
               asm volatile("v_mfma_f64_16x16x4_f64 %0, %3, a[%c4:%c5], %0\n\t"
@@ -554,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
       st_mf += fb - fa;
 #endif
     });
-    ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn;
+    if constexpr (!GEN) { ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn; }
 #ifdef DAV_SYMW_STAMPS
     unsigned long long t4;
     STAMP(t4);
@@ -634,12 +706,22 @@ void launch_matvec_symw(hipStream_t st, int nbw, bool tall, bool tiles_f32, cons
                         int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
                         int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride) {
   dim3 grid(nitems * nwg), block(256);
+  const OpParams op{};
+  const int64_t n = 0;
 #define SYMW_LAUNCH(NBW, T, F)                                                                                                          \
-  hipLaunchKernelGGL((matvec_symw_kernel<NBW, T, F>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
-                     nwg, xt_gstride, slabD_gstride, slabT_gstride, nb)
+  hipLaunchKernelGGL((matvec_symw_kernel<NBW, T, F, false>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
+                     nwg, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
   if (tiles_f32) SYMW_LAUNCH(1, false, true);
   else if (nbw == 2) SYMW_LAUNCH(2, false, false);
   else if (tall) SYMW_LAUNCH(1, true, false);
   else SYMW_LAUNCH(1, false, false);
 #undef SYMW_LAUNCH
+}
+
+// the hashed operator at 17-32 columns per launch: no tiles, entries generated in the sweep (matvec_symw_kernel<2, false, false, GEN>)
+void launch_matvec_symw_generated(hipStream_t st, OpParams op, int64_t n, int nb, const int* items_dev, int nitems, const int* zslot_begin_dev,
+                                  const double* xt, int kcols, double* slabD, double* slabT, int nwg, int64_t xt_gstride, int64_t slabD_gstride,
+                                  int64_t slabT_gstride) {
+  hipLaunchKernelGGL((matvec_symw_kernel<2, false, false, true>), dim3(nitems * nwg), dim3(256), 0, st, (const void*)nullptr, (const int64_t*)nullptr,
+                     items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, nwg, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n);
 }

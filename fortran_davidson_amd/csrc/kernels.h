@@ -134,6 +134,9 @@ void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool
 void launch_matvec_symw(hipStream_t st, int nbw, bool tall, bool tiles_f32, const void* tiles, const int64_t* row_off, int nb, const int* items_dev,
                         int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD, double* slabT, int nwg,
                         int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride);
+void launch_matvec_symw_generated(hipStream_t st, OpParams op, int64_t n, int nb, const int* items_dev, int nitems, const int* zslot_begin_dev,
+                                  const double* xt, int kcols, double* slabD, double* slabT, int nwg, int64_t xt_gstride, int64_t slabD_gstride,
+                                  int64_t slabT_gstride);
 // fp32 copy of `count` stored tile entries (count a multiple of 4)
 void launch_tiles_to_f32(hipStream_t st, const double* src, float* dst, int64_t count);
 void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,

@@ -23,7 +23,9 @@ def test_scaling_model_prefers_the_dealt_out_symmetric_tiles_and_predicts_six_fo
         m = bench.scaling_model(200000, 16, p)
         assert m["symmetric_overlapped_ms"] <= m["symmetric_ms"] < m["full_ms"]
         assert m["symmetric_ms"] < one["symmetric_ms"] / (0.7 * p)
-    assert one["symmetric_ms"] / bench.scaling_model(200000, 16, 8)["symmetric_ms"] >= 5.9
+    eight = bench.scaling_model(200000, 16, 8)
+    assert one["symmetric_ms"] / eight["symmetric_ms"] >= 5.7                 # collectives in program order (incl. the start block's reduce-scatter)
+    assert one["symmetric_ms"] / eight["symmetric_overlapped_ms"] >= 6.0      # ... on the second stream (the default)
 
 
 def test_no_self_launch_from_under_a_profiler():

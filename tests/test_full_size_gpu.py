@@ -327,17 +327,29 @@ def test_sweep_kernels_at_full_size_against_oracle_rows():
 
 def test_generated_sweeps_at_n1000000_against_oracle_rows():
     """configs[4]'s operator at its stated order: the hashed diagonal-dominant operator generated in the symmetric sweep (every
-    pair once), 16 and 8 columns, against rows of the oracle's matrix (1.5e8 entries generated on the host)."""
+    pair once), 16 and 8 columns, and the blocks wider than 16 columns that generate every entry once per 32 columns
+    (`matvec_symw_kernel<2, GEN>`: 32, and 40 = 32 + 8 with its ragged second launch) against rows of the oracle's matrix
+    (1.5e8 entries generated on the host; N=10^6 is not a multiple of the tile edge: the last block row is ragged)."""
     from fortran_davidson_amd.engine_c import PANEL_V, PANEL_W
     n, sp = 1000000, 1e-3
     rows, a_rows = oracle_rows(n, sp, 1, None, nrandom=100)
     rng = np.random.default_rng(6)
-    with fd.CEngine(n=n, max_cols=16) as e:
+    with fd.CEngine(n=n, max_cols=48) as e:
         e.set_storage(1)
         e.set_operator_hashed(OP_A, 1, sp)
-        X = rng.standard_normal((n, 16))
+        X = rng.standard_normal((n, 48))
         e.panel_put(PANEL_V, 0, X)
         e.apply(OP_A, PANEL_V, 0, 16, PANEL_W, 0)
-        assert_rows_match(e.panel_get(PANEL_W, 0, 16), X, rows, a_rows, "generated, 16 columns")
+        assert_rows_match(e.panel_get(PANEL_W, 0, 16), X[:, :16], rows, a_rows, "generated, 16 columns")
         e.apply(OP_A, PANEL_V, 4, 8, PANEL_W, 0)
         assert_rows_match(e.panel_get(PANEL_W, 0, 8), X[:, 4:12], rows, a_rows, "generated, 8 columns")
+        e.reset_stats()
+        e.apply(OP_A, PANEL_V, 0, 32, PANEL_W, 0)
+        assert e.stats().apply_launches == 1                     # one generation of the operator for 32 columns
+        W32 = e.panel_get(PANEL_W, 0, 32)
+        assert_rows_match(W32, X[:, :32], rows, a_rows, "generated, 32 columns in one launch")
+        e.apply(OP_A, PANEL_V, 5, 40, PANEL_W, 0)
+        W40 = e.panel_get(PANEL_W, 0, 40)
+        assert_rows_match(W40, X[:, 5:45], rows, a_rows, "generated, 40 columns")
+        e.apply(OP_A, PANEL_V, 0, 32, PANEL_W, 8)                # bitwise reproducible, wherever the block lands
+        assert np.array_equal(e.panel_get(PANEL_W, 8, 32), W32)

@@ -471,6 +471,35 @@ def test_symmetric_super_row_schedules_at_a_size_that_selects_them(n, k):
             assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
 
 
+@pytest.mark.parametrize("gen_wide", ["1", "0"])
+def test_hashed_operator_wider_than_16_columns_generates_each_entry_once_per_32(gen_wide, monkeypatch):
+    """The matrix-free hashed operator in symmetric generation at 17-64 columns: `matvec_symw_kernel<2, GEN>` generates a 32 x 16
+    sub-block per half-step and feeds both 16-column groups from it (DAV_SYM_GEN_WIDE=0: the 16-column kernel per group, as before).
+    Two-block-row schedule forced at small orders; ragged orders (last block row and last tile column partly outside the matrix),
+    diagonal = i (A) and = 1 (B), block widths that leave a ragged second group; against the oracle's matrix."""
+    monkeypatch.setenv("DAV_SYM_R", "2")
+    monkeypatch.setenv("DAV_SYM_GEN_WIDE", gen_wide)
+    for n, k in [(300, 17), (700, 32), (1300, 40), (2305, 64), (2560, 24)]:
+        rng = np.random.default_rng(n + k)
+        G = O.generate_diagonal_dominant(n, 1e-2, seed=21)
+        GB = O.generate_diagonal_dominant(n, 1e-2, 1.0, seed=22)
+        X = rng.standard_normal((n, k))
+        with fd.CEngine(n=n, max_cols=64, gev=True) as e:
+            e.set_storage(1)
+            e.set_operator_hashed(OP_A, 21, 1e-2)
+            e.set_operator_hashed(OP_B, 22, 1e-2, 1.0)
+            e.panel_put(PANEL_V, 0, X)
+            e.reset_stats()
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+            assert e.stats().apply_launches == ((k + 31) // 32 if gen_wide == "1" else (k + 15) // 16)
+            e.apply(OP_B, PANEL_V, 0, k, PANEL_BV, 0)
+            W, BV = e.panel_get(PANEL_W, 0, k), e.panel_get(PANEL_BV, 0, k)
+            assert relerr(W, G @ X) < 1e-12, (n, k)
+            assert relerr(BV, GB @ X) < 1e-12, (n, k)
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
+            assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))          # bitwise reproducible
+
+
 def _run_ranks(nranks, make, work):
     """nranks engines as threads of this process on one GPU, collectives through the loopback transport"""
     import ctypes as C
