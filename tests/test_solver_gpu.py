@@ -40,6 +40,23 @@ def test_dense_dpr_matches_reference_golden(golden, name):
         assert np.allclose(vec.T @ B @ vec, np.eye(case["lowest"]), atol=1e-10)   # DSYGV itype=1 normalisation
 
 
+@pytest.mark.parametrize("gev", [False, True])
+def test_gjd_outer_iterations_equal_the_oracles_exact_solves_on_a_grid(gev):
+    """The engine solves the GJD correction equations inexactly (block MINRES, wanted pairs to 0.01 tol / |r|, the others to 1e-2:
+    fortran/davidson.f90 gjd_tol_wanted / gjd_tol_unwanted); the reference solves them exactly (DSYSV, src/davidson.f90:700-734).
+    Same outer iteration count, eigenvalues and residuals as the oracle's restatement of the reference on a grid of problems of
+    our generator (profiles/tools/gjd_policy_sweep.py runs the larger grid and the alternative settings)."""
+    for n, lowest, sp, seed in [(150, 2, 1e-3, 1), (150, 4, 1e-2, 2), (150, 8, 1e-2, 1), (300, 2, 1e-2, 2), (300, 4, 1e-3, 1),
+                                (300, 8, 1e-2, 2), (500, 4, 1e-2, 1), (500, 8, 1e-3, 2)]:
+        A = O.generate_diagonal_dominant(n, sp, seed=seed)
+        B = O.generate_diagonal_dominant(n, sp, 1.0, seed=seed + 100) if gev else None
+        lam_o, _, it_o = O.generalized_eigensolver_dense(A, lowest, "GJD", 50, 1e-8, None, B)
+        lam, vec, it = fd.generalized_eigensolver(A, lowest, "GJD", 50, 1e-8, None, B)
+        assert it == it_o, (n, lowest, sp, seed, it, it_o)
+        assert np.abs(lam - lam_o).max() < 1e-8
+        assert (residuals(A, B, lam, vec) < 1e-8).all()
+
+
 GJD_CASES = ["matrix_txt_gjd", "c1_n50_std_gjd", "c1_n50_gev_gjd", "n100_main_gev_gjd", "n400_std_gjd", "n400_gev_gjd"]
 
 
