@@ -122,6 +122,15 @@ extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const dou
     beta[j] = phibar[j] = beta1[j];
     if (!(beta1[j] > 0.0)) active[j] = 0.0;
   }
+  // tol_per_col[j] < 0 marks a FOLLOWER: its tolerance is |tol_per_col[j]|, and it also stops as soon as every column that is not a
+  // follower has stopped (the corrections of the unwanted Ritz pairs only enrich the basis: they get the steps the wanted pairs
+  // need, not a solve of their own)
+  std::vector<char> follower(m, 0);
+  bool any_leader = false;
+  for (int j = 0; j < m; ++j) {
+    follower[j] = tol_per_col && tol_per_col[j] < 0.0;
+    any_leader = any_leader || !follower[j];
+  }
   int itn = 0;
   std::vector<double> c0(m), c1(m), c2(m), c3(m);
   std::vector<int> stall(m, 0);
@@ -222,9 +231,15 @@ extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const dou
     for (int j = 0; j < m; ++j) c1[j] = phi[j] * active[j];
     CHK(gjd_lincomb(g, T, T, &one, w, &c1));
     for (int j = 0; j < m; ++j)
-      if (active[j] != 0.0 && (!(phibar[j] > (tol_per_col ? tol_per_col[j] : inner_tol) * beta1[j]) || !(beta[j] > 0.0) ||
+      if (active[j] != 0.0 && (!(phibar[j] > (tol_per_col ? std::fabs(tol_per_col[j]) : inner_tol) * beta1[j]) || !(beta[j] > 0.0) ||
                                (stall[j] >= 8 && phibar[j] < 1e-6 * beta1[j])))
         active[j] = 0.0;      // converged, broke down, or stagnated at the attainable accuracy
+    if (any_leader) {
+      bool leader_active = false;
+      for (int j = 0; j < m; ++j) leader_active = leader_active || (!follower[j] && active[j] != 0.0);
+      if (!leader_active)
+        for (int j = 0; j < m; ++j) active[j] = 0.0;
+    }
   }
   if (inner_iters_out) *inner_iters_out = itn;
   HIPCHK(hipGetLastError());

@@ -716,15 +716,18 @@ contains
   !> exact solves (profiles/tools/gjd_policy_sweep.py: orders 150-500, lowest 2-8, sparsity 1e-3 - 5e-2, standard
   !> and generalized) 1e-2 gives the iteration counts of 1e-4 in every case.  These pairs sit in the interior of the
   !> projected spectrum, where MINRES on A - theta B converges slowest: at configs[3] they kept the inner solve
-  !> going for 13 of 18 steps after the wanted pairs had finished.
+  !> going for 13 of 18 steps after the wanted pairs had finished.  Hence the sign: a NEGATIVE tolerance (the default,
+  !> -1e-2) makes these pairs followers (dav_gjd_correction_n) - they stop at |t| or when every wanted pair has
+  !> stopped, whichever comes first: they get the inner steps the wanted pairs need, not a solve of their own
+  !> (144-problem sweep against the oracle: never more outer iterations than the reference's exact solves).
   function gjd_tol_unwanted() result(t)
     real(dp) :: t
     integer :: stat, length
     character(len=32) :: buf
-    t = 1.0e-2_dp
+    t = -1.0e-2_dp
     call get_environment_variable("DAV_GJD_TOL_UNWANTED", buf, length, stat)
     if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) t
-    if (stat /= 0) t = 1.0e-2_dp
+    if (stat /= 0 .or. t == 0.0_dp) t = -1.0e-2_dp
   end function gjd_tol_unwanted
 
   !> Inner tolerance of the GJD solve for a WANTED pair whose residual norm is `err`: the correction equation is solved

@@ -210,7 +210,9 @@ int dav_gjd_correction(dav_handle_t h, int m, const double* theta, int max_inner
                        int* inner_iters_out);
 /* Same for ncols <= m pairs whose X and R sit in the first ncols columns of their panels; T goes to
  * V[:, m:m+ncols] (opt-in correction policy, see dav_ritz_residual_correction_n).  tol_per_col (ncols
- * entries, or NULL = inner_tol everywhere) sets the relative residual at which each pair's inner solve stops. */
+ * entries, or NULL = inner_tol everywhere) sets the relative residual at which each pair's inner solve stops; a NEGATIVE entry
+ * marks a follower: it stops at |tol| or as soon as every pair with a positive entry has stopped, whichever comes first (the
+ * corrections of the Ritz pairs beyond `lowest` only enrich the basis). */
 int dav_gjd_correction_n(dav_handle_t h, int m, int ncols, const double* theta, int max_inner, double inner_tol,
                          const double* tol_per_col, int* inner_iters_out);
 /* K4 - replaces concatenate + lapack_qr (src/davidson.f90:210-213): block Gram-Schmidt of the

@@ -12,7 +12,8 @@ import torch  # noqa: F401
 import fortran_davidson_amd as fd
 from oracle import davidson_oracle as O
 
-settings = [("0", "1e-4"), ("0.01", "1e-4"), ("0.01", "1e-2"), ("0.01", "1e-1"), ("0.1", "1e-1"), ("0.01", "0.5")]
+# a negative tolerance marks the unwanted pairs as followers: they also stop when every wanted pair has stopped
+settings = [("0", "1e-4"), ("0.01", "1e-2"), ("0.01", "-1e-2"), ("0.01", "-1e-4"), ("0.01", "1e-1"), ("0.01", "0.5")]
 orders = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "150,300,500".split(","))]
 tol = 1e-8
 bad = {s: [] for s in settings}
