@@ -30,3 +30,12 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/k_write -o w
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/k_mfma -o m -- python3 $K > $O/k_mfma.log 2>&1
 echo k2k3 done
 du -sh $O
+# the hashed matrix-free operator swept on its own (profiles/tools/free_apply.py at N=200000: 16 columns on matvec_sym9_kernel<2, GEN>,
+# 32 / 64 on the generating variant of the wide kernel): kernel stats, traffic, matrix-pipe busy
+G="profiles/tools/free_apply.py 200000 16,32,64"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/g_stats -o g -- python3 $G > $O/g_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/g_fetch -o f -- python3 $G > $O/g_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/g_write -o w -- python3 $G > $O/g_write.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/g_mfma -o m -- python3 $G > $O/g_mfma.log 2>&1
+echo generated done
+du -sh $O
