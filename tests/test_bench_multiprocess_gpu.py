@@ -71,6 +71,12 @@ def test_bench_single_gpu_default_shape_of_the_line():
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["launches"] > 0
     assert 0 < line["roofline_hbm"]["frac"] <= line["roofline_hbm"]["frac_kernel_only"] < 1
+    # the north-star figure inside `roofline` (what the driver's record keeps), against 8 TB/s and against the rates measured in this run
+    assert r["hbm_k"] == 8 and 0 < r["hbm_frac"] <= r["hbm_frac_kernel_only"] < 1
+    assert r["hbm_measured_read_GBps"] > 1000 and r["hbm_frac_of_measured_read"] > r["hbm_frac"]
+    assert line["hbm_measured"]["read_GBps"] > line["hbm_measured"]["copy_GBps"] * 0.8
+    f = line["configs4_free"]["roofline"]
+    assert f["launches_of_16_columns"] + f["launches_of_32_columns"] == line["configs4_free"]["launches"] and 0 < f["frac"] < 1.2
     assert line["configs3_gjd"]["sweeps_of_A"] > line["configs3_gjd"]["iters"]
     assert line["dropin"]["iters"] == line["small"]["iters_per_solve"]
 
