@@ -76,7 +76,11 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
       for (double* b : bufs) if (b) (void)hipFree(b);
       if (cs) (void)hipStreamDestroy(cs);
     };
-    bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+    // highest priority: the collective's few workgroups take the first CUs the sweep's work items give back, instead of queueing
+    // behind the thousands of workgroups of the sweep that is already launched
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_greatest = 0; }
+    bool ok = hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i) {
       ok = hipMalloc(&bufs[i], sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32) == hipSuccess &&
