@@ -147,8 +147,12 @@ contains
   !> lapack_generalized_eigensolver above).  Above that the host eigensolver is the largest non-device cost of
   !> an iteration (sequential MKL on the MI355X host: n = 64: 202 us DSYEV / 152 us DSYEVD, n = 256: 6.2 / 3.8 ms;
   !> n = 800: 170 ms DSYEV against a 30 ms sweep of a 160 GB matrix), so: all pairs -> divide and conquer
-  !> (DSYEVD / DSYGVD); a leading subset (nvec <= n/2, the opt-in correction policy) -> MRRR on that
-  !> subset only (DSYEVR; generalized: Cholesky reduction DPOTRF + DSYGST, back-transformation DTRSM).
+  !> (DSYEVD / DSYGVD); a SMALL leading subset (nvec <= n/8) -> MRRR on that subset only (DSYEVR; generalized:
+  !> Cholesky reduction DPOTRF + DSYGST, back-transformation DTRSM).  Where the line is, measured on the MI355X
+  !> host (profiles/tools/rr_time2.py, sequential MKL): a quarter of the pairs costs DSYEVR MORE than DSYEVD
+  !> costs for all of them (n = 128: 1108 against 754 us, n = 400: 13.3 against 10.7 ms), an eighth less
+  !> (n = 128: 646 us, n = 256: 3.0 against 3.9 ms, n = 800: 46 against 64 ms) - until round 4 the line was at
+  !> n/2, and the restart-size problem of a configs[2] solve (32 of 128 pairs) ran the slower of the two.
   !> Eigenvalues ascending; eigenvectors normalised as DSYEV / DSYGV itype=1 do (y^T stx y = I).
   subroutine lapack_rayleigh_ritz(mtx, eigenvalues, eigenvectors, nvec, stx)
     real(dp), dimension(:, :), intent(in) :: mtx
@@ -173,7 +177,7 @@ contains
        allocate(b(n, n))
        b = stx
     end if
-    if (2 * nvec > n) then
+    if (8 * nvec > n) then
        if (present(stx)) then
           call dsygvd(1, "V", "U", n, a, n, b, n, eigenvalues, query, -1, iquery, -1, info)
           call check_lapack_call(info, "DSYGVD")
