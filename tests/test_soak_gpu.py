@@ -1,0 +1,41 @@
+"""Repeated solves on one engine and repeated engine life cycles (profiles/tools/soak.py in small): results bitwise identical
+from solve to solve (every reduction of the engine is in fixed order) and no device memory left behind - the reference allocates
+and frees all work arrays inside the call (src/davidson.f90:94-96,238-244); the drop-in entry creates and destroys its engine
+the same way."""
+import numpy as np
+import pytest
+
+import fortran_davidson_amd as fd
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_mb():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2**20
+
+
+@pytest.mark.parametrize("gev,method,n,lowest", [(False, "DPR", 12000, 8), (True, "GJD", 4000, 4), (False, "GJD", 4000, 8)])
+def test_repeated_solves_are_bitwise_identical_and_leave_no_memory_behind(gev, method, n, lowest):
+    with fd.DavidsonEngine(n, lowest, None, gev=gev, storage="symmetric") as eng:
+        eng.generate_diagonal_dominant(1, 1e-3, seed=1)
+        if gev:
+            eng.set_hashed_operator(2, 1e-3, 1.0, seed=2)
+        lam0, _, it0 = eng.solve(method, 1000, 1e-8, want_vectors=False)
+        f0 = _free_mb()
+        for _ in range(40):
+            lam, _, it = eng.solve(method, 1000, 1e-8, want_vectors=False)
+            assert it == it0 and np.array_equal(lam, lam0)
+        assert abs(_free_mb() - f0) < 64
+
+
+def test_engine_life_cycles_of_the_drop_in_entry_leave_no_memory_behind():
+    n = 1200
+    A = np.asfortranarray(np.random.default_rng(0).standard_normal((n, n)))
+    A = A + A.T + np.diag(np.arange(n) * 10.0)
+    fd.generalized_eigensolver(A, 4, "DPR", 200, 1e-8)
+    f0 = _free_mb()
+    out = [fd.generalized_eigensolver(A, 4, "DPR", 200, 1e-8) for _ in range(20)]
+    assert all(np.array_equal(o[0], out[0][0]) and o[2] == out[0][2] for o in out)
+    assert abs(_free_mb() - f0) < 64
