@@ -39,3 +39,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/g_write -o w
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/g_mfma -o m -- python3 $G > $O/g_mfma.log 2>&1
 echo generated done
 du -sh $O
+# configs[3] (N=200000 generalized, GJD; profiles/tools/gjd_timing.py: a warm-up solve and six timed ones): kernel stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_stats -o c3 -- python3 profiles/tools/gjd_timing.py > $O/c3_stats.log 2>&1
+echo configs3 done
