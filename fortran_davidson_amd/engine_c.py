@@ -213,6 +213,17 @@ class CEngine:
                                               C.c_double(inner_tol), C.byref(it)))
         return it.value
 
+    def gjd_correction_n(self, m, ncols, theta, tol_per_col, max_inner=500, inner_tol=1e-12):
+        """dav_gjd_correction_n: per-column relative tolerances; a negative entry marks a follower (stops at |tol| or when every
+        column with a positive entry has stopped)"""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        tols = np.ascontiguousarray(tol_per_col, dtype=np.float64)
+        assert theta.size >= ncols and tols.size >= ncols
+        it = C.c_int(0)
+        self._chk(self.lib.dav_gjd_correction_n(self.h, C.c_int(m), C.c_int(ncols), _dp(theta), C.c_int(max_inner),
+                                                C.c_double(inner_tol), _dp(tols), C.byref(it)))
+        return it.value
+
     def ortho_gram(self, m, kt):
         Cm = np.zeros((max(m, 1), kt), order="F")
         G = np.zeros((kt, kt), order="F")

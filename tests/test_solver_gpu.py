@@ -103,6 +103,46 @@ def test_gjd_correction_solves_the_projected_systems():
         assert np.linalg.norm(P @ T[:, k] - P @ T_ref[:, k]) < 1e-6 * max(1e-30, np.linalg.norm(P @ T_ref[:, k]))
 
 
+def test_gjd_correction_per_column_tolerances_and_followers():
+    """dav_gjd_correction_n: every column stops at its own relative tolerance; a column with a NEGATIVE tolerance follows - it stops at
+    |tol| or as soon as every column with a positive tolerance has stopped, whichever comes first (include/davidson_hip.h).  The
+    residual of each projected system (src/davidson.f90:719-732) shows where its column stopped."""
+    from fortran_davidson_amd.engine_c import OP_A, PANEL_V, PANEL_W, PANEL_R, METHOD_GJD
+    n, m = 600, 8
+    A = O.generate_diagonal_dominant(n, 2e-2, seed=9)
+    V = O.generate_preconditioner(np.diag(A).copy(), m)
+    W = A @ V
+    theta, Y = O.lapack_generalized_eigensolver(V.T @ W)
+    X = V @ Y
+    R = W @ Y - X * theta[None, :]
+
+    def run(tols):
+        with fd.CEngine(n=n, max_cols=2 * m) as e:
+            e.set_dense_host(OP_A, A)
+            e.panel_put(PANEL_V, 0, V)
+            e.panel_put(PANEL_W, 0, W)
+            e.ritz_residual_correction(m, m, Y, theta, METHOD_GJD)
+            its = e.gjd_correction_n(m, m, theta, tols, 300, 1e-10)
+            T = e.panel_get(PANEL_V, m, m)
+        res = []
+        for k in range(m):
+            P = np.eye(n) - np.outer(X[:, k], X[:, k])
+            res.append(np.linalg.norm(P @ (A - theta[k] * np.eye(n)) @ P @ T[:, k] + R[:, k]) / np.linalg.norm(R[:, k]))
+        return its, np.array(res)
+
+    its_all, res_all = run(np.full(m, 1e-10))
+    assert (res_all < 1e-7).all()
+    # the second half only to 1e-2: those columns stop early, the others are solved as before
+    its_mixed, res_mixed = run(np.r_[np.full(4, 1e-10), np.full(4, 1e-2)])
+    assert (res_mixed[:4] < 1e-7).all() and (res_mixed[4:] < 0.2).all() and res_mixed[4:].max() > 1e-6
+    # followers of a leader that stops at once (tolerance 0.9): everything stops within a step or two, long before 1e-10
+    its_follow, res_follow = run(np.r_[np.full(4, 0.9), np.full(4, -1e-10)])
+    assert its_follow < its_all and its_follow <= 3 and res_follow[4:].min() > 1e-8
+    # followers stop by themselves at |tol| when the leaders take longer
+    its_f2, res_f2 = run(np.r_[np.full(4, 1e-10), np.full(4, -1e-2)])
+    assert its_f2 == its_mixed and np.allclose(res_f2, res_mixed)
+
+
 def test_device_resident_engine_and_generator(golden):
     manifest, arrays = golden
     case = manifest["dense"]["n2000_std_dpr"]
