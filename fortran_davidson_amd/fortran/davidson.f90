@@ -713,7 +713,7 @@ contains
   !> overrides; 1e-4 until round 4).  Their corrections only enrich the search space; with 1e-6, 1e-4, 1e-2 and 1e-1
   !> every golden GJD case keeps the reference's outer iteration count while the block sweeps of A drop by a third
   !> to a half (N=40000 generalized: 62 -> 45 / 39 / 33 sweeps), and over a grid of 108 problems against the oracle's
-  !> exact solves (profiles/tools/gjd_policy_sweep.py: orders 150-500, lowest 2-8, sparsity 1e-3 - 5e-2, standard
+  !> exact solves (tests/gjd_policy_sweep.py: orders 150-500, lowest 2-8, sparsity 1e-3 - 5e-2, standard
   !> and generalized) 1e-2 gives the iteration counts of 1e-4 in every case.  These pairs sit in the interior of the
   !> projected spectrum, where MINRES on A - theta B converges slowest: at configs[3] they kept the inner solve
   !> going for 13 of 18 steps after the wanted pairs had finished.  Hence the sign: a NEGATIVE tolerance (the default,

@@ -1,12 +1,13 @@
 """Outer iteration counts of the GJD solve against the oracle (the reference's exact DSYSV solves, oracle/davidson_oracle.py) over a
 grid of problems, for several settings of the inner tolerances (DAV_GJD_ADAPTIVE: wanted pairs, DAV_GJD_TOL_UNWANTED: the others):
-    python profiles/tools/gjd_policy_sweep.py
-Checker tool (uses the oracle): not part of the product path."""
+    python tests/gjd_policy_sweep.py
+Checker tool: it uses the oracle, which is test infrastructure, so it lives under tests/ (not collected by pytest; the suite runs a small
+version of it: test_solver_gpu.py::test_gjd_outer_iterations_equal_the_oracles_exact_solves_on_a_grid)."""
 import itertools
 import os
 import sys
 import time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
 import torch  # noqa: F401
 import fortran_davidson_amd as fd

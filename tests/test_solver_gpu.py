@@ -45,7 +45,7 @@ def test_gjd_outer_iterations_equal_the_oracles_exact_solves_on_a_grid(gev):
     """The engine solves the GJD correction equations inexactly (block MINRES, wanted pairs to 0.01 tol / |r|, the others to 1e-2:
     fortran/davidson.f90 gjd_tol_wanted / gjd_tol_unwanted); the reference solves them exactly (DSYSV, src/davidson.f90:700-734).
     Same outer iteration count, eigenvalues and residuals as the oracle's restatement of the reference on a grid of problems of
-    our generator (profiles/tools/gjd_policy_sweep.py runs the larger grid and the alternative settings)."""
+    our generator (tests/gjd_policy_sweep.py runs the larger grid and the alternative settings)."""
     for n, lowest, sp, seed in [(150, 2, 1e-3, 1), (150, 4, 1e-2, 2), (150, 8, 1e-2, 1), (300, 2, 1e-2, 2), (300, 4, 1e-3, 1),
                                 (300, 8, 1e-2, 2), (500, 4, 1e-2, 1), (500, 8, 1e-3, 2)]:
         A = O.generate_diagonal_dominant(n, sp, seed=seed)
