@@ -121,15 +121,17 @@ def test_config2_n20000_full_and_symmetric_storage_agree():
     assert np.abs(lams["full"] - lams["symmetric"]).max() < 1e-10
 
 
-def test_config3_n200000_one_gpu():
+@pytest.mark.parametrize("seed", [1, 5])
+def test_config3_n200000_one_gpu(seed):
     """configs[2]: N=200000 dense fp64, lowest=16, DPR, subspace restart at 80 - on ONE MI355X
-    (symmetric-tiled storage, 160 GB)."""
+    (symmetric-tiled storage, 160 GB).  Seed 1 is the bench's matrix; a second seed so that nothing here is tuned to one matrix
+    (the oracle rows the residual check is anchored to are generated for that seed too)."""
     n, L, sp = 200000, 16, 1e-3
     with fd.DavidsonEngine(n, L, 80, storage="symmetric") as eng:
-        eng.generate_diagonal_dominant(1, sp, seed=1)
+        eng.generate_diagonal_dominant(1, sp, seed=seed)
         lam, _, iters = eng.solve("DPR", 1000, TOL, want_vectors=False)
         assert 0 < iters <= 1000
-        verify_on_device(eng, lam, False, n, sp, anchor={"A": (1, None)})
+        verify_on_device(eng, lam, False, n, sp, anchor={"A": (seed, None)})
         st = eng.c.stats()
         assert st.apply_bytes / st.applies > 1.5e11            # each pass swept the 160 GB triangle
 
