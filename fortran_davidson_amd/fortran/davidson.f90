@@ -391,7 +391,7 @@ contains
     real(dp), intent(out), optional :: phase_seconds(8)
 
     integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr, nvec, nrestart
-    integer, parameter :: refresh_every = 8
+    integer :: refresh_every
     integer(c_int), allocatable :: sel(:)
     integer(c_int) :: sweeps
     logical :: drr
@@ -432,6 +432,7 @@ contains
     hm = 0.0_dp
     sm = 0.0_dp
     has_converged = .false.
+    refresh_every = restart_refresh_interval()
     nrestart = 0
     drr = .false.
     if (present(device_rr)) drr = device_rr .and. cap <= 128
@@ -547,6 +548,9 @@ contains
        end if
        call lap(3)
        eigenvalues = theta(1:lowest)
+       if (trace_iterations()) print "(a, i0, a, i0, a, es10.3, a, es10.3, a, i0)", "davidson trace: iteration ", i, " m=", m, &
+            " max residual ", maxval(errors(1:lowest)), " min ", minval(errors(1:lowest)), " below tolerance ", &
+            count(errors(1:lowest) < tolerance)
        if (sticky .and. pol == POLICY_ALL) then
           do j = 1, lowest
              if (errors(j) < tolerance) has_converged(j) = .true.
@@ -760,6 +764,32 @@ contains
     call system_clock(count, rate)
     t = real(count, dp) / real(rate, dp)
   end function tick
+
+  !> DAVIDSON_VERBOSE=2 (or more): one line per outer iteration (basis width, residual norms of the wanted pairs)
+  function trace_iterations() result(on)
+    logical :: on
+    integer :: stat, length, level
+    character(len=8) :: buf
+    on = .false.
+    call get_environment_variable("DAVIDSON_VERBOSE", buf, length, stat)
+    if (stat == 0 .and. length > 0) then
+       read (buf(1:length), *, iostat=stat) level
+       on = (stat == 0 .and. level >= 2)
+    end if
+  end function trace_iterations
+
+  !> After how many collapse restarts W = A*V (and B*V) of the kept block are recomputed instead of contracted (see the restart
+  !> branch of the loop): 8; DAV_REFRESH_EVERY overrides (1 = after every restart, as the reference does).
+  function restart_refresh_interval() result(k)
+    integer :: k, stat, length
+    character(len=16) :: buf
+    k = 8
+    call get_environment_variable("DAV_REFRESH_EVERY", buf, length, stat)
+    if (stat == 0 .and. length > 0) then
+       read (buf(1:length), *, iostat=stat) k
+       if (stat /= 0 .or. k < 1) k = 8
+    end if
+  end function restart_refresh_interval
 
   function verbose() result(on)
     logical :: on
