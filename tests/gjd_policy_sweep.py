@@ -16,7 +16,7 @@ from oracle import davidson_oracle as O
 # a negative tolerance marks the unwanted pairs as followers: they also stop when every wanted pair has stopped
 settings = [("0", "1e-4"), ("0.01", "1e-2"), ("0.01", "-1e-2"), ("0.01", "-1e-4"), ("0.01", "1e-1"), ("0.01", "0.5")]
 orders = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "150,300,500".split(","))]
-tol = 1e-8
+tol = float(os.environ.get("SWEEP_TOL", "1e-8"))
 bad = {s: [] for s in settings}
 ncases = 0
 t0 = time.time()
