@@ -306,6 +306,10 @@ def main():
                          "(python bench.py --gpus N starts torch.distributed.run by itself)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that never completes (a peer died, a link hangs) ends its rank with a message after this many seconds
+        # (the engine's watchdog; its own default is 600): every collective of this bench completes in milliseconds, the longest
+        # legitimate wait is for the slowest rank to finish generating its tiles (seconds)
+        os.environ.setdefault("DAVIDSON_COLLECTIVE_TIMEOUT", "180")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if args.control_plane_only:
         # CPU-testable part of the multi-GPU launch: what bench.py does around the engine
