@@ -39,3 +39,19 @@ def test_engine_life_cycles_of_the_drop_in_entry_leave_no_memory_behind():
     out = [fd.generalized_eigensolver(A, 4, "DPR", 200, 1e-8) for _ in range(20)]
     assert all(np.array_equal(o[0], out[0][0]) and o[2] == out[0][2] for o in out)
     assert abs(_free_mb() - f0) < 64
+
+
+def test_a_matrix_that_does_not_fit_is_refused_with_a_message_and_nothing_is_left_behind():
+    """An operator larger than the HBM: the C ABI returns an error (the Fortran front ends print it and stop, as the reference does for
+    a failed LAPACK call, src/lapack_wrapper.f90:395-408), no memory stays allocated and the next engine works."""
+    from fortran_davidson_amd.engine_c import OP_A
+    f0 = _free_mb()
+    for n, storage in ((300000, 1), (250000, 0)):               # 344 GB of tiles / 477 GB of rows
+        with pytest.raises(Exception, match="out of memory|failed"):
+            with fd.CEngine(n=n, max_cols=32) as e:
+                e.set_storage(storage)
+                e.set_dense_generated(OP_A, 1, 1e-3)
+    assert abs(_free_mb() - f0) < 64
+    with fd.DavidsonEngine(4000, 4) as eng:
+        eng.generate_diagonal_dominant(1, 1e-3, seed=1)
+        assert eng.solve("DPR", 100, 1e-8, want_vectors=False)[2] == 3
