@@ -28,6 +28,16 @@ def cases(ncases, seed):
     return out
 
 
+def free_cases(ncases, seed):
+    rng = np.random.default_rng(seed + 77)
+    out = []
+    for _ in range(ncases):
+        lowest = int(rng.choice([1, 3, 4, 8]))
+        out.append((int(rng.choice([150, 300, 600, 1000])), lowest, float(rng.choice([1e-4, 1e-3, 1e-2])), bool(rng.integers(2)),
+                    [2 * lowest, 4 * lowest, 10 * lowest][int(rng.integers(3))], int(rng.integers(1, 1000))))
+    return out
+
+
 def matrices(n, sp, gev, seed):
     from oracle import davidson_oracle as O
     A = O.generate_diagonal_dominant(n, sp, seed=seed)
@@ -46,7 +56,15 @@ if len(sys.argv) > 3 and sys.argv[3] == "--reference-child":
         A, B = matrices(n, sp, gev, s)
         lam, _, it = ref.dense_solve(A, lowest, method, 60, 1e-8, max_dim, B)
         res.append({"lam": [float(x) for x in lam], "iters": int(it)})
-    print("REFERENCE_RESULTS " + json.dumps(res))
+    # the matrix-free driver (src/davidson.f90:277-460) with numpy callbacks on the same kind of matrices (B hashed or the identity)
+    free = []
+    for n, lowest, sp, identity_b, max_dim, s in free_cases(ncases // 4, seed):
+        A, B = matrices(n, sp, True, s)
+        if identity_b:
+            B = np.eye(n)
+        lam, _, it = ref.free_solve_callbacks(n, lambda x: A @ x, lambda x: B @ x, lowest, 60, 1e-8, max_dim)
+        free.append({"lam": [float(x) for x in lam], "iters": int(it)})
+    print("REFERENCE_RESULTS " + json.dumps({"dense": res, "free": free}))
     raise SystemExit(0)
 
 t0 = time.time()
@@ -73,7 +91,8 @@ child = subprocess.run([sys.executable, os.path.abspath(__file__), str(ncases), 
 line = [ln for ln in child.stdout.splitlines() if ln.startswith("REFERENCE_RESULTS ")]
 if child.returncode != 0 or not line:
     raise SystemExit("the reference child failed: " + (child.stdout + child.stderr)[-2000:])
-reference = json.loads(line[0][len("REFERENCE_RESULTS "):])
+both = json.loads(line[0][len("REFERENCE_RESULTS "):])
+reference, reference_free = both["dense"], both["free"]
 print(f"reference: {ncases} solves in {time.time() - t0:.0f} s", flush=True)
 import torch  # noqa: F401,E402
 import fortran_davidson_amd as fd  # noqa: E402
@@ -88,4 +107,18 @@ for (method, n, lowest, sp, gev, max_dim, s), r in zip(cases(ncases, seed), refe
     bad += not ok
     print(f"{method} n={n:5d} lowest={lowest} sparsity={sp:g} gev={int(gev)} max_dim={max_dim} seed={s:3d}: reference iters {r['iters']:2d}, engine {it:2d}, "
           f"|dlam| {np.abs(lam - lam_r).max():.1e}, residual {res:.1e}{'' if ok else '   <-- MISMATCH'}", flush=True)
-print(f"{ncases} cases in {time.time() - t0:.0f} s, mismatches: {bad}")
+for (n, lowest, sp, identity_b, max_dim, s), r in zip(free_cases(ncases // 4, seed), reference_free):
+    A, B = matrices(n, sp, True, s)
+    if identity_b:
+        B = np.eye(n)
+    with fd.DavidsonEngine(n, lowest, max_dim, gev=True) as eng:
+        eng.set_hashed_operator(1, sp, seed=s)
+        eng.set_identity(2) if identity_b else eng.set_hashed_operator(2, sp, 1.0, seed=s + 1000)
+        lam, vec, it = eng.solve("DPR", 60, 1e-8)
+    res = np.linalg.norm(A @ vec - (B @ vec) * lam[None, :], axis=0).max()
+    lam_r = np.array(r["lam"])
+    ok = it == r["iters"] and np.abs(lam - lam_r).max() < 1e-8 and (res < 1e-8 or r["iters"] > 60)
+    bad += not ok
+    print(f"matrix-free n={n:5d} lowest={lowest} sparsity={sp:g} B={'I' if identity_b else 'hashed'} max_dim={max_dim} seed={s:3d}: reference iters "
+          f"{r['iters']:2d}, engine {it:2d}, |dlam| {np.abs(lam - lam_r).max():.1e}, residual {res:.1e}{'' if ok else '   <-- MISMATCH'}", flush=True)
+print(f"{ncases} dense + {ncases // 4} matrix-free cases in {time.time() - t0:.0f} s, mismatches: {bad}")
