@@ -633,6 +633,15 @@ int sym_resident_split(E* e, int which) {
 }
 
 // fraction of the block rows (by tiles) of operator `which` that a generated symmetric operator keeps resident as stored tiles
+extern "C" int dav_device_memory(dav_handle_t e, int64_t* free_bytes, int64_t* total_bytes) {
+  CHK(bind(e));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return 0;
+}
+
 extern "C" int dav_resident_fraction(dav_handle_t e, int which, double* fraction) {
   if (which < 0 || which > 1 || !fraction) return fail("dav_resident_fraction: bad arguments");
   const OpDesc& o = e->op[which];

@@ -29,7 +29,7 @@ class Stats(C.Structure):
                 ("collectives", C.c_int64), ("comm_ranks", C.c_int32), ("comm_overlap", C.c_int32)]
 
 
-ABI_VERSION = 102      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
+ABI_VERSION = 103      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
 
 
 def _dp(a):
@@ -111,6 +111,12 @@ class CEngine:
         return buf.raw
 
     # -- operators
+    def device_memory(self):
+        """(free, total) bytes of the engine's device"""
+        f, t = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.dav_device_memory(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def set_storage(self, mode):
         """0 = full storage, 1 = symmetric-tiled (lower block triangle only)."""
         self._chk(self.lib.dav_set_storage(self.h, C.c_int(mode)))

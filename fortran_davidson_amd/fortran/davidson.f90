@@ -20,7 +20,7 @@ module davidson_device
   use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_cholesky_inverse, lapack_matmul
   implicit none
   private
-  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, env_storage_symmetric, engine_set_device_rr, engine_set_inner_precision, &
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, env_storage_symmetric, fits_as_full_rows, engine_set_device_rr, engine_set_inner_precision, &
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
@@ -71,6 +71,17 @@ contains
     if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) dev
     if (stat /= 0) dev = 0
   end function env_device
+
+  !> Do `nmat` dense operators of order n fit the engine's device as full rows (8 n^2 bytes each), with a tenth of the memory left
+  !> for the panels and the partial-sum slabs?  (dav_device_memory: what is free now.)
+  function fits_as_full_rows(eng, n, nmat) result(fits)
+    type(davidson_engine), intent(in) :: eng
+    integer, intent(in) :: n, nmat
+    logical :: fits
+    integer(c_int64_t) :: free_bytes, total_bytes
+    call check_dav(dav_device_memory(eng%h, free_bytes, total_bytes), "dav_device_memory")
+    fits = 8.0_dp * real(n, dp) * real(n, dp) * real(nmat, dp) <= 0.9_dp * real(free_bytes, dp)
+  end function fits_as_full_rows
 
   !> DAVIDSON_STORAGE=symmetric selects symmetric-tiled storage for the dense front end (engines: engine_set_storage)
   function env_storage_symmetric() result(sym)
@@ -1053,7 +1064,13 @@ contains
     call engine_create(eng, size(matrix, 1), lowest, max_dim, present(second_matrix), env_device())
     ! DAVIDSON_STORAGE=symmetric: upload and keep only the lower block triangle of the (symmetric, as the reference
     ! assumes) input - half the PCIe bytes, half the HBM; default: the full matrix, as the reference's DGEMM reads it
-    if (env_storage_symmetric()) call engine_set_storage(eng, "symmetric")
+    if (env_storage_symmetric()) then
+       call engine_set_storage(eng, "symmetric")
+    else if (.not. fits_as_full_rows(eng, size(matrix, 1), merge(2, 1, present(second_matrix)))) then
+       ! the full matrices do not fit the device next to the panels, their lower block triangles may: symmetric tiles instead of
+       ! an out-of-memory stop (same results - the reference assumes a symmetric matrix; one GPU holds N = 190000 that way)
+       call engine_set_storage(eng, "symmetric")
+    end if
     call engine_set_dense(eng, 1, matrix)
     if (present(second_matrix)) call engine_set_dense(eng, 2, second_matrix)
     call generalized_eigensolver_device(eng, eigenvalues, eigenvectors, lowest, method, max_iterations, &

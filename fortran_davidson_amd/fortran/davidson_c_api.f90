@@ -244,6 +244,17 @@ contains
     out = eng%phase_seconds
   end subroutine fd_engine_phase_seconds
 
+  !> what the dense front end decides before it uploads (davidson_device: fits_as_full_rows): 1 = nmat matrices of order n fit the
+  !> engine's device as full rows, 0 = the front end switches to symmetric tiles
+  function fd_engine_fits_as_full_rows(p, n, nmat) bind(C, name="fd_engine_fits_as_full_rows") result(fits)
+    type(c_ptr), value :: p
+    integer(c_int), value :: n, nmat
+    integer(c_int) :: fits
+    type(davidson_engine), pointer :: eng
+    call c_f_pointer(p, eng)
+    fits = merge(1_c_int, 0_c_int, fits_as_full_rows(eng, int(n), int(nmat)))
+  end function fd_engine_fits_as_full_rows
+
   ! ---- helper modules (unit tests mirror src/tests/test_call_lapack.f90) ----------------------------
   subroutine fd_lapack_eigensolver(n, mtx, has_stx, stx, evals, evecs) bind(C, name="fd_lapack_eigensolver")
     integer(c_int), value :: n, has_stx

@@ -75,9 +75,9 @@ typedef struct dav_stats {
 } dav_stats;
 
 /* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */
-/* caller built against another layout of the statistics structure (it grew in 101 and 102) must not    */
+/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory) must not    */
 /* use the unsized call - the sized one, which copies at most `bytes` bytes, is safe across versions.   */
-#define DAV_HIP_ABI_VERSION 102
+#define DAV_HIP_ABI_VERSION 103
 const char* dav_last_error(void);
 int dav_version(void);
 
@@ -111,6 +111,9 @@ int dav_local_rows(dav_handle_t h, int64_t* row0, int64_t* nloc);
  * A (all-gather of the new block per sweep); symmetric = the block rows of the triangle are dealt out over
  * the ranks, N*N/2P entries each (all-gather + reduce-scatter per sweep). */
 int dav_set_storage(dav_handle_t h, int mode);
+/* Free and total memory of the engine's device in bytes (hipMemGetInfo) - what a front end needs to decide, before it uploads, whether
+ * a dense operator fits as full rows (8 N^2 / nranks bytes) or only as symmetric tiles (half of that). */
+int dav_device_memory(dav_handle_t h, int64_t* free_bytes, int64_t* total_bytes);
 /* Dense matrix from host memory, full storage a(lda, n), the caller's array as passed to
  * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and
  * extracts the diagonal (replaces array_utils.f90:115-134). */

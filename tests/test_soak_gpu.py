@@ -55,3 +55,34 @@ def test_a_matrix_that_does_not_fit_is_refused_with_a_message_and_nothing_is_lef
     with fd.DavidsonEngine(4000, 4) as eng:
         eng.generate_diagonal_dominant(1, 1e-3, seed=1)
         assert eng.solve("DPR", 100, 1e-8, want_vectors=False)[2] == 3
+
+
+def test_the_dense_front_end_switches_to_symmetric_tiles_when_the_full_rows_do_not_fit():
+    """generalized_eigensolver(matrix, ...) keeps the matrix as the reference's DGEMM reads it - full rows - unless they do not fit the
+    device next to the panels: then only the lower block triangle is uploaded (same results; the reference assumes a symmetric
+    matrix, src/davidson.f90:75-76).  The decision (fits_as_full_rows, from dav_device_memory) at orders one cannot allocate on a
+    test box's host; the tiled path itself through DAVIDSON_STORAGE=symmetric."""
+    import ctypes as C
+    with fd.DavidsonEngine(1000, 4) as eng:
+        free, total = eng.c.device_memory()
+        assert 0 < free <= total and total > 200 * 2**30              # an MI355X: 288 GB
+        fits = lambda n, nmat: eng.lib.fd_engine_fits_as_full_rows(eng.p, C.c_int(n), C.c_int(nmat))   # noqa: E731
+        assert fits(20000, 1) == 1 and fits(100000, 2) == 1           # 3.2 GB; 2 x 80 GB
+        assert fits(200000, 1) == 0 and fits(150000, 2) == 0          # 320 GB; 2 x 180 GB
+        n_edge = int((0.9 * free / 8.0) ** 0.5)
+        assert fits(n_edge - 50, 1) == 1 and fits(n_edge + 50, 1) == 0
+    n = 1500
+    A = O_matrix(n)
+    lam_full, vec_full, it_full = fd.generalized_eigensolver(A, 4, "DPR", 200, 1e-8)
+    import os
+    os.environ["DAVIDSON_STORAGE"] = "symmetric"
+    try:
+        lam_sym, vec_sym, it_sym = fd.generalized_eigensolver(A, 4, "DPR", 200, 1e-8)
+    finally:
+        del os.environ["DAVIDSON_STORAGE"]
+    assert it_sym == it_full and np.abs(lam_sym - lam_full).max() < 1e-12
+
+
+def O_matrix(n):
+    from oracle import davidson_oracle as O
+    return O.generate_diagonal_dominant(n, 1e-3, seed=3)
