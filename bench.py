@@ -243,29 +243,88 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
         return None, None
 
 
-def scaling_model(n, lowest, world):
-    """Predicted milliseconds per configs[2] solve on `world` GPUs for both storages of the operator (nothing in
-    it has been measured on more than one GPU).  One-GPU inputs (round 4, N=200000, lowest=16: one 32- and one 64-column block per
-    solve): symmetric sweeps end to end 122.0 ms per solve (kernel 116.5 + pack / fixed-order reduction 5.5) - their tiles are
-    dealt out to within 0.1 %, so they divide by the rank count; a full row slab streams 8 N^2 / P bytes per sweep at the K1
-    rates measured at N=20000 (k = 32: 0.624 of 8 TB/s end to end; k = 64: bound by the fp64 matrix pipe, 57.8 TFLOP/s);
-    Gram / panel phases + host 2.9 ms of which 1.0 ms does not shrink; collectives priced as rings at 70 GB/s per xGMI link and
-    direction (7 links per GPU), small all-reduces 50 us each."""
+REHEARSAL = os.path.join(ROOT, "profiles", "experiments", "r05_ranks_rehearsal_n200000.jsonl")
+LINK_GBPS = 70.0            # assumed payload rate of one xGMI link in one direction (153.6 GB/s bidirectional on the data sheet)
+
+
+def rehearsal_inputs():
+    """Per-rank times of a configs[2] solve on P = 1, 2, 4, 8 ranks MEASURED ON ONE GPU: P engines over the loopback transport of
+    the test build taking turns on the device (profiles/tools/ranks_rehearsal.py, DAV_TEST_SERIALIZE=1) - each rank's HIP-event
+    times are those of a rank that owns a GPU.  {P: {apply_local_ms, small_ms, collectives}} (median over the ranks, the rank that
+    goes first after the transport's host-staged collective kept apart), or {} when the log is not there."""
+    out = {}
+    try:
+        with open(REHEARSAL) as f:
+            for line in f:
+                line = line.strip()
+                if not line.startswith("{"):
+                    continue
+                d = json.loads(line)
+                if d.get("n") != 200000 or d.get("DAV_SYM_RUN9", "0") not in ("0", ""):
+                    continue
+                out[int(d["ranks"])] = {"apply_local_ms": d["apply_local_ms"]["median"], "sweep_kernel_ms": d["sweep_kernel_ms"]["median"],
+                                        "small_ms": d["gram_ms"]["median"] + d["panel_ms"]["median"],
+                                        "collectives": d["collectives_per_solve"]}
+    except (OSError, ValueError, KeyError):
+        return {}
+    return out
+
+
+def scaling_model(n, lowest, world, measured=None):
+    """Predicted milliseconds per configs[2] solve on `world` GPUs (nothing in it has run on more than one GPU).  Inputs, in this
+    order of preference: THIS run (one GPU: end-to-end sweeps, Gram / panel phases, host share of a solve), the one-GPU rehearsal
+    of P ranks taking turns on the device (per-rank sweep + packing + reduction time at P = 2, 4, 8: REHEARSAL), and two assumptions
+    that only a multi-GPU run can replace: LINK_GBPS per xGMI link and direction, 30 us per collective.  Collective volume per
+    solve and rank: all-gather and reduce-scatter of the 32- and the 64-column block (8 N 96 bytes (P-1)/P each) + the
+    reduce-scatter of W0 (8 N 32).  symmetric_ms prices them as RINGS bound by ONE link (the pessimistic end); symmetric_all_links_ms
+    as exchanges that use the P-1 direct links of the xGMI mesh at once (what RCCL's multi-ring schedules aim at) - the first
+    multi-GPU run's `comm` object (measured ms and bytes per collective) says which."""
+    P = max(int(world), 1)
+    reh = rehearsal_inputs()
+    m = dict(measured or {})
     scale = (n / 200000.0) ** 2
-    P = max(world, 1)
-    sym_sweeps = 122.0 * scale / P
-    full32 = 8.0 * n * n / P / (0.624 * 8.0e12) * 1e3
-    full64 = max(8.0 * n * n / P / (0.66 * 8.0e12), 2.0 * n * n * 64 / P / 57.8e12) * 1e3
-    block_bytes = 8.0 * n * (32 + 64)
-    ring = 0.0 if P == 1 else block_bytes * (P - 1) / P / 70.0e9 * 1e3          # one all-gather (or one reduce-scatter) of the blocks
-    # W0 = A * V0 of the 32 unit columns: gathered from the dealt-out tiles and reduce-scattered (no sweep; dav_init_basis)
-    ring0 = 0.0 if P == 1 else 8.0 * n * 32 * (P - 1) / P / 70.0e9 * 1e3
-    other = 1.0 + 1.9 * scale ** 0.5 / P + (0.0 if P == 1 else 0.05 * 10)
-    return {"symmetric_ms": round(sym_sweeps + 2 * ring + ring0 + other, 2),
-            "symmetric_overlapped_ms": round(sym_sweeps + 2 * ring / 3 + ring0 + other, 2),
-            "full_ms": round(full32 + full64 + ring + other, 2),
-            "note": "model, not a measurement: symmetric = dealt-out tiles (all-gather + reduce-scatter per block), overlapped = their "
-                    "collectives on a second stream (about two thirds hidden under the 64-column block), full = row slabs (all-gather only, twice the bytes per sweep)"}
+    base = reh.get(1, {"apply_local_ms": 123.0, "small_ms": 1.06})
+    box = (m["apply_ms"] / (base["apply_local_ms"] * scale)) if m.get("apply_ms") else 1.0      # this box against the rehearsal's
+    if P in reh:
+        local = reh[P]["apply_local_ms"] * scale * box
+        small = reh[P]["small_ms"] * scale ** 0.5 * box
+        ncoll = reh[P]["collectives"] if P > 1 else 0
+        src = "rehearsal"
+    else:
+        local = base["apply_local_ms"] * scale * box / P / (1.0 - 0.014 * (P - 1))             # fitted to the rehearsal: 0.90 at P = 8
+        small = (0.18 + 0.88 / P) * scale ** 0.5 * box
+        ncoll = 11 if P > 1 else 0
+        src = "fit"
+    host = m.get("host_ms", 1.4)
+    lat = 0.03 * ncoll
+    blk = 8.0 * n * (2 * lowest + 4 * lowest)          # the two expansion blocks of a solve: 2 lowest and 4 lowest columns
+    w0 = 8.0 * n * 2 * lowest
+    frac = (P - 1) / P
+    ring_blk = blk * frac / (LINK_GBPS * 1e9) * 1e3
+    ring_w0 = w0 * frac / (LINK_GBPS * 1e9) * 1e3
+    links_blk = 0.0 if P == 1 else blk / P / (LINK_GBPS * 1e9) * 1e3
+    links_w0 = 0.0 if P == 1 else w0 / P / (LINK_GBPS * 1e9) * 1e3
+    sym = local + small + host + lat + 2 * ring_blk + ring_w0
+    sym_links = local + small + host + lat + 2 * links_blk + links_w0
+    # opt-in (DAV_SYM_OVERLAP=1): the collectives of the 64-column block (two thirds of the block volume) run under its sweeps
+    sym_ovl = local + small + host + lat + 2 * ring_blk * (1.0 - 2.0 / 3.0 * 2.0 / 3.0) + ring_w0
+    # north_star's literal partition (row slabs, all-gather only, 8 N^2 / P bytes per sweep) at the K1 rates of this run's N=20000 leg
+    f32 = m.get("k1_frac_k32", 0.624)
+    t64 = m.get("k1_tflops_k64", 57.8)
+    full32 = 8.0 * n * n / P / (f32 * 8.0e12) * 1e3
+    full64 = max(8.0 * n * n / P / (0.66 * 8.0e12), 2.0 * n * n * 64 / P / (t64 * 1e12)) * 1e3
+    full = full32 + full64 + small + host + lat + ring_blk
+    one = m.get("ms_per_solve") or (base["apply_local_ms"] * scale * box + base["small_ms"] * scale ** 0.5 * box + host)
+    r2 = lambda x: round(x, 2)      # noqa: E731
+    return {"symmetric_ms": r2(sym), "symmetric_all_links_ms": r2(sym_links), "symmetric_overlapped_ms": r2(sym_ovl), "full_ms": r2(full),
+            "speedup_symmetric": r2(one / sym), "speedup_symmetric_all_links": r2(one / sym_links),
+            "speedup_symmetric_overlapped": r2(one / sym_ovl), "one_gpu_ms": r2(one),
+            "inputs": {"per_rank_sweeps_end_to_end_ms": r2(local), "per_rank_gram_panel_ms": r2(small), "host_ms": r2(host),
+                       "collectives_per_solve": ncoll, "latency_ms": r2(lat), "ring_ms_per_block_pass": r2(ring_blk),
+                       "all_links_ms_per_block_pass": r2(links_blk), "link_GBps_assumed": LINK_GBPS, "per_rank_times_from": src,
+                       "rehearsal_log": os.path.relpath(REHEARSAL, ROOT) if reh else None, "box_speed_vs_rehearsal": round(box, 3)},
+            "note": "model, not a measurement: symmetric = dealt-out tiles, collectives in program order as one-link rings; all_links = the "
+                    "same volume over the P-1 direct links at once; overlapped = opt-in second stream; full = row slabs"}
 
 
 def self_launch(args):

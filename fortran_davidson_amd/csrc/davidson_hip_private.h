@@ -26,6 +26,10 @@ int dav_bench_stream(dav_handle_t h, int64_t doubles, int reps, double* copy_GBp
 /* The same, plus the rate of a kernel that only READS (two of the arrays, same access pattern, one partial sum per workgroup
  * written): the practical roof of the operator sweeps, which read 8*S bytes and write 8*N*k. */
 int dav_bench_stream3(dav_handle_t h, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps, double* read_GBps);
+/* Entries per second of the arithmetic of the reference's matrix-free test operator (one fp64 atan2, sqrt, log and cos per matrix
+ * entry, src/tests/test_utils.f90:72-116) on register operands, two waves per SIMD, no memory traffic: the measured roof of the
+ * generated sweeps of that operator (bench.py: benchmark_free leg). */
+int dav_bench_harness_rate(dav_handle_t h, int iters, double* entries_per_s);
 /* dav_apply as the GJD correction solve calls it (an "inner" sweep: may read the fp32 copy of the stored tiles,
  * dav_set_inner_precision) - so that the parity tests can compare that sweep with the oracle directly. */
 int dav_apply_inner(dav_handle_t h, int which, int src_panel, int c0, int k, int dst_panel, int d0);
@@ -40,6 +44,10 @@ int dav_pack_operand_image(const double* src, int64_t ld, int p, int q, double* 
 /* Test transport: the n engines (created with rank r of n, same process, same GPU) exchange through
  * device copies and thread barriers instead of RCCL; each rank must then be driven by its own thread. */
 int dav_local_group_join(dav_handle_t* handles, int n);
+/* DAV_TEST_SERIALIZE=1 at dav_local_group_join: between two collectives the ranks' threads run ONE AT A TIME, in rank order, so
+ * that a rank's HIP-event times are those of a rank that owns a GPU.  A thread that has finished its work calls this to pass the
+ * turn on (the ranks behind it would wait for ever otherwise). */
+int dav_local_group_yield(dav_handle_t h);
 /* Second test transport: ranks are PROCESSES sharing one GPU; collectives go through the POSIX shared-memory
  * segment `name` ("/something", created by rank 0).  Exercises the complete multi-process launch flow
  * (one engine per process, as under torch.distributed.run) on a single-GPU box. */

@@ -38,6 +38,7 @@ int collect_events(E* e) {
       e->st.panel_ms += ms;
     } else {
       e->st.comm_ms += ms;
+      if (e->ev_inside[i]) e->st.apply_comm_ms += ms;
       if (e->ev_kind[i] == 5) { e->st.allgather_ms += ms; e->st.allgather_bytes += e->ev_bytes[i]; }
       else if (e->ev_kind[i] == 6) { e->st.reduce_scatter_ms += ms; e->st.reduce_scatter_bytes += e->ev_bytes[i]; }
       else if (e->ev_kind[i] == 7) { e->st.allreduce_ms += ms; e->st.allreduce_bytes += e->ev_bytes[i]; }
@@ -57,8 +58,9 @@ int timed_begin_on(E* e, int kind, double bytes, int* slot, hipStream_t stream) 
   // pairs nest (kernel inside apply): collect only while no pair is open, and leave room for the inner ones
   if (e->ev_open == 0 && e->ev_used > N_EVPAIRS - 12) CHK(collect_events(e));   // room for the inner pairs of one apply (<= 8 chunks + collectives)
   if (e->ev_used == N_EVPAIRS) { *slot = -1; return 0; }
-  ++e->ev_open;
   *slot = e->ev_used++;
+  e->ev_inside[*slot] = e->ev_open > 0 && kind >= 5;
+  ++e->ev_open;
   e->ev_done[*slot] = false;
   e->ev_kind[*slot] = kind;
   e->ev_bytes[*slot] = bytes;
@@ -246,6 +248,7 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   HIPCHK(hipHostMalloc(&e->gram_host, sizeof(double) * e->gram_doubles, hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void**)&e->gram_host_dev, e->gram_host, 0));
   HIPCHK(hipMalloc(&e->gather_dev, sizeof(double) * (size_t)e->ncols_pad));
+  HIPCHK(hipHostMalloc(&e->agree_pin, sizeof(double) * 16 * (size_t)e->nranks, hipHostMallocDefault));
   HIPCHK(hipMalloc(&e->idx_dev, sizeof(int64_t) * e->cols_alloc));
   HIPCHK(hipMalloc(&e->norm_partial, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc));
   HIPCHK(hipMalloc(&e->counters, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8)));
@@ -279,6 +282,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipFree(e->scratch);
   hipFree(e->gram_dev);
   if (e->gram_host) hipHostFree(e->gram_host);
+  if (e->agree_pin) hipHostFree(e->agree_pin);
   hipFree(e->gather_dev);
   hipFree(e->idx_dev);
   hipFree(e->norm_partial);
@@ -345,7 +349,7 @@ extern "C" int dav_get_stats_n(dav_handle_t e, void* out, size_t bytes) {
   CHK(collect_events(e));
   e->st.m = e->m;
   e->st.comm_ranks = e->comm_ranks;
-  e->st.comm_overlap = (e->comm && (e->tune.sym_overlap < 0 ? e->nranks > 1 : e->tune.sym_overlap != 0)) ? 1 : 0;
+  e->st.comm_overlap = (e->comm && e->tune.sym_overlap != 0) ? 1 : 0;
   std::memcpy(out, &e->st, std::min(bytes, sizeof(dav_stats)));
   return 0;
 }

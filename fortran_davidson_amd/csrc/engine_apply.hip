@@ -194,45 +194,49 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
     // two-block-row schedule)
     const bool gen_wide = o.kind == DAV_KIND_HASHED && e->tune.sym_gen_wide && e->tune.sym_wide > 0 && sym_schedule(e, 32, false) == 2;
     int step = (e->tune.sym_pair && !e->sym_no_pair && (o.kind == DAV_KIND_DENSE || gen_wide)) ? 32 : 16;
-    // 64 columns (the widest expansion of the doubling policy below a basis of 128) as FOUR column groups in one launch on
-    // the super-row kernels: the four workgroups of a work item share every tile read through their XCD's L2.  Same box,
-    // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  Tune::sym_quad = 0: off.
-    if (e->tune.sym_quad && step == 32 && o.kind == DAV_KIND_DENSE && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2 && !has_comm(e)) step = 64;
     // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
     // reduce-scatter of this path through RCCL on a one-GPU box)
     const bool multi = e->nranks > 1 || has_comm(e);
+    const bool pair_ok = step == 32;
+    // Opt-in (Tune::sym_overlap, DAV_SYM_OVERLAP=1 at dav_create): the collectives of a block wider than 32 columns run on a second
+    // stream under the sweeps of its 32-column chunks.  All collectives of that pipeline are issued on the ONE communication stream in
+    // the same order on every rank, ordered against the engine's stream by events, so no two collectives of the communicator are
+    // ever in flight together.  Off by default: it has never run over more than one RCCL rank (round-4 advisor); the default below
+    // keeps every collective on the engine's stream in program order.
+    if (e->tune.sym_overlap != 0 && !partial && (e->comm || has_test_transport(e)) && pair_ok && k > 32 && o.kind == DAV_KIND_DENSE &&
+        sym_schedule(e, 32, true) == 2) {
+      const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
+      if (rc != 2) return rc;                          // 2: its streams / buffers / slabs could not be set up - serial path below
+    }
+    // 64 columns (the widest expansion of the doubling policy below a basis of 128) as FOUR column groups in one launch on
+    // the super-row kernels: the four workgroups of a work item share every tile read through their XCD's L2.  Same box,
+    // N=200000, k=64: two paired launches 102.6 ms, one launch of four groups 93.6 ms (56.9 TFLOP/s).  Tune::sym_quad = 0: off.
+    // Several ranks (round 5): the same launch between ONE all-gather and ONE reduce-scatter of all four column groups - a block of
+    // 64 columns costs two collectives, not four.
+    if (e->tune.sym_quad && pair_ok && o.kind == DAV_KIND_DENSE && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2) step = 64;
     if (multi && !e->sym_wpart) {
-      HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
-      HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
+      HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 64));
+      HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 64));
     }
     const int64_t* owned = (multi || partial) ? set.row_off : nullptr;
     const int64_t total_rows = (int64_t)e->nranks * e->nslab;
-    {
-      // Default over a real multi-rank communicator (Tune::sym_overlap = -1; DAV_SYM_OVERLAP=0 / 1 at dav_create forces it off / on,
-      // 1 also over the 1-rank communicator of the GPU tests): the collectives of a block wider than 32 columns run on a second
-      // stream under the sweeps.  All collectives of the pipeline are issued on that ONE stream in the same order on every rank,
-      // ordered against the engine's stream by events, so no two collectives of the communicator are ever in flight together.
-      const bool overlap = e->tune.sym_overlap < 0 ? e->nranks > 1 : e->tune.sym_overlap != 0;
-      if (overlap && !partial && (e->comm || (has_test_transport(e) && e->tune.sym_overlap == 1)) && step == 32 && k > 32 &&
-          o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2) {
-        const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
-        if (rc != 2) return rc;                        // 2: its streams / buffers / slabs could not be set up - serial path below
-      }
-    }
     for (int c = 0; c < k; c += step) {
       int kk = std::min(step, k - c);
       int npair = (kk + 15) / 16;
       // fp32 tiles (inner sweeps of the GJD correction, opt-in) where the sweep is bound by bytes: up to 16 columns.  Wider ones
       // are bound by the fp64 matrix pipe either way, and the one-wave-per-SIMD kernel on the fp64 tiles is the faster of the two
       const bool use32 = inner && kk <= 16 && inner_f32_tiles(e, o);
-      int R = o.kind == DAV_KIND_HARNESS ? 1 : sym_schedule(e, kk, o.kind == DAV_KIND_DENSE && !use32);
+      int R = sym_schedule(e, kk, o.kind == DAV_KIND_DENSE && !use32);      // (the harness operator runs the super-row kernels too since round 5)
       if (use32 && R == 1) R = 2;            // the fp32 tiles are read by the super-row kernels only
       const SymPlan* pl = R > 1 ? &set.plan[R == 4 ? 1 : 0] : nullptr;
       const int64_t dstride = R > 1 ? (int64_t)pl->nitems * R * 16 * SYM_TB : (int64_t)set.nitems * 16 * SYM_TB;
       const int64_t tstride = R > 1 ? pl->zslots * 16 * SYM_TB : (int64_t)e->sym_nb * (e->sym_nb - 1) / 2 * 16 * SYM_TB;
       while (sym_ensure_slabs(e, (size_t)npair * (size_t)(dstride + tstride) + 1) != 0) {
-        // not enough memory for this many column groups per launch: fewer from here on (4 -> 2 -> 1)
+        // not enough memory for this many column groups per launch: fewer from here on (4 -> 2 -> 1) - on ONE rank.  Several ranks
+        // must issue the same collectives: a rank that quietly fell back to narrower launches would leave its peers in theirs
         if (npair < 2) return 1;
+        if (e->nranks > 1) return fail("symmetric sweep: no room for the partial-sum slabs of a " + std::to_string(16 * npair) +
+                                       "-column launch on rank " + std::to_string(e->rank) + " (DAV_SYM_QUAD=0 / DAV_SYM_PAIR=0 on every rank select narrower launches)");
         if (npair > 2) { e->sym_no_quad = true; step = 32; kk = 32; npair = 2; }
         else { e->sym_no_pair = true; step = 16; kk = 16; npair = 1; }
       }
@@ -378,8 +382,8 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
 int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst) {
   CHK(need_comm(e));
   if (!e->sym_wpart) {
-    HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32));
-    HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 32));
+    HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 64));
+    HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 64));
   }
   const int64_t total_rows = (int64_t)e->nranks * e->nslab;
   for (int c = 0; c < ncols; c += 32) {
@@ -510,4 +514,32 @@ extern "C" int dav_bench_stream3(dav_handle_t e, int64_t doubles, int reps, doub
 }
 extern "C" int dav_bench_stream(dav_handle_t e, int64_t doubles, int reps, double* copy_GBps, double* triad_GBps) {
   return dav_bench_stream3(e, doubles, reps, copy_GBps, triad_GBps, nullptr);
+}
+
+// Entries of the matrix-free test operator (atan2 + sqrt + log + cos in fp64, src/tests/test_utils.f90:72-116) the chip evaluates
+// per second when nothing else is in the way: the roof bench.py prices the generated sweeps of that operator against.
+extern "C" int dav_bench_harness_rate(dav_handle_t e, int iters, double* entries_per_s) {
+  CHK(bind(e));
+  if (iters <= 0) iters = 2000;
+  const int wgs = 512;
+  double* out = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  HIPCHK(hipMalloc(&out, sizeof(double) * (size_t)wgs * 512));
+  auto cleanup = [&]() { hipFree(out); for (hipEvent_t v : ev) if (v) hipEventDestroy(v); };
+  auto run = [&]() -> int {
+    HIPCHK(hipEventCreate(&ev[0]));
+    HIPCHK(hipEventCreate(&ev[1]));
+    launch_harness_rate(e->stream, out, wgs, 200);           // warm-up
+    HIPCHK(hipEventRecord(ev[0], e->stream));
+    launch_harness_rate(e->stream, out, wgs, iters);
+    HIPCHK(hipEventRecord(ev[1], e->stream));
+    HIPCHK(hipEventSynchronize(ev[1]));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    *entries_per_s = (double)wgs * 512.0 * iters / (ms * 1e-3);
+    return 0;
+  };
+  const int rc = run();
+  cleanup();
+  return rc;
 }

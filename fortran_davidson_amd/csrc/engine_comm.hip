@@ -129,7 +129,35 @@ struct LocalGroup {
   int n = 0;
   pthread_barrier_t bar;
   const double* send[16] = {nullptr};
+  // DAV_TEST_SERIALIZE=1 (read at dav_local_group_join): between two collectives only ONE rank's thread runs at a time, in rank
+  // order - each rank has the GPU to itself for its segment, so the HIP-event times of its sweeps are those of a rank that owns
+  // a GPU (what a P-rank run on P GPUs would see per rank), not of P kernels time-slicing one device.  A rehearsal tool: the
+  // wall time of such a run is the SUM over the ranks.
+  bool serialize = false;
+  int first = 0;                     // DAV_TEST_SERIALIZE_FIRST: the rank that goes first in every segment (the order is first, first + 1, ... mod n)
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t turn = 0;                 // ticket being served: segment * n + rank
+  uint64_t segment[16] = {0};        // per rank: collectives passed so far
 };
+// entry of a collective (the rank's stream is idle): hand the GPU to the next rank
+static void lg_release_turn(LocalGroup* g, int rank) {
+  if (!g->serialize || g->segment[rank] == 0) return;            // segment 0 (set-up, before the first collective) runs concurrently
+  const uint64_t pos = (uint64_t)((rank - g->first + g->n) % g->n);
+  { std::lock_guard<std::mutex> lk(g->mu); g->turn = std::max(g->turn, g->segment[rank] * (uint64_t)g->n + pos + 1); }
+  g->cv.notify_all();
+}
+// exit of a collective: wait until the ranks before this one have finished their segment
+static void lg_acquire_turn(LocalGroup* g, int rank) {
+  if (!g->serialize) return;
+  g->segment[rank] += 1;
+  const uint64_t pos = (uint64_t)((rank - g->first + g->n) % g->n);
+  const uint64_t ticket = g->segment[rank] * (uint64_t)g->n + pos;
+  std::unique_lock<std::mutex> lk(g->mu);
+  if (pos == 0 && g->turn < ticket) g->turn = ticket;            // the first rank opens the segment (everyone has passed the collective's last barrier)
+  g->cv.notify_all();
+  g->cv.wait(lk, [&] { return g->turn >= ticket; });
+}
 
 // ---- shared-memory transport: several ranks of one problem as PROCESSES that share one GPU ---------------
 // Same collective semantics again, through a POSIX shared-memory segment (staging via the host).  It lets
@@ -155,6 +183,7 @@ int test_allgather(E* e, const double* send, double* recv, size_t count) {
   if (e->lg) {
     LocalGroup* g = e->lg;
     HIPCHK(hipStreamSynchronize(e->stream));
+    lg_release_turn(g, e->rank);
     g->send[e->rank] = send;
     pthread_barrier_wait(&g->bar);
     for (int p = 0; p < g->n; ++p)
@@ -162,6 +191,7 @@ int test_allgather(E* e, const double* send, double* recv, size_t count) {
         HIPCHK(hipMemcpyAsync(recv + (size_t)p * count, g->send[p], sizeof(double) * count, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     pthread_barrier_wait(&g->bar);
+    lg_acquire_turn(g, e->rank);
     return 0;
   }
   if (e->shm) {
@@ -185,6 +215,7 @@ int test_allreduce(E* e, double* buf, size_t count) {
   if (e->lg) {
     LocalGroup* g = e->lg;
     HIPCHK(hipStreamSynchronize(e->stream));
+    lg_release_turn(g, e->rank);
     g->send[e->rank] = buf;
     pthread_barrier_wait(&g->bar);
     std::vector<double> sum(count, 0.0), tmp(count);
@@ -194,6 +225,7 @@ int test_allreduce(E* e, double* buf, size_t count) {
     }
     pthread_barrier_wait(&g->bar);            // everyone has read every buffer
     HIPCHK(hipMemcpy(buf, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    lg_acquire_turn(g, e->rank);
     return 0;
   }
   if (e->shm) {
@@ -218,6 +250,7 @@ int test_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
   if (e->lg) {
     LocalGroup* g = e->lg;
     HIPCHK(hipStreamSynchronize(e->stream));
+    lg_release_turn(g, e->rank);
     g->send[e->rank] = send;
     pthread_barrier_wait(&g->bar);
     std::vector<double> sum(count, 0.0), tmp(count);
@@ -227,6 +260,7 @@ int test_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
     }
     pthread_barrier_wait(&g->bar);
     HIPCHK(hipMemcpy(recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    lg_acquire_turn(g, e->rank);
     return 0;
   }
   if (e->shm) {
@@ -310,6 +344,16 @@ extern "C" int dav_comm_init_shm(dav_handle_t e, const char* name) {
   return 0;
 }
 
+// A rank whose thread has no further collective to enter (the end of its work) must pass the turn on, or the ranks behind it
+// would wait for ever (DAV_TEST_SERIALIZE=1); harmless otherwise.
+extern "C" int dav_local_group_yield(dav_handle_t e) {
+  if (!e || !e->lg) return 0;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  lg_release_turn(e->lg, e->rank);
+  return 0;
+}
+
 extern "C" int dav_local_group_join(dav_handle_t* handles, int n) {
   if (!handles || n < 1 || n > 16) return fail("dav_local_group_join: 1..16 engines");
   for (int r = 0; r < n; ++r)
@@ -317,6 +361,8 @@ extern "C" int dav_local_group_join(dav_handle_t* handles, int n) {
       return fail("dav_local_group_join: engine r must be created with rank r of n and have no transport yet");
   LocalGroup* g = new LocalGroup();
   g->n = n;
+  if (const char* ev = getenv("DAV_TEST_SERIALIZE")) g->serialize = ev[0] == '1';
+  if (const char* ev = getenv("DAV_TEST_SERIALIZE_FIRST")) g->first = std::max(0, std::min(n - 1, atoi(ev)));
   pthread_barrier_init(&g->bar, nullptr, (unsigned)n);
   for (int r = 0; r < n; ++r) handles[r]->lg = g;
   return 0;
@@ -426,6 +472,17 @@ int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
   NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
   CHK(timed_end(e, slot));
   return watch_mark(e, "reduce-scatter", e->stream);
+}
+
+// The same check without a collective of its own: the words wait in the engine and ride on the NEXT all-reduced small result
+// (the residual norms + Gram blocks of the Ritz phase: allreduce_with_agreement in engine_solver.hip).  One rank: only the
+// iteration hint of the watchdog's message is kept.
+extern "C" int dav_agree_next(dav_handle_t e, const double* words, int nwords) {
+  if (nwords < 0 || nwords > 16 || (nwords > 0 && !words)) return fail("dav_agree_next: 0..16 words");
+  if (nwords > 0) e->iter_hint = (long)words[0];
+  e->agree_words.clear();
+  if (e->nranks > 1 && has_comm(e)) e->agree_words.assign(words, words + nwords);
+  return 0;
 }
 
 extern "C" int dav_ranks_agree(dav_handle_t e, const double* words, int nwords) {

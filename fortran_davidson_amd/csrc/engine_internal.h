@@ -137,7 +137,7 @@ struct Tune {
   int sym_wide32 = 1;     // DAV_SYM_WIDE32: its fp32-tile variant for the mixed-precision inner sweeps of up to 16 columns
   int sym_pair = 1;       // DAV_SYM_PAIR: 32 columns per launch (two 16-column groups share their tile reads)
   int sym_quad = 1;       // DAV_SYM_QUAD: 64 columns per launch
-  int sym_overlap = -1;   // DAV_SYM_OVERLAP: collectives of wide blocks on a second stream; -1 = default (on over a real multi-rank communicator)
+  int sym_overlap = 0;    // DAV_SYM_OVERLAP=1: collectives of wide blocks on a second stream under the sweeps (opt-in until it has run over real links)
   int sym_r = 0;          // DAV_SYM_R: 1 | 2 | 4 forces the block rows per workgroup
   int sym_tall = 1;       // DAV_SYM_TALL: four block rows per workgroup at 9-16 columns
   int sym_gen_wide = 1;   // DAV_SYM_GEN_WIDE: the hashed operator at more than 16 columns generates its entries once per 32 columns (0: once per 16)
@@ -196,6 +196,8 @@ struct dav_engine {
   int group_depth = 0;            // inside ncclGroupStart / ncclGroupEnd: the group is marked once, at its end
   bool group_timed = false;       // a CollGroup times its members as a whole
   long iter_hint = -1;            // outer iteration the driver is in (dav_ranks_agree), for the watchdog's message
+  std::vector<double> agree_words;   // dav_agree_next: the driver's control words, riding on the next all-reduced small result
+  double* agree_pin = nullptr;       // pinned staging of those words (16 x nranks doubles)
   hipStream_t comm_stream = nullptr;
   bool ov_ready = false;          // stream, events and buffers of apply_sym_overlapped all exist
   hipEvent_t ov_packed[2] = {nullptr, nullptr}, ov_gathered[2] = {nullptr, nullptr}, ov_reduced[2] = {nullptr, nullptr},
@@ -230,6 +232,7 @@ struct dav_engine {
   double ev_bytes[N_EVPAIRS];
   int ev_kind[N_EVPAIRS];
   bool ev_done[N_EVPAIRS];        // end event recorded (a call that fails between begin and end leaves a pair without one)
+  bool ev_inside[N_EVPAIRS];      // a collective's pair opened inside another pair (the end-to-end pair of an apply)
   int ev_used = 0, ev_open = 0;
   int timing_level = 1;           // 0 = nothing, 1 = block matvec only, 2 = every phase
   bool lazy_x = false;            // dav_set_lazy_ritz_vectors: the Ritz phases compute X only for GJD
@@ -364,6 +367,8 @@ int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst);
 // ---- engine_solver.hip -----------------------------------------------------------------------------------
 double* result_target(E* e);
 int result_fetch(E* e, size_t count);
+int allreduce_with_agreement(E* e, size_t count, size_t* total_out);
+int agreement_verify(E* e, size_t count);
 int gram_impl(E* e, const double* P, int p, const double* Q, int q);
 int ritz_impl(E* e, int m, int ncorr, int lowest, const double* Y, int64_t ldy, const double* theta, int method,
                      double* resnorm, double* C, int64_t ldc, double* G, int64_t ldg, double* theta_out,

@@ -7,12 +7,58 @@
 // the final reduction kernel write straight into device-visible pinned memory and only synchronises
 // the stream; with a communicator the partial result is all-reduced in HBM first and then copied.
 double* result_target(E* e) { return has_comm(e) ? e->gram_dev : e->gram_host_dev; }
+
+// Several ranks: the all-reduce of `count` doubles at gram_dev - with the control words of dav_agree_next behind them when the
+// driver left any (word i of rank r in slot i * nranks + r, zeros from the other ranks: the sum reproduces every rank's value).
+// ONE collective carries the result and the agreement check (until round 4 the check was an all-reduce of its own per outer
+// iteration).  total_out: doubles to bring to the host (result + words).
+int allreduce_with_agreement(E* e, size_t count, size_t* total_out) {
+  size_t total = count;
+  const size_t nw = e->agree_words.size();
+  if (nw > 0 && e->nranks > 1) {
+    const size_t off = (count + 7) / 8 * 8, span = nw * (size_t)e->nranks;
+    if (off + span <= e->gram_doubles) {
+      // pinned staging that lives as long as the engine; every fetch that carries words ends in a stream synchronisation, so the
+      // previous copy has left it
+      std::memset(e->agree_pin, 0, sizeof(double) * span);
+      for (size_t i = 0; i < nw; ++i) e->agree_pin[i * e->nranks + e->rank] = e->agree_words[i];
+      if (off > count) HIPCHK(hipMemsetAsync(e->gram_dev + count, 0, sizeof(double) * (off - count), e->stream));
+      HIPCHK(hipMemcpyAsync(e->gram_dev + off, e->agree_pin, sizeof(double) * span, hipMemcpyHostToDevice, e->stream));
+      total = off + span;
+    }
+  }
+  CHK(coll_allreduce(e, e->gram_dev, total));
+  *total_out = total;
+  return 0;
+}
+// after the copy to gram_host and the synchronisation: every rank must have contributed the same words
+int agreement_verify(E* e, size_t count) {
+  const size_t nw = e->agree_words.size();
+  if (nw == 0 || e->nranks <= 1) { e->agree_words.clear(); return 0; }
+  const size_t off = (count + 7) / 8 * 8, span = nw * (size_t)e->nranks;
+  std::vector<double> words;
+  words.swap(e->agree_words);                            // consumed: one check per dav_agree_next
+  if (off + span > e->gram_doubles) return dav_ranks_agree(e, words.data(), (int)nw);     // no room behind this result: its own collective
+  const double* got = e->gram_host + off;
+  for (size_t i = 0; i < nw; ++i)
+    for (int r = 0; r < e->nranks; ++r)
+      if (got[i * e->nranks + r] != words[i])
+        return fail("ranks disagree on a control decision of the driver loop (word " + std::to_string(i) + ": rank " + std::to_string(r) +
+                    " has " + std::to_string(got[i * e->nranks + r]) + ", rank " + std::to_string(e->rank) + " has " +
+                    std::to_string(words[i]) + "): inputs or environment differ between the ranks");
+  return 0;
+}
+
 int result_fetch(E* e, size_t count) {
   if (has_comm(e)) {
-    CHK(coll_allreduce(e, e->gram_dev, count));
-    HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream));
+    size_t total = count;
+    CHK(allreduce_with_agreement(e, count, &total));
+    HIPCHK(hipMemcpyAsync(e->gram_host, e->gram_dev, sizeof(double) * total, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return agreement_verify(e, count);
   }
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->agree_words.clear();
   return 0;
 }
 
@@ -84,6 +130,46 @@ extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh
         if (i < c0) out[i * ld + (c0 + j)] = v;       // mirror: the projected matrices are symmetric
       }
   }
+  return 0;
+}
+
+// Projection of the new block AND the Gram blocks of its last orthonormalisation pass in ONE reduction / fetch (round 5).
+// The driver sweeps the block as it stands after the FIRST Gram-Schmidt pass (T', orthonormal to ~1e-8), W' = A T' (B T'), and
+// asks here for  [V T']^T W'  ((m + k) x k; generalized: [V T']^T (B T') too)  together with  C2 = V^T T',  G2 = T'^T T'.  The
+// second pass is linear - T'' = (T' - V C2) M2 carries W'' = (W' - W C2) M2 along (dav_ortho_apply_all) - so the projected blocks
+// of T'' follow on the host from these numbers and the H it already has.  One collective and one round trip per outer iteration
+// fewer than dav_ortho_gram + dav_project.  H_raw / S_raw: (m + k) x k, column-major.
+extern "C" int dav_project_ortho(dav_handle_t e, int m, int k, double* H_raw, int64_t ldh, double* S_raw, int64_t lds, double* C, int64_t ldc,
+                                 double* G, int64_t ldg) {
+  CHK(bind(e));
+  const int p = m + k;
+  CHK(check_panel(e, DAV_PANEL_V, 0, p));
+  if (m < 0 || k <= 0 || !H_raw || ldh < p || !C || !G || ldg < k || (m > 0 && ldc < m)) return fail("dav_project_ortho: bad shape");
+  const bool both = e->gev && S_raw != nullptr;
+  if (both && lds < p) return fail("dav_project_ortho: bad shape");
+  if (e->rr_on) return fail("dav_project_ortho: not with the device-resident Rayleigh-Ritz (dav_project_dev)");
+  const size_t blk = (size_t)p * k;
+  const int nblk = both ? 3 : 2;
+  if (nblk * blk > e->gram_doubles) return fail("gram result exceeds engine capacity");
+  if (gram_scratch_doubles(p, k, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
+  int slot;
+  CHK(timed_begin(e, 1, 0, &slot));
+  const double* Vp = panel_ptr(e, DAV_PANEL_V, 0);
+  launch_gram(e->stream, Vp, e->ldp, p, panel_ptr(e, DAV_PANEL_W, m), e->ldp, k, e->nloc_pad, e->scratch, result_target(e), e->counters, e->tune.gram_wgs);
+  launch_gram(e->stream, Vp, e->ldp, p, panel_ptr(e, DAV_PANEL_V, m), e->ldp, k, e->nloc_pad, e->scratch, result_target(e) + blk, e->counters, e->tune.gram_wgs);
+  if (both)
+    launch_gram(e->stream, Vp, e->ldp, p, panel_ptr(e, DAV_PANEL_BV, m), e->ldp, k, e->nloc_pad, e->scratch, result_target(e) + 2 * blk, e->counters, e->tune.gram_wgs);
+  CHK(timed_end(e, slot));
+  if (e->nranks > 1) CHK(need_comm(e));
+  CHK(result_fetch(e, nblk * blk));
+  const double* gh = e->gram_host;
+  for (int j = 0; j < k; ++j) {
+    std::memcpy(H_raw + (size_t)j * ldh, gh + (size_t)j * p, sizeof(double) * p);
+    for (int i = 0; i < m; ++i) C[(size_t)j * ldc + i] = gh[blk + (size_t)j * p + i];
+    for (int i = 0; i < k; ++i) G[(size_t)j * ldg + i] = gh[blk + (size_t)j * p + m + i];
+    if (both) std::memcpy(S_raw + (size_t)j * lds, gh + 2 * blk + (size_t)j * p, sizeof(double) * p);
+  }
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -286,7 +372,8 @@ extern "C" int dav_ortho_gram(dav_handle_t e, int m, int kt, double* C, int64_t 
   return 0;
 }
 
-extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm) {
+// T <- (T - V C) M on the basis panel; with_images: the same transform on W = A V (and B V), whose columns m.. hold the images of T
+static int ortho_apply_impl(E* e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm, bool with_images) {
   CHK(bind(e));
   if (m < 0 || kt <= 0 || ldm < kt) return fail("dav_ortho_apply: bad shape");
   CHK(check_panel(e, DAV_PANEL_V, 0, m + kt));
@@ -302,20 +389,32 @@ extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, i
   const int64_t ld_m = sm2[0].ldm, ld_cm = m > 0 ? sm2[1].ldm : 4;
   int slot;
   CHK(timed_begin(e, 2, 0, &slot));
-  PanelGemmArgs a{};
-  a.P1 = panel_ptr(e, DAV_PANEL_V, m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.tp1 = ld_m;
-  a.P2 = panel_ptr(e, DAV_PANEL_V, 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.tp2 = ld_cm;
-  // in place where one workgroup covers all kt output columns (k_panel.hip: a wave has read its rows of every input column before
-  // it stores the first output); wider blocks go through the scratch panel
-  const bool in_place = kt <= PG_INPLACE_COLS;
-  a.out = in_place ? panel_ptr(e, DAV_PANEL_V, m) : panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
-  a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
-  a.pin = e->tune.pg_pin;
-  launch_panel_gemm(e->stream, a);
-  if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, DAV_PANEL_V, m), e->ldp, e->nloc_pad, kt);
+  const int panels[3] = {DAV_PANEL_V, DAV_PANEL_W, DAV_PANEL_BV};
+  const int npanels = with_images ? (e->gev ? 3 : 2) : 1;
+  for (int i = 0; i < npanels; ++i) {
+    PanelGemmArgs a{};
+    a.P1 = panel_ptr(e, panels[i], m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.tp1 = ld_m;
+    a.P2 = panel_ptr(e, panels[i], 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.tp2 = ld_cm;
+    // in place where one workgroup covers all kt output columns (k_panel.hip: a wave has read its rows of every input column before
+    // it stores the first output); wider blocks go through the scratch panel
+    const bool in_place = kt <= PG_INPLACE_COLS;
+    a.out = in_place ? panel_ptr(e, panels[i], m) : panel_ptr(e, DAV_PANEL_S, 0); a.ldo = e->ldp; a.q = kt;
+    a.nloc = e->nloc; a.nrows_pad = e->nloc_pad; a.epilogue = 0;
+    a.pin = e->tune.pg_pin;
+    launch_panel_gemm(e->stream, a);
+    if (!in_place) launch_copy_columns(e->stream, panel_ptr(e, DAV_PANEL_S, 0), e->ldp, panel_ptr(e, panels[i], m), e->ldp, e->nloc_pad, kt);
+  }
   CHK(timed_end(e, slot));
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+extern "C" int dav_ortho_apply(dav_handle_t e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm) {
+  return ortho_apply_impl(e, m, kt, C, ldc, M, ldm, false);
+}
+// ... for a block that has been swept already (dav_project_ortho): W[:, m:m+kt] = A T and (generalized) BV[:, m:m+kt] = B T follow T
+extern "C" int dav_ortho_apply_all(dav_handle_t e, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm) {
+  return ortho_apply_impl(e, m, kt, C, ldc, M, ldm, true);
 }
 
 extern "C" int dav_expand(dav_handle_t e, int m, int kt) {
@@ -441,6 +540,13 @@ extern "C" int dav_rr_ritz(dav_handle_t e, int m, int ncorr, int lowest, int met
   // checked BEFORE the eigensolver and the operand packing are launched: they index the device-resident arrays with these
   if (lowest <= 0 || lowest > m || ncorr < 0 || ncorr > m) return fail("dav_rr_ritz: bad shape (0 < lowest <= m, 0 <= ncorr <= m)");
   if (C && (!G || ldc < m || ldg < ncorr)) return fail("dav_rr_ritz: bad shape");
+  if (!e->agree_words.empty()) {
+    // the device-resident Ritz phase keeps its own layout behind the all-reduced part of its result: the driver's control words get
+    // a collective of their own here, BEFORE the kernels below write their partial results (dav_ranks_agree stages in the same buffer)
+    std::vector<double> w;
+    w.swap(e->agree_words);
+    CHK(dav_ranks_agree(e, w.data(), (int)w.size()));
+  }
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
   if (!launch_small_eig(e->stream, e->rr_H, e->rr_ld, e->rr_S, e->rr_ld, m, e->gev != 0, e->rr_theta, e->rr_Y, e->rr_ld, e->rr_work, e->rr_info))

@@ -51,7 +51,10 @@ __device__ __forceinline__ const double* sym9_tile(const double* tiles, const in
 // clock - same box, N=200000, k=8, random X: 28.5 ms with every second MFMA removed 27.1 ms.
 __device__ __forceinline__ double mfma4_f64(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
-template <int R, bool GEN, bool F32, bool M4>
+// HARN (with GEN): the generated operator is the reference's matrix-free test operator (src/tests/test_utils.f90:72-116,
+// src/benchmark_free.f90:38-63: cos / sin (log (sqrt (atan2 (e_lo, e_hi)))) * 1e-4 from a table of exp(real(i) / real(n))), every
+// symmetric pair evaluated ONCE and used for both products - bound by fp64 transcendental throughput, not by memory.
+template <int R, bool GEN, bool F32, bool M4, bool HARN = false>
 __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restrict__ tiles_v, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items,
                                                              const int* __restrict__ zslot_begin, const double* __restrict__ xt,
@@ -154,8 +157,14 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     if constexpr (GEN) {
       const int64_t gi = (int64_t)Ie * SYM_TB + 128 * rhalf + 32 * hs + 2 * c;
       const int64_t gj = (int64_t)J * SYM_TB + col + g;
-      // hashed operator only: the harness operator (transcendental entries, a test fixture) stays on the one-block-row kernel
-      if (J < Ie && ((int64_t)Ie + 1) * SYM_TB <= n) {
+      if constexpr (HARN) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t cj = gj + 4 * u;
+          a[u].x = (gi < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi, cj) : 0.0;
+          a[u].y = (gi + 1 < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi + 1, cj) : 0.0;
+        }
+      } else if (J < Ie && ((int64_t)Ie + 1) * SYM_TB <= n) {
         const uint64_t k0 = (uint64_t)gi + seedmix;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -354,17 +363,20 @@ void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool
                         int nb, const int* items_dev, int nitems, const int* zslot_begin_dev, const double* xt, int kcols, double* slabD,
                         double* slabT, int npair, int64_t xt_gstride, int64_t slabD_gstride, int64_t slabT_gstride, bool m4) {
   dim3 grid(nitems * npair), block(512);
-#define DAV_SYM9_LAUNCH(RR, GG, FF, MM)                                                                                          \
-  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG, FF, MM>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, \
+#define DAV_SYM9_LAUNCH(RR, GG, FF, MM, ...)                                                                                     \
+  hipLaunchKernelGGL((matvec_sym9_kernel<RR, GG, FF, MM, ##__VA_ARGS__>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, \
                      kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
   // m4 = false (Tune::sym_mfma4 = 0): the k <= 8 sweep of a stored fp64 matrix on the 16-wide MFMA (A/B runs)
+  const bool harness = gen && op.kind == DAV_KIND_HARNESS;
   if (R == 4) {
-    if (gen) DAV_SYM9_LAUNCH(4, true, false, true);
+    if (harness) DAV_SYM9_LAUNCH(4, true, false, true, true);
+    else if (gen) DAV_SYM9_LAUNCH(4, true, false, true);
     else if (tiles_f32) DAV_SYM9_LAUNCH(4, false, true, true);
     else if (m4) DAV_SYM9_LAUNCH(4, false, false, true);
     else DAV_SYM9_LAUNCH(4, false, false, false);
   } else {
-    if (gen) DAV_SYM9_LAUNCH(2, true, false, false);
+    if (harness) DAV_SYM9_LAUNCH(2, true, false, false, true);
+    else if (gen) DAV_SYM9_LAUNCH(2, true, false, false);
     else if (tiles_f32) DAV_SYM9_LAUNCH(2, false, true, false);
     else DAV_SYM9_LAUNCH(2, false, false, false);
   }

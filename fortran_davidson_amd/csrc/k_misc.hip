@@ -190,3 +190,21 @@ void launch_stream(hipStream_t st, int mode, double* a, const double* b, const d
   if (mode == 0) hipLaunchKernelGGL(stream_kernel<0>, dim3(2048), dim3(256), 0, st, a, b, c, s, n / 2);
   else hipLaunchKernelGGL(stream_kernel<1>, dim3(2048), dim3(256), 0, st, a, b, c, s, n / 2);
 }
+
+// What the chip delivers of the matrix-free TEST operator's arithmetic (src/tests/test_utils.f90:72-116: one fp64 atan2, sqrt, log
+// and cos / sin per matrix entry): every lane evaluates `iters` entries of dav_harness_entry's chain on register operands in
+// [1, e] (the range of the exp table), no memory traffic - the roof of the generated sweeps of that operator.  8 waves per
+// workgroup, `wgs` workgroups (2 x 256 CUs: two waves per SIMD, like the sweep kernel).
+__global__ __launch_bounds__(512) void harness_rate_kernel(double* __restrict__ out, int iters, double x0, double dx) {
+  const int lane = threadIdx.x + blockIdx.x * 512;
+  double x = x0 + 1e-9 * (lane & 1023), y = 2.0 - 1e-9 * (lane & 511), acc = 0.0;
+  for (int i = 0; i < iters; ++i) {
+    acc += cos(log(sqrt(atan2(x, y)))) * (double)1e-4f;
+    x += dx;
+    y += 0.5 * dx;
+  }
+  out[lane] = acc;
+}
+void launch_harness_rate(hipStream_t st, double* out, int wgs, int iters) {
+  hipLaunchKernelGGL(harness_rate_kernel, dim3(wgs), dim3(512), 0, st, out, iters, 1.0, 1e-7);
+}

@@ -86,6 +86,7 @@ void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double*
                          int64_t nrows_pad, int k);
 // stream microbenchmark over n doubles (n even): mode 0: a = b, mode 1: a = b + s c
 void launch_stream(hipStream_t st, int mode, double* a, const double* b, const double* c, double s, int64_t n);
+void launch_harness_rate(hipStream_t st, double* out, int wgs, int iters);
 
 
 

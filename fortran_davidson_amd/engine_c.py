@@ -26,10 +26,10 @@ class Stats(C.Structure):
                 ("apply_launches", C.c_int64), ("restarts", C.c_int64),
                 ("allgather_ms", C.c_double), ("reduce_scatter_ms", C.c_double), ("allreduce_ms", C.c_double),
                 ("allgather_bytes", C.c_double), ("reduce_scatter_bytes", C.c_double), ("allreduce_bytes", C.c_double),
-                ("collectives", C.c_int64), ("comm_ranks", C.c_int32), ("comm_overlap", C.c_int32)]
+                ("collectives", C.c_int64), ("comm_ranks", C.c_int32), ("comm_overlap", C.c_int32), ("apply_comm_ms", C.c_double)]
 
 
-ABI_VERSION = 103      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
+ABI_VERSION = 104      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
 
 
 def _dp(a):
@@ -243,6 +243,25 @@ class CEngine:
         self._chk(self.lib.dav_ortho_apply(self.h, C.c_int(m), C.c_int(kt), _dp(Cm), C.c_int64(Cm.shape[0]), _dp(M),
                                            C.c_int64(M.shape[0])))
 
+    def ortho_apply_all(self, m, kt, Cm, M):
+        """dav_ortho_apply on T and on its images in the W (and BV) panels"""
+        Cm = _f(Cm) if m > 0 else np.zeros((1, kt), order="F")
+        M = _f(M)
+        self._chk(self.lib.dav_ortho_apply_all(self.h, C.c_int(m), C.c_int(kt), _dp(Cm), C.c_int64(Cm.shape[0]), _dp(M),
+                                               C.c_int64(M.shape[0])))
+
+    def project_ortho(self, m, k, gev=False):
+        """dav_project_ortho: ([V T]^T (A T), [V T]^T (B T) | None, V^T T, T^T T) in one fetch"""
+        p = m + k
+        H = np.zeros((p, k), order="F")
+        S = np.zeros((p, k), order="F") if gev else None
+        Cm = np.zeros((max(m, 1), k), order="F")
+        G = np.zeros((k, k), order="F")
+        sp = _dp(S) if gev else C.POINTER(C.c_double)()
+        self._chk(self.lib.dav_project_ortho(self.h, C.c_int(m), C.c_int(k), _dp(H), C.c_int64(p), sp, C.c_int64(p), _dp(Cm),
+                                             C.c_int64(max(m, 1)), _dp(G), C.c_int64(k)))
+        return H, S, Cm[:m], G
+
     def expand(self, m, kt):
         self._chk(self.lib.dav_expand(self.h, C.c_int(m), C.c_int(kt)))
 
@@ -272,6 +291,10 @@ class CEngine:
     def ranks_agree(self, words):
         w = np.ascontiguousarray(words, dtype=np.float64)
         self._chk(self.lib.dav_ranks_agree(self.h, _dp(w), C.c_int(w.size)))
+
+    def agree_next(self, words):
+        w = np.ascontiguousarray(words, dtype=np.float64)
+        self._chk(self.lib.dav_agree_next(self.h, _dp(w), C.c_int(w.size)))
 
     def set_inner_precision(self, bits):
         self._chk(self.lib.dav_set_inner_precision(self.h, C.c_int(bits)))
@@ -317,6 +340,12 @@ class CEngine:
         cp, tr, rd = C.c_double(), C.c_double(), C.c_double()
         self._chk(self.lib.dav_bench_stream3(self.h, C.c_int64(doubles), C.c_int(reps), C.byref(cp), C.byref(tr), C.byref(rd)))
         return cp.value, tr.value, rd.value
+
+    def bench_harness_rate(self, iters=2000):
+        """entries per second of the matrix-free test operator's arithmetic (atan2 + sqrt + log + cos, fp64) on registers"""
+        r = C.c_double(0.0)
+        self._chk(self.lib.dav_bench_harness_rate(self.h, C.c_int(iters), C.byref(r)))
+        return r.value
 
     def bench_apply2(self, k, reps, which=OP_A):
         """(ms per apply end to end, ms of the block-matvec kernel alone, algorithmic bytes, flops) per apply"""

@@ -401,7 +401,7 @@ contains
     !> wall time of this solve by phase (see davidson_engine%phase_seconds)
     real(dp), intent(out), optional :: phase_seconds(8)
 
-    integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr, nvec, nrestart
+    integer :: m, kt, i, j, cap, initial_dimension, meth, inner, phase, pol, ncorr, nvec, nrestart, opass
     integer :: refresh_every
     integer(c_int), allocatable :: sel(:)
     integer(c_int) :: sweeps
@@ -486,6 +486,11 @@ contains
           expand_now = ((m + lowest <= max_dim) .or. (m <= initial_dimension)) .and. m < cap
           ncorr = lowest
        end if
+       ! several ranks: the decisions of this iteration must be the same everywhere.  They are functions of these words and of
+       ! the all-reduced (bitwise identical) residual norms; the words ride on the all-reduce of the Ritz phase below (no
+       ! collective of their own), and a rank that differs stops with a message instead of hanging its peers
+       call check_dav(dav_agree_next(h, [real(i, dp), real(m, dp), merge(1.0_dp, 0.0_dp, expand_now), real(ncorr, dp), &
+            tolerance, real(count(has_converged), dp), real(pol, dp), real(meth, dp)], 8_c_int), "dav_agree_next")
        ! Convergence usually arrives at the widest basis, exactly where the full Ritz problem is dearest
        ! (order 64: 150-200 us on the host) although a converged iteration only needs the `lowest` wanted pairs.
        ! When the previous residues say convergence is near, solve for those pairs first (MRRR on a subset) and
@@ -570,10 +575,6 @@ contains
        else
           done = all(errors < tolerance)
        end if
-       ! several ranks: the decisions of this iteration must be the same everywhere (they are, from all-reduced
-       ! results) - enforced, so that a diverged rank stops with a message instead of hanging its peers
-       call check_dav(dav_ranks_agree(h, [real(i, dp), real(m, dp), merge(1.0_dp, 0.0_dp, done), &
-            merge(1.0_dp, 0.0_dp, expand_now), real(ncorr, dp)], 5_c_int), "dav_ranks_agree")
        if (done .or. i == max_iterations) call finish_ritz_vectors()     ! the last Ritz pairs are what a non-converged solve returns
        if (done) then
           iters = i
@@ -640,22 +641,35 @@ contains
                 end if
              end if
           end if
-          if (have_pre) then
-             call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt))
-          else
-             call block_orthonormalise(h, n, m, kt)
-          end if
-          call lap(4)
-          ! 6. one block sweep of A over the new columns, then the new rows/columns of H (and S)
-          call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
-          if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
-          call lap(5)
           if (drr) then
+             ! device-resident projected matrices: all passes first, then the sweep and the projection on the device
+             if (have_pre) then
+                call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt))
+             else
+                call block_orthonormalise(h, n, m, kt)
+             end if
+             call lap(4)
+             call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+             call lap(5)
              call check_dav(dav_project_dev(h, int(m, c_int), int(kt, c_int)), "dav_project")
+             call lap(6)
           else
-             call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+             ! first Gram-Schmidt pass only (the block is then orthonormal to ~1e-8) ...
+             if (have_pre) then
+                call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt), only_first=.true., last_pass=opass)
+             else
+                call block_orthonormalise(h, n, m, kt, only_first=.true., last_pass=opass)
+             end if
+             call lap(4)
+             ! 6. ... one block sweep of A over the new columns as that pass left them ...
+             call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+             if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
+             call lap(5)
+             ! ... and the last pass together with the projection: one reduction, one round trip (the pass is linear, so the
+             ! images A*T and B*T follow T, and the new rows / columns of H (and S) follow on the host)
+             call project_with_last_pass(opass + 1)
+             call lap(6)
           end if
-          call lap(6)
           m = m + kt
        else
           ! collapse restart: V <- V*Y(:, 1:2L) (src/davidson.f90:218).  The reference then re-applies A (and B) to the
@@ -708,6 +722,46 @@ contains
     call check_dav(dav_set_lazy_ritz_vectors(h, 0_c_int), "dav_set_lazy_ritz_vectors")
 
   contains
+
+    !> The last orthonormalisation pass of the block V(:, m+1:m+kt) (already swept: W, B*V hold its images) fused with the
+    !> projection: dav_project_ortho returns [V T]^T (A T), [V T]^T (B T), C = V^T T and G = T^T T in one fetch; the pass
+    !> T <- (T - V C) M is applied to T and its images (dav_ortho_apply_all) and to the projected blocks here:
+    !>   V^T A T'' = (Hv - H C) M,   T''^T A T'' = M^T (Ht - C^T Hv - Hv^T C + C^T H C) M   (A symmetric, as everywhere).
+    !> A pass that does not leave the block clean (rank-deficient corrections: rare) falls back to the separate passes, a second
+    !> sweep of the block and dav_project.
+    subroutine project_with_last_pass(pass)
+      integer, intent(in) :: pass
+      real(dp), allocatable, target :: hraw(:, :), sraw(:, :)
+      real(dp), allocatable :: c2(:, :), g2(:, :), mm(:, :)
+      logical, allocatable :: null_cols(:)
+      real(dp) :: wmin, wmax
+      integer :: nnull, p
+      p = m + kt
+      allocate(hraw(p, kt), c2(max(m, 1), kt), g2(kt, kt), mm(kt, kt), null_cols(kt))
+      if (gev) then
+         allocate(sraw(p, kt))
+         call check_dav(dav_project_ortho(h, int(m, c_int), int(kt, c_int), hraw, int(p, c_int64_t), c_loc(sraw), &
+              int(p, c_int64_t), c2, int(max(m, 1), c_int64_t), g2, int(kt, c_int64_t)), "dav_project_ortho")
+      else
+         call check_dav(dav_project_ortho(h, int(m, c_int), int(kt, c_int), hraw, int(p, c_int64_t), c_null_ptr, &
+              0_c_int64_t, c2, int(max(m, 1), c_int64_t), g2, int(kt, c_int64_t)), "dav_project_ortho")
+      end if
+      call ortho_pass_transform(pass, m, kt, c2, g2, mm, wmin, wmax, null_cols, nnull)
+      if (nnull == 0) then
+         call check_dav(dav_ortho_apply_all(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), mm, &
+              int(kt, c_int64_t)), "dav_ortho_apply_all")
+         if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) then
+            call project_transformed(hm, hraw, c2, mm, m, kt)
+            if (gev) call project_transformed(sm, sraw, c2, mm, m, kt)
+            return
+         end if
+      end if
+      call block_orthonormalise(h, n, m, kt, first_pass=pass + merge(1, 0, nnull == 0))
+      call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+      if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
+      call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+
+    end subroutine project_with_last_pass
 
     !> X(:, 1:lowest) = V(:, 1:m) * Y(:, 1:lowest) for the Ritz pairs of this iteration (see lazy_x above)
     subroutine finish_ritz_vectors()
@@ -829,126 +883,62 @@ contains
 
   !> Orthonormalise the kt columns T = V(:, m+1:m+kt) against V(:, 1:m) and among themselves
   !> (replaces concatenate + lapack_qr of the whole basis, src/davidson.f90:210-213).
-  !> Each pass: one device Gram [V T]^T T, a kt x kt symmetric eigen-decomposition on the host
-  !> (SVQB: T <- (T - V C) D U L^{-1/2}), one device block update.  Two passes give orthonormality to
+  !> Each pass: one device Gram [V T]^T T, a kt x kt factorisation on the host (ortho_pass_transform:
+  !> T <- (T - V C) M), one device block update.  Two passes give orthonormality to
   !> rounding; a direction that is numerically dependent (e.g. the correction of an already converged
   !> pair) is replaced by a deterministic pseudo-random vector, as Householder QR would complete the
   !> basis with an arbitrary direction.
-  subroutine block_orthonormalise(h, n, m, kt, c_first, g_first)
+  !> only_first = .true.: return after the first pass that applied a transform (its number in last_pass) - the driver then
+  !> sweeps the block and runs the last pass together with the projection (project_with_last_pass); first_pass: number of
+  !> the first pass made here (a continuation).
+  subroutine block_orthonormalise(h, n, m, kt, c_first, g_first, only_first, last_pass, first_pass)
     type(c_ptr), intent(in) :: h
     integer, intent(in) :: n, m, kt
     !> Gram blocks V^T T and T^T T of the block as it stands (first pass), when the caller already has them
     real(dp), intent(in), optional :: c_first(:, :), g_first(:, :)
+    logical, intent(in), optional :: only_first
+    integer, intent(out), optional :: last_pass
+    integer, intent(in), optional :: first_pass
     integer, parameter :: max_pass = 6
-    real(dp), parameter :: floor_rel = 1.0e-14_dp
-    real(dp), allocatable :: c(:, :), g(:, :), gp(:, :), d(:), w(:), u(:, :), mm(:, :), vec(:)
-    integer :: pass, j, l, nrep, info
-    logical :: chol_ok
-    real(dp) :: wmax, wmin, dev
-    logical :: clean
+    real(dp), allocatable :: c(:, :), g(:, :), mm(:, :), vec(:)
+    logical, allocatable :: null_cols(:)
+    integer :: pass, j, nnull, pass0
+    real(dp) :: wmax, wmin
+    logical :: clean, stop_early
 
-    allocate(c(max(m, 1), kt), g(kt, kt), gp(kt, kt), d(kt), w(kt), u(kt, kt), mm(kt, kt))
+    allocate(c(max(m, 1), kt), g(kt, kt), mm(kt, kt), null_cols(kt))
     clean = .false.
-    do pass = 1, max_pass
-       if (pass == 1 .and. present(c_first)) then
+    stop_early = .false.
+    if (present(only_first)) stop_early = only_first
+    pass0 = 1
+    if (present(first_pass)) pass0 = first_pass
+    if (present(last_pass)) last_pass = pass0
+    do pass = pass0, max(max_pass, pass0 + 2)
+       if (pass == pass0 .and. present(c_first)) then
           if (m > 0) c(1:m, :) = c_first
           g = g_first
        else
           call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
                int(kt, c_int64_t)), "dav_ortho_gram")
        end if
-       gp = g
-       if (m > 0) then
-          if (m * kt >= 4096) then
-             gp = gp - lapack_matmul("T", "N", c(1:m, :), c(1:m, :))      ! DGEMM: the intrinsic is O(100 ms) at m = kt = 400
-          else
-             gp = gp - matmul(transpose(c(1:m, :)), c(1:m, :))
-          end if
-       end if
-       ! replace numerically null columns before factoring
-       nrep = 0
-       do j = 1, kt
-          if (.not. (gp(j, j) > tiny(1.0_dp) * 1.0e16_dp)) then
-             nrep = nrep + 1
-             allocate(vec(n))
-             call pseudo_random_vector(vec, m + j + 7919 * pass)
-             call check_dav(dav_panel_put(h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(n, c_int64_t)), &
-                  "dav_panel_put")
-             deallocate(vec)
-          end if
-       end do
-       if (nrep > 0) cycle
-       do j = 1, kt
-          d(j) = 1.0_dp / sqrt(gp(j, j))
-       end do
-       do j = 1, kt
-          do l = 1, kt
-             gp(l, j) = gp(l, j) * d(l) * d(j)
-          end do
-       end do
-       ! deviation of the scaled Gram block from the identity
-       dev = 0.0_dp
-       do j = 1, kt
-          do l = 1, kt
-             if (l == j) then
-                dev = max(dev, abs(gp(l, j) - 1.0_dp))
-             else
-                dev = max(dev, abs(gp(l, j)))
+       call ortho_pass_transform(pass, m, kt, c, g, mm, wmin, wmax, null_cols, nnull)
+       if (nnull > 0) then
+          ! replace numerically null columns and repeat the pass
+          do j = 1, kt
+             if (null_cols(j)) then
+                allocate(vec(n))
+                call pseudo_random_vector(vec, m + j + 7919 * pass)
+                call check_dav(dav_panel_put(h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(n, c_int64_t)), &
+                     "dav_panel_put")
+                deallocate(vec)
              end if
           end do
-       end do
-       if (pass >= 2 .and. dev * real(kt, dp) < 1.0e-7_dp) then
-          ! already orthonormal to ~1e-7: G^(-1/2) = I - E/2 + O(E^2) is exact to rounding, no
-          ! eigen-decomposition needed (the usual state of the second pass)
-          do j = 1, kt
-             do l = 1, kt
-                mm(l, j) = -0.5_dp * gp(l, j) * d(l)
-             end do
-             mm(j, j) = (1.5_dp - 0.5_dp * gp(j, j)) * d(j)
-          end do
-          wmin = 1.0_dp - dev * real(kt, dp)
-          wmax = 1.0_dp + dev * real(kt, dp)
-       else
-          ! Cholesky route first (CholQR: M = D R^-1 with D G' D = R^T R): a k x k DPOTRF + DTRTRI costs a
-          ! fraction of a symmetric eigen-decomposition.  It is accepted only when the factor is well
-          ! conditioned (diagonal ratio); otherwise - rank deficiency, clustered corrections - the
-          ! eigen-decomposition route (SVQB) with its eigenvalue floor takes over.
-          call lapack_cholesky_inverse(gp, u, info)
-          chol_ok = .false.
-          if (info == 0) then
-             wmin = huge(1.0_dp)
-             wmax = 0.0_dp
-             do j = 1, kt
-                wmin = min(wmin, abs(u(j, j)))
-                wmax = max(wmax, abs(u(j, j)))
-             end do
-             chol_ok = wmax < 1.0e4_dp * wmin          ! cond(R) estimate below 1e4 => cond(G') below 1e8
-          end if
-          if (chol_ok) then
-             do j = 1, kt
-                do l = 1, kt
-                   mm(l, j) = d(l) * u(l, j)
-                end do
-             end do
-             ! report the conditioning in the same terms as the eigenvalue route (1/r_jj^2 ~ eigenvalues)
-             wmin = 1.0_dp / (wmax * wmax)
-             wmax = wmin * 1.0e8_dp
-          else
-             call lapack_rayleigh_ritz(gp, w, u, kt)
-             wmax = maxval(w)
-             wmin = minval(w)
-             do j = 1, kt
-                w(j) = max(w(j), floor_rel * wmax)
-             end do
-             do j = 1, kt
-                do l = 1, kt
-                   mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
-                end do
-             end do
-          end if
+          cycle
        end if
        call check_dav(dav_ortho_apply(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
             int(kt, c_int64_t)), "dav_ortho_apply")
+       if (present(last_pass)) last_pass = pass
+       if (stop_early) return
        ! a pass that started from a nearly orthonormal block (all scaled Gram eigenvalues close to 1
        ! and negligible overlap with V) leaves it orthonormal to rounding
        if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) then
@@ -960,6 +950,128 @@ contains
        print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
     end if
   end subroutine block_orthonormalise
+
+  !> Projected blocks of T'' = (T' - V C) M from those of T' (raw = [V T']^T (Op T'), (m + kt) x kt) and the projected matrix pm
+  !> of the basis so far: see project_with_last_pass.
+  subroutine project_transformed(pm, raw, c2, mm, m, kt)
+    real(dp), intent(inout) :: pm(:, :)
+    real(dp), intent(in) :: raw(:, :), c2(:, :), mm(:, :)
+    integer, intent(in) :: m, kt
+    real(dp), allocatable :: pc(:, :), newv(:, :), tt(:, :)
+    integer :: p
+    p = m + kt
+    pc = lapack_matmul("N", "N", pm(1:m, 1:m), c2(1:m, 1:kt))                            ! H C
+    newv = lapack_matmul("N", "N", raw(1:m, 1:kt) - pc, mm(1:kt, 1:kt))
+    tt = raw(m + 1:p, 1:kt) - lapack_matmul("T", "N", c2(1:m, 1:kt), raw(1:m, 1:kt)) &
+         - lapack_matmul("T", "N", raw(1:m, 1:kt), c2(1:m, 1:kt)) + lapack_matmul("T", "N", c2(1:m, 1:kt), pc)
+    pm(1:m, m + 1:p) = newv
+    pm(m + 1:p, 1:m) = transpose(newv)
+    pm(m + 1:p, m + 1:p) = lapack_matmul("T", "N", mm(1:kt, 1:kt), lapack_matmul("N", "N", tt, mm(1:kt, 1:kt)))
+  end subroutine project_transformed
+
+  !> The transform of ONE block Gram-Schmidt pass from its Gram blocks C = V^T T (m x kt) and G = T^T T (kt x kt):
+  !> T <- (T - V C) M.  wmin / wmax: conditioning of the scaled Gram block G' = D (G - C^T C) D the pass started from (a pass
+  !> numbered >= 2 with wmin > 0.5 and wmax < 2 leaves the block orthonormal to rounding).  nnull > 0: the columns flagged in
+  !> null_cols are numerically null - no transform is made, the caller replaces them and repeats the pass.
+  subroutine ortho_pass_transform(pass, m, kt, c, g, mm, wmin, wmax, null_cols, nnull)
+    integer, intent(in) :: pass, m, kt
+    real(dp), intent(in) :: c(:, :), g(:, :)
+    real(dp), intent(out) :: mm(kt, kt), wmin, wmax
+    logical, intent(out) :: null_cols(kt)
+    integer, intent(out) :: nnull
+    real(dp), parameter :: floor_rel = 1.0e-14_dp
+    real(dp), allocatable :: gp(:, :), d(:), w(:), u(:, :)
+    integer :: j, l, info
+    logical :: chol_ok
+    real(dp) :: dev
+
+    allocate(gp(kt, kt), d(kt), w(kt), u(kt, kt))
+    wmin = 0.0_dp
+    wmax = huge(1.0_dp)
+    gp = g(1:kt, 1:kt)
+    if (m > 0) then
+       if (m * kt >= 4096) then
+          gp = gp - lapack_matmul("T", "N", c(1:m, 1:kt), c(1:m, 1:kt))      ! DGEMM: the intrinsic is O(100 ms) at m = kt = 400
+       else
+          gp = gp - matmul(transpose(c(1:m, 1:kt)), c(1:m, 1:kt))
+       end if
+    end if
+    nnull = 0
+    do j = 1, kt
+       null_cols(j) = .not. (gp(j, j) > tiny(1.0_dp) * 1.0e16_dp)
+       if (null_cols(j)) nnull = nnull + 1
+    end do
+    if (nnull > 0) return
+    do j = 1, kt
+       d(j) = 1.0_dp / sqrt(gp(j, j))
+    end do
+    do j = 1, kt
+       do l = 1, kt
+          gp(l, j) = gp(l, j) * d(l) * d(j)
+       end do
+    end do
+    ! deviation of the scaled Gram block from the identity
+    dev = 0.0_dp
+    do j = 1, kt
+       do l = 1, kt
+          if (l == j) then
+             dev = max(dev, abs(gp(l, j) - 1.0_dp))
+          else
+             dev = max(dev, abs(gp(l, j)))
+          end if
+       end do
+    end do
+    if (pass >= 2 .and. dev * real(kt, dp) < 1.0e-7_dp) then
+       ! already orthonormal to ~1e-7: G^(-1/2) = I - E/2 + O(E^2) is exact to rounding, no
+       ! eigen-decomposition needed (the usual state of the second pass)
+       do j = 1, kt
+          do l = 1, kt
+             mm(l, j) = -0.5_dp * gp(l, j) * d(l)
+          end do
+          mm(j, j) = (1.5_dp - 0.5_dp * gp(j, j)) * d(j)
+       end do
+       wmin = 1.0_dp - dev * real(kt, dp)
+       wmax = 1.0_dp + dev * real(kt, dp)
+    else
+       ! Cholesky route first (CholQR: M = D R^-1 with D G' D = R^T R): a k x k DPOTRF + DTRTRI costs a
+       ! fraction of a symmetric eigen-decomposition.  It is accepted only when the factor is well
+       ! conditioned (diagonal ratio); otherwise - rank deficiency, clustered corrections - the
+       ! eigen-decomposition route (SVQB) with its eigenvalue floor takes over.
+       call lapack_cholesky_inverse(gp, u, info)
+       chol_ok = .false.
+       if (info == 0) then
+          wmin = huge(1.0_dp)
+          wmax = 0.0_dp
+          do j = 1, kt
+             wmin = min(wmin, abs(u(j, j)))
+             wmax = max(wmax, abs(u(j, j)))
+          end do
+          chol_ok = wmax < 1.0e4_dp * wmin          ! cond(R) estimate below 1e4 => cond(G') below 1e8
+       end if
+       if (chol_ok) then
+          do j = 1, kt
+             do l = 1, kt
+                mm(l, j) = d(l) * u(l, j)
+             end do
+          end do
+          ! report the conditioning in the same terms as the eigenvalue route (1/r_jj^2 ~ eigenvalues)
+          wmin = 1.0_dp / (wmax * wmax)
+          wmax = wmin * 1.0e8_dp
+       else
+          call lapack_rayleigh_ritz(gp, w, u, kt)
+          wmax = maxval(w)
+          wmin = minval(w)
+          do j = 1, kt
+             w(j) = max(w(j), floor_rel * wmax)
+          end do
+          do j = 1, kt
+             do l = 1, kt
+                mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
+             end do
+          end do
+       end if
+    end if
+  end subroutine ortho_pass_transform
 
   !> yk (m x kt) <- yk * M with M = G^(-1/2)-like (Cholesky R^-1, or the eigen-decomposition route with an eigenvalue
   !> floor when the factor is ill-conditioned), G = yk^T yk: the columns of the result are Euclidean-orthonormal.

@@ -22,10 +22,11 @@ module davidson_hip_c
      real(c_double) :: allgather_bytes, reduce_scatter_bytes, allreduce_bytes
      integer(c_int64_t) :: collectives
      integer(c_int32_t) :: comm_ranks, comm_overlap
+     real(c_double) :: apply_comm_ms
   end type dav_stats
   !> DAV_HIP_ABI_VERSION of include/davidson_hip.h these interfaces were written against: engine_create checks that the
-  !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101 and 102)
-  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 103
+  !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101, 102 and 104)
+  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 104
 
   interface
      function dav_last_error() bind(C, name="dav_last_error") result(p)
@@ -278,6 +279,23 @@ module davidson_hip_c
        integer(c_int64_t), value :: ldc, ldm
        integer(c_int) :: ierr
      end function
+     function dav_ortho_apply_all(h, m, kt, c, ldc, mm, ldm) bind(C, name="dav_ortho_apply_all") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, kt
+       integer(c_int64_t), value :: ldc, ldm
+       real(c_double), intent(in) :: c(*), mm(*)
+       integer(c_int) :: ierr
+     end function
+     function dav_project_ortho(h, m, k, hraw, ldh, sraw, lds, c, ldc, g, ldg) bind(C, name="dav_project_ortho") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: m, k
+       integer(c_int64_t), value :: ldh, lds, ldc, ldg
+       real(c_double), intent(out) :: hraw(*), c(*), g(*)
+       type(c_ptr), value :: sraw
+       integer(c_int) :: ierr
+     end function
      function dav_expand(h, m, kt) bind(C, name="dav_expand") result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: h
@@ -285,6 +303,13 @@ module davidson_hip_c
        integer(c_int) :: ierr
      end function
      function dav_ranks_agree(h, words, nwords) bind(C, name="dav_ranks_agree") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: words(*)
+       integer(c_int), value :: nwords
+       integer(c_int) :: ierr
+     end function
+     function dav_agree_next(h, words, nwords) bind(C, name="dav_agree_next") result(ierr)
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
        real(c_double), intent(in) :: words(*)

@@ -72,12 +72,14 @@ typedef struct dav_stats {
   int64_t collectives;     /* collectives (or groups of them) issued so far, at any timing level      */
   int32_t comm_ranks;      /* ranks the RCCL communicator reports (ncclCommCount); 0 = no communicator */
   int32_t comm_overlap;    /* 1 = wide blocks run their collectives on a second stream under the sweeps */
+  double apply_comm_ms;    /* (ABI 104) the part of the collectives' time that lies INSIDE apply_ms (all-gather / reduce-scatter of the */
+                           /* applies, timing level 2): apply_ms - apply_comm_ms = packing + kernel + reduction of this rank            */
 } dav_stats;
 
 /* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */
-/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory) must not    */
+/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next) must not    */
 /* use the unsized call - the sized one, which copies at most `bytes` bytes, is safe across versions.   */
-#define DAV_HIP_ABI_VERSION 103
+#define DAV_HIP_ABI_VERSION 104
 const char* dav_last_error(void);
 int dav_version(void);
 
@@ -225,6 +227,16 @@ int dav_gjd_correction_n(dav_handle_t h, int m, int ncols, const double* theta, 
 int dav_ortho_gram(dav_handle_t h, int m, int kt, double* C, int64_t ldc, double* G, int64_t ldg);
 int dav_ortho_apply(dav_handle_t h, int m, int kt, const double* C, int64_t ldc,
                     const double* M, int64_t ldm);
+/* (ABI 104) The LAST Gram-Schmidt pass fused with the projection: the driver sweeps the block as the first pass left it (T',
+ * orthonormal to ~1e-8: dav_expand), then ONE reduction / fetch returns the raw projected blocks [V T']^T (A T') (and, S_raw
+ * != NULL on a generalized engine, [V T']^T (B T')), each (m + k) x k, together with C = V^T T' and G = T'^T T' of that pass.
+ * The pass is linear, T'' = (T' - V C) M, so dav_ortho_apply_all applies it to T' AND to its images A T', B T' in the W / BV
+ * panels, and the projected blocks of T'' follow on the host: V^T A T'' = (H_raw_V - H C) M, T''^T A T'' = M^T (H_raw_T - C^T
+ * H_raw_V - H_raw_V^T C + C^T H C) M.  Replaces dav_ortho_gram + dav_project of the same iteration: one host round trip and,
+ * with several ranks, one all-reduce fewer per outer iteration.  Not with dav_rr_enable. */
+int dav_project_ortho(dav_handle_t h, int m, int k, double* H_raw, int64_t ldh, double* S_raw, int64_t lds,
+                      double* C, int64_t ldc, double* G, int64_t ldg);
+int dav_ortho_apply_all(dav_handle_t h, int m, int kt, const double* C, int64_t ldc, const double* M, int64_t ldm);
 /* Commit T as basis columns m..m+kt-1 and apply the operators to them (device operators only):
  * W[:, m:m+kt] = A*T (one block sweep of A - the only one per iteration), BV likewise. */
 int dav_expand(dav_handle_t h, int m, int kt);
@@ -238,6 +250,12 @@ int dav_restart(dav_handle_t h, int m, int keep, const double* Yk, int64_t ldy);
  * iteration) - one small all-reduce; a no-op on a single rank.  Lets a diverged rank end with a message instead of
  * leaving its peers in a collective. */
 int dav_ranks_agree(dav_handle_t h, const double* words, int nwords);
+/* The same check without a collective of its own (ABI 104): the words (at most 16) wait in the engine and ride on the NEXT
+ * all-reduced small result - the residual norms and Gram blocks of dav_ritz_residual_correction_* - behind the payload; the call
+ * that fetches that result fails on every rank when the words differ.  The Fortran driver calls it at the top of every outer
+ * iteration with (iteration, basis width, grow-or-restart, corrections, tolerance, converged flags): together with the
+ * all-reduced (hence bitwise identical) residual norms they determine every decision of the iteration.  One rank: a no-op. */
+int dav_agree_next(dav_handle_t h, const double* words, int nwords);
 /* Mixed-precision correction path (opt-in).  bits = 32: the block sweeps inside the GJD correction solve
  * (replacing the dense projected solves of src/davidson.f90:700-734 + src/lapack_wrapper.f90:238-277) read an fp32 copy of
  * the stored symmetric tiles (made on first use; half the bytes per inner sweep), widen to fp64 in registers and

@@ -87,6 +87,17 @@ def free_solve_harness(n, lowest, max_it=1000, tol=1e-8, max_dim=20):
     return evals, evecs, iters.value
 
 
+def free_solve_benchmark(n=1000, lowest=3, max_it=1000, tol=1e-8, max_dim=20):
+    """The reference's benchmark program as a call (benchmark_free.f90:80-111): A = the cos row generator, B = I, DPR; defaults =
+    that program's parameters."""
+    evals = np.zeros(lowest)
+    evecs = np.zeros((n, lowest), order="F")
+    iters = C.c_int(-1)
+    lib().ref_free_solve_benchmark(C.c_int(n), C.c_int(lowest), C.c_int(max_it), C.c_double(tol),
+                                   C.c_int(max_dim), _p(evals), _p(evecs), C.byref(iters))
+    return evals, evecs, iters.value
+
+
 def free_solve_callbacks(n, apply_a, apply_b, lowest, max_it=1000, tol=1e-8, max_dim=20):
     """Reference matrix-free solve (davidson.f90:277-460) with numpy callbacks X(n,k)->Y(n,k)."""
     def wrap(fn):

@@ -47,6 +47,28 @@ contains
 end module ref_driver_callbacks
 
 
+!> The second operator of the reference's benchmark program (src/benchmark_free.f90:65-76, :24-34): the identity, applied the way
+!> that program applies it - through the reference's free_matmul with a row function that returns e_i.
+module ref_driver_benchmark
+  use numeric_kinds, only: dp
+  use davidson_free, only: free_matmul
+  implicit none
+contains
+  function unit_row(i, dim) result(vector)
+    integer, intent(in) :: i, dim
+    real(dp), dimension(dim) :: vector
+    vector = 0.0_dp
+    vector(i) = 1.0_dp
+  end function unit_row
+
+  function apply_unit_rows(input_vect) result(output_vect)
+    real(dp), dimension(:, :), intent(in) :: input_vect
+    real(dp), dimension(size(input_vect, 1), size(input_vect, 2)) :: output_vect
+    output_vect = free_matmul(unit_row, input_vect)
+  end function apply_unit_rows
+end module ref_driver_benchmark
+
+
 !> dense solve: matrix (n,n) column-major, optional second matrix, method 0=DPR 1=GJD,
 !> max_dim < 0 means "argument absent" (davidson.f90:115-119).
 subroutine ref_dense_solve(n, a, has_b, b, lowest, method, max_it, tol, max_dim, evals, evecs, iters) bind(C)
@@ -100,6 +122,26 @@ subroutine ref_free_solve_harness(n, lowest, max_it, tol, max_dim, evals, evecs,
        apply_stx_to_vect)
   iters = it
 end subroutine ref_free_solve_harness
+
+
+!> the reference's benchmark program as a call (src/benchmark_free.f90:80-111): A = the cos row generator of the tests
+!> (test_utils: apply_mtx_to_vect - the same function as that program's mtx_gemv), B = I through free_matmul, DPR.
+subroutine ref_free_solve_benchmark(n, lowest, max_it, tol, max_dim, evals, evecs, iters) bind(C)
+  use iso_c_binding
+  use numeric_kinds, only: dp
+  use davidson, only: generalized_eigensolver
+  use test_utils, only: apply_mtx_to_vect
+  use ref_driver_benchmark, only: apply_unit_rows
+  implicit none
+  integer(c_int), value :: n, lowest, max_it, max_dim
+  real(c_double), value :: tol
+  real(c_double), intent(out) :: evals(lowest), evecs(n, lowest)
+  integer(c_int), intent(out) :: iters
+  integer :: it
+  it = -1
+  call generalized_eigensolver(apply_mtx_to_vect, evals, evecs, lowest, "DPR", max_it, tol, it, max_dim, apply_unit_rows)
+  iters = it
+end subroutine ref_free_solve_benchmark
 
 
 !> matrix-free solve with C callbacks y = A x, y = B x (x, y are (n,k) column-major).

@@ -24,7 +24,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 30
     assert not [n for n in names if n.startswith("dav_bench_") or n in ("dav_local_group_join", "dav_comm_init_shm")]
     private = _declared(os.path.join(ROOT, "fortran_davidson_amd", "csrc", "davidson_hip_private.h"))
-    test_only = ["dav_local_group_join", "dav_comm_init_shm"]
+    test_only = ["dav_local_group_join", "dav_local_group_yield", "dav_comm_init_shm"]
     assert all(n in private for n in test_only + ["dav_bench_apply2", "dav_bench_stream", "dav_apply_inner"])
     libdir = os.path.join(ROOT, "fortran_davidson_amd", "lib")
     fd.hip_lib()                 # first: it brings PyTorch's HIP runtime in before any other copy (see _lib.py)

@@ -181,42 +181,79 @@ def test_config5_n1000000_matrix_free_one_rank():
         verify_on_device(eng, lam, True, n, sp, anchor={"A": (1, None)})      # B = I
 
 
-@pytest.mark.parametrize("storage", ["full", "symmetric"])
-def test_config5_n1000000_matrix_free_four_ranks(storage):
-    """configs[4] as BASELINE.json partitions it - rows over the ranks, all-gather of the new block each iteration -
-    with 4 ranks as threads on one GPU (loopback transport): row slabs (every rank generates its N/4 rows) and
-    symmetric generation (every rank generates the lower-triangle tiles of its block rows; reduce-scatter of the
-    partial products).  Same eigenvalues and iteration count on every rank as the one-rank run."""
+def _loopback_ranks(engs, work, timeout=900):
+    """The engines (rank r of len(engs), one process, one GPU) joined through the loopback transport, each driven by its own thread."""
     import ctypes as C
-    import threading
-    n, L, sp, nranks = 1000000, 8, 1e-3, 4
-    engs = [fd.DavidsonEngine(n, L, 80, gev=True, rank=r, nranks=nranks, storage=storage) for r in range(nranks)]
+    nranks = len(engs)
     handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
     assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
     out, err = [None] * nranks, [None] * nranks
 
-    def work(r):
+    def run(r):
         try:
-            engs[r].set_hashed_operator(1, sp, seed=1)
-            engs[r].set_identity(2)
-            lam, _, iters = engs[r].solve("DPR", 100, TOL, want_vectors=False)
-            verify_on_device(engs[r], lam, True, n, sp, anchor={"A": (1, None)})
-            out[r] = (lam, iters)
+            out[r] = work(r, engs[r])
         except Exception as exc:      # noqa: BLE001
             err[r] = exc
+        finally:
+            fd.hip_lib().dav_local_group_yield(engs[r].c.h)          # ranks taking turns: the next one may go
 
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
     [t.start() for t in threads]
-    [t.join(timeout=600) for t in threads]
+    [t.join(timeout=timeout) for t in threads]
     for e in engs:
         e.close()
     assert all(x is None for x in err), err
-    assert all(o is not None for o in out)
-    for lam, iters in out:
+    assert all(o is not None for o in out), "a rank did not finish"
+    return out
+
+
+def _experiment_log(name, doc):
+    """Measurements of a rehearsal, kept for profiles/experiments/ (gpurun_out/ travels back from the GPU box)."""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(doc, f, indent=1)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("storage", ["full", "symmetric"])
+def test_config5_n1000000_matrix_free_eight_ranks(storage, monkeypatch):
+    """configs[4] as BASELINE.json states it - N=10^6, rows over EIGHT ranks, all-gather of the new block each iteration -
+    with the 8 ranks as threads on one GPU (loopback transport, the ranks taking turns on the device): row slabs (every rank
+    generates its N/8 rows) and symmetric generation (every rank generates the lower-triangle tiles of the block rows dealt out
+    to it; reduce-scatter of the partial products).  Same eigenvalues and iteration count on every rank as the one-rank run; the
+    per-rank device memory stays within the budget a 288 GB GPU leaves."""
+    monkeypatch.setenv("DAV_TEST_SERIALIZE", "1")
+    n, L, sp, nranks = 1000000, 8, 1e-3, 8
+    with fd.CEngine(n=1024, max_cols=16) as probe:
+        free0, _ = probe.device_memory()
+    engs = [fd.DavidsonEngine(n, L, 80, gev=True, rank=r, nranks=nranks, storage=storage) for r in range(nranks)]
+
+    def work(r, eng):
+        eng.set_hashed_operator(1, sp, seed=1)
+        eng.set_identity(2)
+        lam, _, iters = eng.solve("DPR", 100, TOL, want_vectors=False)
+        free1, _ = eng.c.device_memory()
+        verify_on_device(eng, lam, True, n, sp, anchor={"A": (1, None)})
+        st = eng.c.stats()
+        return lam, iters, free1, st.apply_kernel_ms / max(st.apply_launches, 1), int(st.collectives)
+
+    out = _loopback_ranks(engs, work)
+    for lam, iters, _, _, _ in out:
         assert np.array_equal(lam, out[0][0]) and iters == out[0][1]
     # the one-rank run of this problem (bench.py configs4_free leg, same seed): first three eigenvalues
     assert np.abs(out[0][0][:3] - np.array([0.9999946355480692, 1.9999955176766737, 2.9999964218285395])).max() < 1e-9
     assert out[0][1] == 4
+    per_rank_gb = (free0 - min(o[2] for o in out)) / nranks / 1e9
+    assert per_rank_gb < 40.0, per_rank_gb             # panels 0.9 GB + partial-sum slabs of the rank's share of the generated triangle
+    _experiment_log(f"r05_eight_ranks_n1000000_{storage}.json",
+                    {"n": n, "ranks": nranks, "storage": storage, "iters": out[0][1], "per_rank_device_GB": round(per_rank_gb, 2),
+                     "sweep_kernel_ms_per_launch_by_rank": [round(o[3], 2) for o in out], "collectives_by_rank": [o[4] for o in out],
+                     "note": "ranks take turns on the one GPU (DAV_TEST_SERIALIZE=1): a rank's kernel times are those of a rank that owns a GPU"})
 
 
 # lowest eigenvalues of configs[2] (seed 1) from the one-rank run: bench.py headline, profiles/r04_bench_default.log
@@ -261,6 +298,57 @@ def test_config3_n200000_two_ranks_dealt_tiles(overlap, monkeypatch):
     # the one-rank run of this problem (test_config3_n200000_one_gpu / bench.py headline, same seed)
     assert out[0][1] == 3
     assert np.abs(out[0][0][:3] - np.array(ONE_RANK_CONFIG3_LAM[:3])).max() < 1e-10
+
+
+def test_config3_n200000_eight_ranks_dealt_tiles(monkeypatch):
+    """configs[2] at its full order on EIGHT ranks - what `bench.py --gpus 8` runs on an 8-GPU node - as threads on the one GPU
+    (loopback transport; DAV_TEST_SERIALIZE=1: the ranks take turns on the device, so each rank's HIP-event times are those of a
+    rank that owns a GPU).  782 block rows dealt out by groups of four to 8 owners (20 GB of tiles per rank), 8-way all-gather /
+    reduce-scatter layouts, collectives in program order.  Asserted: the one-rank iteration count and eigenvalues (1e-10), the
+    eigenpairs against the generator on every rank, the per-rank device memory, the collectives per solve; the per-rank sweep
+    times go to gpurun_out/ (they are the inputs of bench.py's scaling model)."""
+    monkeypatch.setenv("DAV_TEST_SERIALIZE", "1")
+    n, L, sp, nranks = 200000, 16, 1e-3, 8
+    with fd.CEngine(n=1024, max_cols=16) as probe:
+        free0, _ = probe.device_memory()
+    engs = [fd.DavidsonEngine(n, L, 80, rank=r, nranks=nranks, storage="symmetric") for r in range(nranks)]
+
+    def work(r, eng):
+        eng.generate_diagonal_dominant(1, sp, seed=1)
+        lam, _, iters = eng.solve("DPR", 1000, TOL, want_vectors=False)          # warm-up: lazy workspace
+        eng.c.set_timing(2)
+        eng.c.synchronize(); eng.c.reset_stats()
+        lam, _, iters = eng.solve("DPR", 1000, TOL, want_vectors=False)
+        eng.c.synchronize()
+        st = eng.c.stats()
+        rec = {"rank": r, "iters": iters, "collectives": int(st.collectives), "sweep_launches": int(st.apply_launches),
+               "sweep_kernel_ms": st.apply_kernel_ms, "apply_local_ms": st.apply_ms - st.apply_comm_ms,
+               "gram_ms": st.gram_ms, "panel_ms": st.panel_ms, "tiles_GB": st.apply_bytes / max(st.applies, 1) / 1e9,
+               "allgather_MB": st.allgather_bytes / 1e6, "reduce_scatter_MB": st.reduce_scatter_bytes / 1e6,
+               "allreduce_KB": st.allreduce_bytes / 1e3}
+        eng.c.set_timing(1)
+        free1, _ = eng.c.device_memory()
+        verify_on_device(eng, lam, False, n, sp, anchor={"A": (1, None)})
+        return lam, iters, free1, rec
+
+    out = _loopback_ranks(engs, work)
+    for lam, iters, _, rec in out:
+        assert np.array_equal(lam, out[0][0]) and iters == out[0][1]
+        assert 0.18e2 < rec["tiles_GB"] < 0.23e2                 # every rank swept its eighth of the triangle (+ the block)
+        # init: reduce-scatter of W0 + projection; per growing iteration: Ritz phase (norms + Gram + control words), second
+        # orthonormalisation pass, all-gather, reduce-scatter, projection; last iteration: the Ritz phase
+        assert rec["collectives"] <= 13, rec
+    assert out[0][1] == 3
+    assert np.abs(out[0][0][:3] - np.array(ONE_RANK_CONFIG3_LAM[:3])).max() < 1e-10
+    per_rank_gb = (free0 - min(o[2] for o in out)) / nranks / 1e9
+    assert per_rank_gb < 26.0, per_rank_gb             # 20.1 GB of tiles + partial-sum slabs + panels + exchange buffers
+    recs = [o[3] for o in out]
+    sweep = [r_["sweep_kernel_ms"] for r_ in recs]
+    _experiment_log("r05_eight_ranks_n200000.json",
+                    {"n": n, "ranks": nranks, "lowest": L, "iters": out[0][1], "per_rank_device_GB": round(per_rank_gb, 2),
+                     "sweep_kernel_ms_per_solve_min_max": [round(min(sweep), 3), round(max(sweep), 3)], "by_rank": recs,
+                     "note": "ranks take turns on the one GPU (DAV_TEST_SERIALIZE=1): kernel / local times are those of a rank that owns a GPU; "
+                             "collective times are of the loopback transport and mean nothing"})
 
 
 def test_config3_n200000_restart_forcing_variant():

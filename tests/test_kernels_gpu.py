@@ -182,6 +182,70 @@ def test_block_gram_schmidt_phase(n, m, kt):
         assert np.linalg.norm(full - Q @ (Q.T @ full)) < 1e-10 * np.linalg.norm(full)
 
 
+@pytest.mark.parametrize("gev", [False, True])
+@pytest.mark.parametrize("n,m,kt,nranks", [(500, 16, 16, 1), (1200, 64, 64, 1), (700, 32, 8, 1), (900, 32, 32, 3)])
+def test_last_gram_schmidt_pass_fused_with_the_projection(n, m, kt, nranks, gev):
+    """dav_project_ortho + dav_ortho_apply_all (round 5): the block is swept as the first pass left it, ONE fetch returns
+    [V T']^T (A T'), [V T']^T (B T'), V^T T' and T'^T T'; the second pass then moves T', A T' and B T' together, and the
+    projected blocks of the final T'' follow on the host.  Against the separate route (second pass, sweep of T'', dav_project)
+    and against numpy."""
+    rng = np.random.default_rng(n + m + kt)
+    A = rng.standard_normal((n, n)); A = A + A.T
+    B = rng.standard_normal((n, n)); B = B @ B.T / n + np.eye(n)
+    V = np.linalg.qr(rng.standard_normal((n, m)))[0]
+    T1 = rng.standard_normal((n, kt))
+    T1 -= V @ (V.T @ T1)
+    T1 = np.linalg.qr(T1)[0] + 1e-7 * (rng.standard_normal((n, kt)) + V @ rng.standard_normal((m, kt)))   # what a first pass leaves
+    Hvv = V.T @ A @ V
+    Svv = V.T @ B @ V
+
+    def work(r, e):
+        e.set_dense_host(OP_A, A)
+        if gev:
+            e.set_dense_host(OP_B, B)
+        e.panel_put(PANEL_V, 0, V)
+        e.panel_put(PANEL_V, m, T1)
+        e.expand(0, m)
+        # fused route
+        e.expand(m, kt)
+        Hraw, Sraw, C2, G2 = e.project_ortho(m, kt, gev)
+        assert relerr(C2, V.T @ T1) < 1e-9 and relerr(G2, T1.T @ T1) < 1e-12
+        assert relerr(Hraw, np.hstack([V, T1]).T @ (A @ T1)) < 1e-12
+        Gp = G2 - C2.T @ C2
+        w, U = np.linalg.eigh(Gp)
+        M2 = U / np.sqrt(w)[None, :]
+        e.ortho_apply_all(m, kt, C2, M2)
+        T2 = (T1 - V @ C2) @ M2
+        out = {}
+        for name, raw, pvv, Op, panel in (("H", Hraw, Hvv, A, PANEL_W),) + ((("S", Sraw, Svv, B, PANEL_BV),) if gev else ()):
+            pc = pvv @ C2
+            newv = (raw[:m] - pc) @ M2
+            tt = raw[m:] - C2.T @ raw[:m] - raw[:m].T @ C2 + C2.T @ pc
+            newt = M2.T @ tt @ M2
+            assert relerr(newv, V.T @ Op @ T2) < 1e-11, name
+            assert relerr(newt, T2.T @ Op @ T2) < 1e-11, name
+            assert relerr(e.panel_get(panel, m, kt), Op @ T2) < 1e-11, name       # the image followed the block
+            out[name] = (newv, newt)
+        Tdev = e.panel_get(PANEL_V, m, kt)
+        assert relerr(Tdev, T2) < 1e-12
+        Q = np.hstack([V, Tdev])
+        assert np.abs(Q.T @ Q - np.eye(m + kt)).max() < 1e-12
+        # separate route on the same block: sweep of T'' and dav_project
+        e.expand(m, kt)
+        H = np.zeros((m + kt, m + kt), order="F"); S = np.zeros((m + kt, m + kt), order="F")
+        e.project(m, kt, H, S if gev else None)
+        assert relerr(H[:m, m:], out["H"][0]) < 1e-11 and relerr(H[m:, m:], out["H"][1]) < 1e-11
+        if gev:
+            assert relerr(S[:m, m:], out["S"][0]) < 1e-11 and relerr(S[m:, m:], out["S"][1]) < 1e-11
+        return True
+
+    if nranks == 1:
+        with fd.CEngine(n=n, max_cols=m + kt, gev=gev) as e:
+            assert work(0, e)
+    else:
+        assert all(_run_ranks(nranks, lambda r: fd.CEngine(n=n, max_cols=m + kt, gev=gev, rank=r, nranks=nranks), work))
+
+
 def test_init_basis_expand_project_restart():
     n, L = 500, 4
     A = O.generate_diagonal_dominant(n, 1e-2, seed=6)
