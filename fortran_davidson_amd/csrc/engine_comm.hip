@@ -44,7 +44,9 @@ void watchdog_loop(Watchdog* w) {
       const hipError_t q = hipEventQuery(l.check.ev);
       if (q == hipSuccess) {
         // everything up to `check` is done; what was enqueued behind it is covered by `latest`: watch that one next
-        if (l.latest_valid) { std::swap(l.check, l.latest); l.latest_valid = false; }
+        // (its clock starts NOW, when its predecessor has completed - not when it was enqueued: a long backlog of queued collectives
+        // that do complete must not eat the newest one's allowance; round-4 advisor)
+        if (l.latest_valid) { std::swap(l.check, l.latest); l.latest_valid = false; l.check.t0 = now; }
         else l.check_active = false;
         continue;
       }

@@ -621,13 +621,25 @@ int sym_resident_split(E* e, int which) {
     rc = fail("hipMalloc of the resident tiles of a generated operator failed (" + std::to_string((size_t)(tile_bytes * (double)o.res->ntiles) >> 20) +
               " MiB): set DAV_B_RESIDENT=0");
   }
-  if (rc != 0) {                       // (the passes were agreed on across the ranks: no way back to the one-pass route from here)
+  if (rc != 0) {
+    // the passes were agreed on across the ranks: no way back to the one-pass route from here.  The operator becomes unusable ON
+    // THIS RANK - every later apply fails again, instead of sweeping one pass where the peers sweep two (a caller that catches the
+    // error and goes on would otherwise walk into mismatched collectives; round-4 advisor)
+    const std::string msg = g_err;
     sym_resident_release(o);
-    return rc;
+    o.kind = DAV_KIND_NONE;
+    return fail(msg + " - the operator is now unset on this rank: set it again");
   }
   launch_generate_sym_tiles(e->stream, o.res_a, o.res->row_off_h.data(), nb, e->n, o.seed, o.sparsity, o.use_diag, o.diag_val);
   o.res_tiles = o.res->ntiles;
   o.res_first = first;
+  // the split follows the free memory of the moment (a co-tenant or another box moves it, and with it the order of the sums of the
+  // two parts): said once, so that a run can be repeated with the same split (DAV_B_RESIDENT = that percentage)
+  if (getenv("DAVIDSON_VERBOSE"))
+    std::fprintf(stderr, "davidson engine: rank %d keeps block rows %d.. of the generated operator %c resident (%lld of %lld tiles = %.1f %%; "
+                         "DAV_B_RESIDENT=%d fixes an upper bound)\n", e->rank, first, which == DAV_OP_A ? 'A' : 'B', (long long)o.res_tiles,
+                 (long long)e->sym.ntiles, 100.0 * (double)o.res_tiles / (double)std::max<int64_t>(e->sym.ntiles, 1),
+                 (int)std::ceil(100.0 * (double)o.res_tiles / (double)std::max<int64_t>(e->sym.ntiles, 1)));
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -20,7 +20,7 @@ module davidson_device
   use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_cholesky_inverse, lapack_matmul
   implicit none
   private
-  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, env_storage_symmetric, fits_as_full_rows, engine_set_device_rr, engine_set_inner_precision, &
+  public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, env_storage_symmetric, env_storage, symmetry_probe, fits_as_full_rows, engine_set_device_rr, engine_set_inner_precision, &
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
@@ -82,6 +82,41 @@ contains
     call check_dav(dav_device_memory(eng%h, free_bytes, total_bytes), "dav_device_memory")
     fits = 8.0_dp * real(n, dp) * real(n, dp) * real(nmat, dp) <= 0.9_dp * real(free_bytes, dp)
   end function fits_as_full_rows
+
+  !> DAVIDSON_STORAGE for the dense front end: 1 = "symmetric", 0 = "full", -1 = not set (the front end decides by symmetry_probe)
+  function env_storage() result(mode)
+    integer :: mode, stat, length
+    character(len=16) :: buf
+    mode = -1
+    call get_environment_variable("DAVIDSON_STORAGE", buf, length, stat)
+    if (stat == 0 .and. length >= 3) then
+       if (buf(1:3) == "sym") mode = 1
+       if (buf(1:3) == "ful") mode = 0
+    end if
+  end function env_storage
+
+  !> Is the matrix symmetric where it is looked at?  Exact comparison of up to 12 whole rows with their columns (the first, the
+  !> last, and rows spread over the order by a fixed stride), both triangles of each: O(24 n) loads, independent of what the rest
+  !> of the call costs.  A matrix with a single asymmetric entry outside the sampled rows passes - as it passes the reference,
+  !> which never looks; what the probe guards against is an input that is not meant to be symmetric at all.
+  function symmetry_probe(matrix) result(symmetric)
+    real(dp), dimension(:, :), intent(in) :: matrix
+    logical :: symmetric
+    integer :: n, k, i, j, nsample
+    n = size(matrix, 1)
+    symmetric = size(matrix, 2) == n
+    if (.not. symmetric) return
+    nsample = min(n, 12)
+    do k = 0, nsample - 1
+       i = 1 + int(int(k, c_int64_t) * int(n - 1, c_int64_t) / int(max(nsample - 1, 1), c_int64_t))
+       do j = 1, n
+          if (matrix(i, j) /= matrix(j, i)) then
+             symmetric = .false.
+             return
+          end if
+       end do
+    end do
+  end function symmetry_probe
 
   !> DAVIDSON_STORAGE=symmetric selects symmetric-tiled storage for the dense front end (engines: engine_set_storage)
   function env_storage_symmetric() result(sym)
@@ -414,8 +449,8 @@ contains
     integer(c_int64_t), allocatable :: idx(:)
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
     logical, allocatable :: has_converged(:)
-    logical :: host_ops, done, lazy_x
-    real(dp) :: t0, t1, phase_s(8)
+    logical :: host_ops, done, lazy_x, have_all_pairs
+    real(dp) :: t0, t1, phase_s(8), tol_unwanted, adaptive_c
 
     phase_s = 0.0_dp
     host_ops = present(fun_a)
@@ -444,6 +479,8 @@ contains
     sm = 0.0_dp
     has_converged = .false.
     refresh_every = restart_refresh_interval()
+    tol_unwanted = gjd_tol_unwanted()          ! environment knobs of the GJD inner solves: read once, here
+    adaptive_c = gjd_adaptive_factor()
     nrestart = 0
     drr = .false.
     if (present(device_rr)) drr = device_rr .and. cap <= 128
@@ -495,8 +532,12 @@ contains
        ! (order 64: 150-200 us on the host) although a converged iteration only needs the `lowest` wanted pairs.
        ! When the previous residues say convergence is near, solve for those pairs first (MRRR on a subset) and
        ! test them; only if the test fails is the full problem solved.  Same Ritz pairs, same iteration count.
+       have_all_pairs = .false.
        if (.not. drr .and. pol == POLICY_ALL .and. expand_now .and. i > 1 .and. m >= 48 .and. 2 * lowest <= m) then
           if (maxval(errors) < sqrt(tolerance)) then
+             ! (lapack_rayleigh_ritz solves for ALL pairs when the wanted ones are more than an eighth of the order: theta and y are
+             ! then complete, and the full problem below is not solved a second time - round-4 advisor)
+             have_all_pairs = 8 * lowest > m
              if (gev) then
                 call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, lowest, sm(1:m, 1:m))
              else
@@ -524,7 +565,7 @@ contains
        end if
        nvec = min(m, initial_dimension)
        if (pol == POLICY_ALL .and. expand_now) nvec = m
-       if (.not. drr) then
+       if (.not. drr .and. .not. have_all_pairs) then
           if (gev) then
              call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, nvec, sm(1:m, 1:m))
           else
@@ -597,9 +638,9 @@ contains
                 ! reference's exact solves); the other m - lowest corrections only enrich the basis
                 if (allocated(tols)) deallocate(tols)
                 allocate(tols(kt))
-                tols = gjd_tol_unwanted()
+                tols = tol_unwanted
                 do j = 1, min(lowest, kt)
-                   tols(j) = gjd_tol_wanted(errors(j), tolerance)
+                   tols(j) = gjd_tol_wanted(errors(j), tolerance, adaptive_c)
                 end do
                 call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), theta, 300_c_int, 1.0e-10_dp, &
                      tols, inner), "dav_gjd_correction")
@@ -628,7 +669,7 @@ contains
                 if (allocated(tols)) deallocate(tols)
                 allocate(tols(kt))
                 do j = 1, kt
-                   tols(j) = gjd_tol_wanted(errors(sel(j) + 1), tolerance)
+                   tols(j) = gjd_tol_wanted(errors(sel(j) + 1), tolerance, adaptive_c)
                 end do
                 call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), theta_sel, 300_c_int, &
                      1.0e-10_dp, tols, inner), "dav_gjd_correction")
@@ -729,13 +770,14 @@ contains
     !>   V^T A T'' = (Hv - H C) M,   T''^T A T'' = M^T (Ht - C^T Hv - Hv^T C + C^T H C) M   (A symmetric, as everywhere).
     !> A pass that does not leave the block clean (rank-deficient corrections: rare) falls back to the separate passes, a second
     !> sweep of the block and dav_project.
-    subroutine project_with_last_pass(pass)
-      integer, intent(in) :: pass
+    subroutine project_with_last_pass(first_pass)
+      integer, intent(in) :: first_pass
+      integer, parameter :: max_pass = 8
       real(dp), allocatable, target :: hraw(:, :), sraw(:, :)
       real(dp), allocatable :: c2(:, :), g2(:, :), mm(:, :)
       logical, allocatable :: null_cols(:)
       real(dp) :: wmin, wmax
-      integer :: nnull, p
+      integer :: nnull, p, pass
       p = m + kt
       allocate(hraw(p, kt), c2(max(m, 1), kt), g2(kt, kt), mm(kt, kt), null_cols(kt))
       if (gev) then
@@ -746,21 +788,41 @@ contains
          call check_dav(dav_project_ortho(h, int(m, c_int), int(kt, c_int), hraw, int(p, c_int64_t), c_null_ptr, &
               0_c_int64_t, c2, int(max(m, 1), c_int64_t), g2, int(kt, c_int64_t)), "dav_project_ortho")
       end if
-      call ortho_pass_transform(pass, m, kt, c2, g2, mm, wmin, wmax, null_cols, nnull)
-      if (nnull == 0) then
-         call check_dav(dav_ortho_apply_all(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), mm, &
-              int(kt, c_int64_t)), "dav_ortho_apply_all")
-         if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) then
-            call project_transformed(hm, hraw, c2, mm, m, kt)
-            if (gev) call project_transformed(sm, sraw, c2, mm, m, kt)
+      pass = first_pass
+      do
+         call ortho_pass_transform(pass, m, kt, c2, g2, mm, wmin, wmax, null_cols, nnull)
+         if (nnull > 0) then
+            ! numerically null columns (rank-deficient corrections: rare): they are replaced by fresh directions, which have no
+            ! images yet - separate passes, a second sweep of the block and dav_project
+            call block_orthonormalise(h, n, m, kt, first_pass=pass)
+            call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+            if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
+            call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
             return
          end if
+         call check_dav(dav_ortho_apply_all(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), mm, &
+              int(kt, c_int64_t)), "dav_ortho_apply_all")
+         call transform_projected(hm, hraw, c2, mm, m, kt)
+         if (gev) call transform_projected(sm, sraw, c2, mm, m, kt)
+         if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) exit          ! orthonormal to rounding
+         if (pass >= max_pass) then
+            print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
+            exit
+         end if
+         ! one more pass (a block whose second pass still found it ill-conditioned): its Gram blocks; the images and the projected
+         ! blocks keep following the block - no second sweep
+         pass = pass + 1
+         call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), g2, &
+              int(kt, c_int64_t)), "dav_ortho_gram")
+      end do
+      hm(1:m, m + 1:p) = hraw(1:m, :)
+      hm(m + 1:p, 1:m) = transpose(hraw(1:m, :))
+      hm(m + 1:p, m + 1:p) = hraw(m + 1:p, :)
+      if (gev) then
+         sm(1:m, m + 1:p) = sraw(1:m, :)
+         sm(m + 1:p, 1:m) = transpose(sraw(1:m, :))
+         sm(m + 1:p, m + 1:p) = sraw(m + 1:p, :)
       end if
-      call block_orthonormalise(h, n, m, kt, first_pass=pass + merge(1, 0, nnull == 0))
-      call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
-      if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
-      call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
-
     end subroutine project_with_last_pass
 
     !> X(:, 1:lowest) = V(:, 1:m) * Y(:, 1:lowest) for the Ritz pairs of this iteration (see lazy_x above)
@@ -804,10 +866,20 @@ contains
   !> err to ~err**2; an inexact one with relative tolerance tau to ~max(err**2, tau*err).  tau = c * tolerance / err
   !> therefore leaves c * tolerance on top of what the exact solve reaches: where the reference converges (err**2 below
   !> the tolerance) so does this, where it does not, the next residual is the reference's to within c * tolerance.
-  !> c = 0.01 (DAV_GJD_ADAPTIVE; 0 = the fixed 1e-10 of round 3), tau clipped to [1e-10, 1e-2].
-  function gjd_tol_wanted(err, tolerance) result(t)
-    real(dp), intent(in) :: err, tolerance
-    real(dp) :: t, c
+  !> c = 0.01 (gjd_adaptive_factor), tau clipped to [1e-10, 1e-2].
+  function gjd_tol_wanted(err, tolerance, c) result(t)
+    real(dp), intent(in) :: err, tolerance, c
+    real(dp) :: t
+    t = 1.0e-10_dp
+    if (c > 0.0_dp .and. err > 0.0_dp) t = min(1.0e-2_dp, max(1.0e-10_dp, c * tolerance / err))
+    ! (A forcing term on top - no more accurate than c2 * err, because an exact solve "only" leaves ~err**2 - was measured and
+    ! dropped: these matrices converge faster than that estimate, and with c2 = 1e-3 already 11 of 144 problems need an outer
+    ! iteration more than the reference; profiles/experiments/r04_gjd_policy_sweep3.log.)
+  end function gjd_tol_wanted
+
+  !> c of gjd_tol_wanted: 0.01; DAV_GJD_ADAPTIVE overrides (0 = the fixed 1e-10 of round 3).  Read once per solve, before the loop.
+  function gjd_adaptive_factor() result(c)
+    real(dp) :: c
     integer :: stat, length
     character(len=32) :: buf
     c = 0.01_dp
@@ -816,12 +888,7 @@ contains
        read (buf(1:length), *, iostat=stat) c
        if (stat /= 0) c = 0.01_dp
     end if
-    t = 1.0e-10_dp
-    if (c > 0.0_dp .and. err > 0.0_dp) t = min(1.0e-2_dp, max(1.0e-10_dp, c * tolerance / err))
-    ! (A forcing term on top - no more accurate than c2 * err, because an exact solve "only" leaves ~err**2 - was measured and
-    ! dropped: these matrices converge faster than that estimate, and with c2 = 1e-3 already 11 of 144 problems need an outer
-    ! iteration more than the reference; profiles/experiments/r04_gjd_policy_sweep3.log.)
-  end function gjd_tol_wanted
+  end function gjd_adaptive_factor
 
   function tick() result(t)
     real(dp) :: t
@@ -951,23 +1018,23 @@ contains
     end if
   end subroutine block_orthonormalise
 
-  !> Projected blocks of T'' = (T' - V C) M from those of T' (raw = [V T']^T (Op T'), (m + kt) x kt) and the projected matrix pm
-  !> of the basis so far: see project_with_last_pass.
-  subroutine project_transformed(pm, raw, c2, mm, m, kt)
-    real(dp), intent(inout) :: pm(:, :)
-    real(dp), intent(in) :: raw(:, :), c2(:, :), mm(:, :)
+  !> raw = [V T']^T (Op T') ((m + kt) x kt) -> the same blocks for T'' = (T' - V C) M, whose image Op T'' = (Op T' - (Op V) C) M
+  !> follows it: rows 1:m  V^T Op T'' = (raw_V - P C) M,  rows m+1:  T''^T Op T'' = M^T (raw_T - C^T raw_V - raw_V^T C + C^T P C) M,
+  !> with P = pm(1:m, 1:m) the projected matrix of the basis so far (Op symmetric, as everywhere).
+  subroutine transform_projected(pm, raw, c2, mm, m, kt)
+    real(dp), intent(in) :: pm(:, :), c2(:, :), mm(:, :)
+    real(dp), intent(inout) :: raw(:, :)
     integer, intent(in) :: m, kt
     real(dp), allocatable :: pc(:, :), newv(:, :), tt(:, :)
     integer :: p
     p = m + kt
-    pc = lapack_matmul("N", "N", pm(1:m, 1:m), c2(1:m, 1:kt))                            ! H C
+    pc = lapack_matmul("N", "N", pm(1:m, 1:m), c2(1:m, 1:kt))
     newv = lapack_matmul("N", "N", raw(1:m, 1:kt) - pc, mm(1:kt, 1:kt))
     tt = raw(m + 1:p, 1:kt) - lapack_matmul("T", "N", c2(1:m, 1:kt), raw(1:m, 1:kt)) &
          - lapack_matmul("T", "N", raw(1:m, 1:kt), c2(1:m, 1:kt)) + lapack_matmul("T", "N", c2(1:m, 1:kt), pc)
-    pm(1:m, m + 1:p) = newv
-    pm(m + 1:p, 1:m) = transpose(newv)
-    pm(m + 1:p, m + 1:p) = lapack_matmul("T", "N", mm(1:kt, 1:kt), lapack_matmul("N", "N", tt, mm(1:kt, 1:kt)))
-  end subroutine project_transformed
+    raw(1:m, 1:kt) = newv
+    raw(m + 1:p, 1:kt) = lapack_matmul("T", "N", mm(1:kt, 1:kt), lapack_matmul("N", "N", tt, mm(1:kt, 1:kt)))
+  end subroutine transform_projected
 
   !> The transform of ONE block Gram-Schmidt pass from its Gram blocks C = V^T T (m x kt) and G = T^T T (kt x kt):
   !> T <- (T - V C) M.  wmin / wmax: conditioning of the scaled Gram block G' = D (G - C^T C) D the pass started from (a pass
@@ -1170,24 +1237,59 @@ contains
 
     type(davidson_engine) :: eng
     integer :: max_dim
+    logical :: symmetric
+    real(dp) :: t(5)
 
     max_dim = 10 * lowest
     if (present(max_dim_sub)) max_dim = max_dim_sub
+    t(1) = wall()
     call engine_create(eng, size(matrix, 1), lowest, max_dim, present(second_matrix), env_device())
-    ! DAVIDSON_STORAGE=symmetric: upload and keep only the lower block triangle of the (symmetric, as the reference
-    ! assumes) input - half the PCIe bytes, half the HBM; default: the full matrix, as the reference's DGEMM reads it
-    if (env_storage_symmetric()) then
-       call engine_set_storage(eng, "symmetric")
-    else if (.not. fits_as_full_rows(eng, size(matrix, 1), merge(2, 1, present(second_matrix)))) then
-       ! the full matrices do not fit the device next to the panels, their lower block triangles may: symmetric tiles instead of
-       ! an out-of-memory stop (same results - the reference assumes a symmetric matrix; one GPU holds N = 190000 that way)
-       call engine_set_storage(eng, "symmetric")
-    end if
+    ! Storage of the uploaded operators.  The reference ASSUMES a symmetric matrix (it never checks; its DPR / GJD and DSYEV steps
+    ! are only meaningful for one), so only the lower block triangle needs to cross PCIe and stay in HBM: half the upload - which
+    ! is what a drop-in call spends its time on (N=20000: 60 of 62 ms) - and half the bytes per sweep.  Default (round 5): symmetric
+    ! tiles when a cheap exact probe of the host matrices finds them symmetric (symmetry_probe: whole sampled rows against their
+    ! columns); a matrix that fails the probe is uploaded in full and swept as the reference's DGEMM would read it.
+    ! DAVIDSON_STORAGE=full | symmetric overrides; full rows that do not fit the device fall back to symmetric tiles as before.
+    select case (env_storage())
+    case (1)
+       symmetric = .true.
+    case (0)
+       symmetric = .not. fits_as_full_rows(eng, size(matrix, 1), merge(2, 1, present(second_matrix)))
+    case default
+       symmetric = symmetry_probe(matrix)
+       if (symmetric .and. present(second_matrix)) symmetric = symmetry_probe(second_matrix)
+       if (.not. symmetric) symmetric = .not. fits_as_full_rows(eng, size(matrix, 1), merge(2, 1, present(second_matrix)))
+    end select
+    if (symmetric) call engine_set_storage(eng, "symmetric")
+    t(2) = wall()
     call engine_set_dense(eng, 1, matrix)
     if (present(second_matrix)) call engine_set_dense(eng, 2, second_matrix)
+    t(3) = wall()
     call generalized_eigensolver_device(eng, eigenvalues, eigenvectors, lowest, method, max_iterations, &
          tolerance, iters, max_dim)
+    t(4) = wall()
     call engine_destroy(eng)
+    t(5) = wall()
+    if (dense_verbose()) print "(a, i0, a, l1, a, 4f9.3)", "davidson dense call: n=", size(matrix, 1), " symmetric tiles=", symmetric, &
+         " ms[create+probe upload solve+download destroy]=", (t(2:5) - t(1:4)) * 1.0e3_dp
+
+  contains
+
+    function wall() result(s)
+      real(dp) :: s
+      integer(c_int64_t) :: cnt, rate
+      call system_clock(cnt, rate)
+      s = real(cnt, dp) / real(rate, dp)
+    end function wall
+
+    function dense_verbose() result(on)
+      logical :: on
+      integer :: stat, length
+      character(len=8) :: buf
+      call get_environment_variable("DAVIDSON_VERBOSE", buf, length, stat)
+      on = (stat == 0 .and. length > 0)
+    end function dense_verbose
+
   end subroutine generalized_eigensolver_dense
 
 end module davidson_dense

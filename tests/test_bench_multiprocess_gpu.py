@@ -42,14 +42,17 @@ def test_bench_multi_rank_flow_matches_single_rank(nproc, storage):
     # row slabs / the lower block triangle dealt out over the ranks: all-gather + reduce-scatter per sweep);
     # the configs[1] / configs[3] / configs[4] legs at small orders
     extra = ["--steps", "2", "--warmup", "1", "--order", "6000", "--storage", storage, "--small-n", "3000", "--gjd-n", "2000",
-             "--free-n", "4000", "--no-cpu-baseline", "--no-dropin"]
+             "--free-n", "4000", "--harness-n", "0", "--no-cpu-baseline", "--no-dropin"]
     one = run_bench(1, extra)
     many = run_bench(nproc, extra)
     assert many["n_gpus"] == nproc and many["steps"] == 2 and many["scaling"] == "strong"
     assert many["config"]["iters_per_solve"] == one["config"]["iters_per_solve"]
     assert np.abs(np.array(many["eigenvalues"]) - np.array(one["eigenvalues"])).max() < 1e-10
-    assert many["roofline"]["achieved"] > 0 and many["roofline_hbm"]["achieved"] > 0
-    assert many["roofline_hbm"]["ms_end_to_end"] >= many["roofline_hbm"]["ms_kernel_only"] > 0
+    assert many["roofline"]["achieved"] > 0 and many["roofline"]["hbm_GBps_end_to_end"] > 0
+    assert many["roofline"]["hbm_ms_end_to_end"] >= many["roofline"]["hbm_ms_kernel_only"] > 0
+    c = many["comm"]
+    assert c["sweep_kernel_ms_min_over_ranks"] <= c["sweep_kernel_ms_max_over_ranks"] and c["apply_local_ms_max_over_ranks"] > 0
+    assert c["collectives_per_solve"] > 0 and c["model_ms_per_solve"]["symmetric_all_links_ms"] <= c["model_ms_per_solve"]["symmetric_ms"]
     assert many["small"]["phase_ms_per_solve"]["comm_ms"] > 0
     assert many["cpu_baseline"] is None
     for key in ("small", "configs3_gjd", "configs4_free"):
@@ -64,13 +67,21 @@ def test_bench_multi_rank_flow_matches_single_rank(nproc, storage):
 def test_bench_single_gpu_default_shape_of_the_line():
     """The one-GPU flow with symmetric tiles at a reduced order: every object the contract names is there."""
     line = run_bench(1, ["--steps", "2", "--warmup", "1", "--order", "8000", "--small-n", "3000", "--gjd-n", "3000",
-                         "--free-n", "6000", "--no-cpu-baseline"])
+                         "--free-n", "6000", "--harness-n", "6000", "--harness-n2", "9000", "--no-cpu-baseline"])
     assert line["config"]["storage"] == "symmetric" and line["config"]["N"] == 8000
-    for key in ("roofline", "roofline_hbm", "apply", "configs3_gjd", "configs4_free", "small", "dropin", "opt_in_policy"):
+    assert len(line["config"]["workload"]) < 120 and "sparsity" in line["config"]["workload"] and "storage=symmetric" in line["config"]["workload"]
+    for key in ("roofline", "apply", "configs3_gjd", "configs4_free", "benchmark_free", "small", "dropin", "opt_in_policy", "scaling_model"):
         assert key in line and "error" not in line[key], (key, line.get(key))
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["launches"] > 0
-    assert 0 < line["roofline_hbm"]["frac"] <= line["roofline_hbm"]["frac_kernel_only"] < 1
+    # what the driver's record keeps: the first twenty keys carry both fractions and what they are made of
+    head = list(r)[:20]
+    assert all(k in head for k in ("frac", "traffic", "hbm_N", "hbm_k", "hbm_frac", "hbm_traffic", "non_kernel_ms_per_solve", "hbm_algorithmic_bytes"))
+    assert all(len(v) < 120 for v in r.values() if isinstance(v, str))
+    bf = line["benchmark_free"]
+    assert bf["reference_configuration"]["iters_per_solve"] >= 2 and abs(bf["reference_configuration"]["eigenvalues"][0] - 1.0000992) < 1e-6
+    assert 0 < bf["roofline"]["frac"] < 1.2 and bf["large"]["iters"] > 0 and bf["sweep_at_configs4_order"]["ms"] > 0
+    assert line["scaling_model"]["P8"]["symmetric_all_links_ms"] <= line["scaling_model"]["P8"]["symmetric_ms"]
     # the north-star figure inside `roofline` (what the driver's record keeps), against 8 TB/s and against the rates measured in this run
     assert r["hbm_k"] == 8 and 0 < r["hbm_frac"] <= r["hbm_frac_kernel_only"] < 1
     assert r["hbm_measured_read_GBps"] > 1000 and r["hbm_frac_of_measured_read"] > r["hbm_frac"]

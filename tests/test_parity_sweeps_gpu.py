@@ -1,0 +1,85 @@
+"""Fixed-seed slices of the randomised parity sweeps (tests/dpr_parity_sweep.py against the oracle, tests/reference_binary_sweep.py
+against the REFERENCE ITSELF compiled under oracle/_ref), inside `pytest -m gpu`: the long sweeps stay tools whose logs live under
+profiles/experiments/, these slices put the same comparisons where the driver's GPU test run sees them.  Also: the golden cases
+once against the PRODUCT library (every other GPU test loads the test build, tests/conftest.py)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_tool(script, *args, timeout=1500):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), *map(str, args)], capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    return res.stdout
+
+
+def test_dpr_solves_against_the_oracle_on_a_fixed_seed_slice():
+    """24 random DPR problems (orders 120-3000, lowest 1-16, couplings 1e-4 - 5e-2, restart widths, standard / generalized, both
+    storages, tolerances 1e-6 / 1e-8 / 1e-10): iteration counts EQUAL to the oracle's statement of the reference's loop, eigenvalues
+    to 1e-8, residuals below the tolerance."""
+    out = run_tool("dpr_parity_sweep.py", 24, 11)
+    assert re.search(r"mismatches: 0\b", out), out[-3000:]
+    assert len([ln for ln in out.splitlines() if "oracle iters" in ln]) >= 15
+
+
+def test_fresh_problems_against_the_compiled_reference_on_a_fixed_seed_slice():
+    """12 dense + 3 matrix-free random problems solved by the reference binary (oracle/_ref: flang + MKL build of /root/reference) in a
+    child process and by the engine.  DPR and matrix-free: equal iteration counts; GJD: never MORE outer iterations than the
+    reference's exact DSYSV solves (the engine's inner solves are inexact by default); eigenvalues to 1e-8,
+    residuals below the tolerance."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_davidson.so")):
+        pytest.skip("oracle/_ref not built")
+    out = run_tool("reference_binary_sweep.py", 12, 5)
+    rows = [ln for ln in out.splitlines() if "reference iters" in ln]
+    assert len(rows) == 15, out[-3000:]
+    for ln in rows:
+        m = re.search(r"reference iters\s+(\d+), engine\s+(\d+), \|dlam\| ([0-9.e+-]+), residual ([0-9.e+-]+)", ln)
+        ref_it, eng_it, dlam, res = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+        assert dlam < 1e-8 and (res < 1e-8 or ref_it > 60), ln
+        if ln.startswith("GJD"):
+            assert eng_it <= ref_it, ln
+        else:
+            assert eng_it == ref_it, ln
+
+
+def test_golden_cases_against_the_product_library():
+    """The product build lib/libdavidson_hip.so (no test transports) on a subset of the golden cases - DPR and GJD, standard and
+    generalized, a restart case - in a child process that does not see DAVIDSON_HIP_LIB: eigenvalues, residuals, the reference's
+    iteration counts, and the mapped library is the product's."""
+    code = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import fortran_davidson_amd as fd
+from conftest import case_matrices, GOLDEN
+manifest = json.load(open(os.path.join(GOLDEN, "reference_cases.json")))
+arrays = dict(np.load(os.path.join(GOLDEN, "reference_cases.npz")))
+ran = 0
+for name, case in sorted(manifest["dense"].items()):
+    if case["n"] > 1000:
+        continue
+    A, B = case_matrices(case, arrays)
+    lam, vec, it = fd.generalized_eigensolver(A, case["lowest"], case["method"], case["max_it"], case["tol"], case["max_dim"], B)
+    BX = vec if B is None else B @ vec
+    assert np.abs(lam - arrays[name + "__evals"]).max() < 1e-8, name
+    assert (np.linalg.norm(A @ vec - BX * lam[None, :], axis=0) < case["tol"]).all(), name
+    assert it == case["iters"], (name, it, case["iters"])
+    ran += 1
+maps = open("/proc/self/maps").read()
+assert "/lib/libdavidson_hip.so" in maps and "/lib/test/libdavidson_hip.so" not in maps
+print("PRODUCT_OK", ran)
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("DAVIDSON_HIP_LIB",)}
+    env["LD_LIBRARY_PATH"] = ":".join(p for p in env.get("LD_LIBRARY_PATH", "").split(":") if p and not p.endswith(os.path.join("lib", "test")))
+    env["PYTHONPATH"] = ROOT
+    env["DAVIDSON_TEST_NO_TEST_LIB"] = "1"
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0 and "PRODUCT_OK" in res.stdout, (res.stdout + res.stderr)[-3000:]
+    assert int(res.stdout.split("PRODUCT_OK")[1].split()[0]) >= 8
