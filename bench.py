@@ -609,14 +609,25 @@ def main():
         roofline.update({"comm_" + k_: v_ for k_, v_ in extras["comm"].items() if isinstance(v_, (int, float, bool, str)) and k_ != "note"})
         roofline.update({"comm_model_" + k_: v_ for k_, v_ in extras["comm"]["model_ms_per_solve"].items() if isinstance(v_, (int, float))})
     if not args.headline_only:
-        # opt-in correction policy (not the reference's, so never part of `value`)
-        eng.set_correction_policy("unconverged")
-        eng.solve("DPR", 1000, args.tol, want_vectors=False)
-        dt_pol, it_pol, lam_pol = timed_solves(eng, "DPR", 2, args.tol)
+        # opt-in correction policies (not the reference's, so never part of `value`): the same problem, same engine
+        extras["opt_in_policy"] = {"reference_policy_all": {"ms_per_solve": round(elapsed / args.steps * 1e3, 3), "iters_per_solve": total_iters // args.steps}}
+        for pol_ in ("unconverged", "locking"):
+            try:
+                eng.set_correction_policy(pol_)
+                eng.solve("DPR", 1000, args.tol, want_vectors=False)
+                eng.c.synchronize(); eng.c.reset_stats()
+                dt_pol, it_pol, lam_pol = timed_solves(eng, "DPR", 2, args.tol)
+                sp_ = eng.c.stats()
+                extras["opt_in_policy"][pol_] = {"ms_per_solve": round(dt_pol / 2 * 1e3, 3), "iters_per_solve": it_pol // 2,
+                                                 "columns_swept_per_solve": int(sp_.apply_cols) // 2,
+                                                 "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_pol - lam).max())}
+            except Exception as exc:       # noqa: BLE001
+                extras["opt_in_policy"][pol_] = {"error": repr(exc)[:200]}
         eng.set_correction_policy("all")
-        extras["opt_in_policy"] = {"policy": "unconverged (engine_set_correction_policy / DAVIDSON_CORRECTION_POLICY)",
-                                   "ms_per_solve": round(dt_pol / 2 * 1e3, 3), "iters_per_solve": it_pol // 2,
-                                   "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_pol - lam).max())}
+        extras["opt_in_policy"]["note"] = ("engine_set_correction_policy / DAVIDSON_CORRECTION_POLICY: unconverged = corrections only for wanted pairs above the "
+                                           "tolerance; locking = converged wanted pairs leave the active basis, which stays orthogonal to them (standard problems)")
+        extras["opt_in_policy"]["max_abs_eigenvalue_diff_vs_reference_policy"] = max(
+            (v.get("max_abs_eigenvalue_diff_vs_reference_policy", 0.0) for v in extras["opt_in_policy"].values() if isinstance(v, dict)), default=0.0)
     eng.close()
 
     # Order of the legs: the small (launch-bound) problems right behind the timed workload, the other 100+ GB problems after
@@ -647,16 +658,6 @@ def main():
                 small["phase_ms_per_solve"] = {"apply_ms": round(sp.apply_ms / 5, 4), "gram_ms": round(sp.gram_ms / 5, 4),
                                                "panel_ms": round(sp.panel_ms / 5, 4), "comm_ms": round(sp.comm_ms / 5, 4)}
                 s.c.set_timing(1)
-                # opt-in device-side Rayleigh-Ritz: same solve, eigenpairs of the projected problem kept in HBM
-                s.set_device_rr(True)
-                for _ in range(5):
-                    s.solve("DPR", 1000, args.tol, want_vectors=False)
-                dt_r, it_r, lam_r = timed_solves(s, "DPR", 50, args.tol)
-                s.set_device_rr(False)
-                small["device_rr"] = {"ms_per_solve": round(dt_r / 50 * 1e3, 4), "iterations_per_s": round(it_r / dt_r, 2),
-                                      "iters_per_solve": it_r // 50,
-                                      "max_abs_eigenvalue_diff_vs_host_rr": float(np.abs(lam_r - lam_s).max()),
-                                      "note": "one-workgroup Jacobi eigensolver on the device instead of host DSYEV/DSYEVD; not the default"}
                 small["apply"] = apply_rooflines(s, (8, 16, 32, 64), 20)
                 s.close()
                 # the same problem with only the lower block triangle resident (engine_set_storage(eng, "symmetric")): half the bytes per sweep
@@ -706,7 +707,16 @@ def main():
         gn = n if args.gjd_n < 0 else args.gjd_n
         if gn > 0:
             try:
-                g = make_engine(gn, 8, 80, storage, gev=True)
+                # (the resident part of B follows the free memory of the moment unless bounded: 80 % of its tiles - what fits next to
+                # A's 160.5 GB at N=200000 - makes the split, and with it the order of the sums, the same on every box)
+                mine = "DAV_B_RESIDENT" not in os.environ
+                if mine:
+                    os.environ["DAV_B_RESIDENT"] = "80"
+                try:
+                    g = make_engine(gn, 8, 80, storage, gev=True)          # the knobs are read at dav_create
+                finally:
+                    if mine:
+                        del os.environ["DAV_B_RESIDENT"]
                 g.generate_diagonal_dominant(1, args.sparsity, seed=1)
                 g.set_hashed_operator(2, args.sparsity, 1.0, seed=2)
                 g.solve("GJD", 1000, args.tol, want_vectors=False)        # warm-up (lazy workspace)
@@ -732,25 +742,25 @@ def main():
                             "remainder is host latency of the inner MINRES (dot-product round trips, small uploads)"}
                 # rooflines of the two sweeps (per 16-column group; B is generated once per group): A against HBM, B against the
                 # integer-VALU bound of its generator (same model as configs4_free)
-                groups = max(int(sg.apply_cols) // 16, 1)
-                ms_b_group = max(dev_other - 0.0, 0.0) / groups
-                evals_b = 0.5 * float(gn) * float(gn)
                 peak_evals = 1024 * 2.4e9 * 64 / GEN_CYCLES_PER_WAVE_EVALUATION
                 extras["configs3_gjd"]["roofline"] = {
                     "A_sweeps": {"bound": "hbm (16 columns) / mfma (32, 64)", "ms_per_sweep_end_to_end": round(sg.apply_ms / max(sg.applies, 1), 3),
                                  "GBps_end_to_end": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9, 1) if sg.apply_ms > 0 else None,
                                  "frac_of_8TBps": round(sg.apply_bytes / (sg.apply_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sg.apply_ms > 0 else None,
                                  "TFLOPs_kernel_only": round(sg.apply_flops / (sg.apply_kernel_ms * 1e-3) / 1e12, 2) if sg.apply_kernel_ms > 0 else None},
-                    "B_sweeps": {"bound": "resident block rows: hbm / mfma like A; generated block rows: valu-int + mfma on one issue port", "resident_fraction_of_tiles": round(b_resident, 4),
-                                 "sixteen_column_groups": groups, "ms_per_group_upper_bound": round(ms_b_group, 2),
-                                 "ms_per_group_model": round(b_resident * sg.apply_ms / max(groups, 1) + (1.0 - b_resident) * 36.0, 2),
-                                 "hash_evaluations_per_s_lower_bound": round(evals_b / (ms_b_group * 1e-3), 0) if ms_b_group > 0 else None,
-                                 "peak": round(peak_evals, 0),
-                                 "frac_lower_bound": round(evals_b / (ms_b_group * 1e-3) / peak_evals, 4) if ms_b_group > 0 else None,
-                                 "note": "upper bound on the time: all other device phases of the solve (Gram, panel products) are counted into it; the hash-evaluation "
-                                         "figures price the whole group as if generated (peak = the generator's issue bound), so a resident fraction lifts "
-                                         "frac_lower_bound above what generation alone could reach; ms_per_group_model = resident fraction x the measured A rate per "
-                                         "16 columns + generated fraction x 36 ms (the fully generated sweep of round 3)"},
+                    "B_sweeps": {
+                        "resident_fraction_of_tiles": round(b_resident, 4),
+                        # the sweep kernels of B by what they read (HIP events around every launch, timing level 2)
+                        "stored_tiles": {"bound": "hbm (8 / 16 columns) / mfma (32 / 64)", "launches": int(sg.b_stored_launches), "ms": round(sg.b_stored_kernel_ms, 2),
+                                         "GBps": round(sg.b_stored_bytes / (sg.b_stored_kernel_ms * 1e-3) / 1e9, 1) if sg.b_stored_kernel_ms > 0 else None,
+                                         "frac_of_8TBps": round(sg.b_stored_bytes / (sg.b_stored_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sg.b_stored_kernel_ms > 0 else None,
+                                         "TFLOPs": round(sg.b_stored_flops / (sg.b_stored_kernel_ms * 1e-3) / 1e12, 2) if sg.b_stored_kernel_ms > 0 else None},
+                        "generated_block_rows": {"bound": "valu-int + mfma on one issue port", "launches": int(sg.b_generated_launches), "ms": round(sg.b_generated_kernel_ms, 2),
+                                                 "evaluations_per_s": round(sg.b_generated_entries / (sg.b_generated_kernel_ms * 1e-3), 0) if sg.b_generated_kernel_ms > 0 else None,
+                                                 "peak_16_columns": round(peak_evals, 0),
+                                                 "frac_of_16_column_issue_bound": round(sg.b_generated_entries / (sg.b_generated_kernel_ms * 1e-3) / peak_evals, 4) if sg.b_generated_kernel_ms > 0 else None},
+                        "note": "per-kernel: stored_tiles = launches of the stored-tile kernels on B's resident block rows (bytes = 8 x stored entries + 16 N k), "
+                                "generated_block_rows = launches that evaluate the hash (entries once per 16 columns; once per 32 in the wide kernel's generating variant)"},
                     "device_floor_seconds": round((sg.apply_ms + dev_other) * 1e-3, 3),
                     "note": "fp64 MFMA and the generator's integer VALU work share the SIMD's issue port (DESIGN section 0, item 3): a fused A + B pass "
                             "could hide generation only under the HBM stalls of the 16-column A sweeps"}
@@ -888,13 +898,14 @@ def main():
                     res = subprocess.run([exe, str(cn), "8", str(asym)], capture_output=True, text=True, timeout=900, env=env)
                     out = {}
                     for ln in res.stdout.splitlines():
-                        if ln.startswith("DROPIN_TIMING"):
+                        if "DROPIN_TIMING" in ln:
+                            ln = ln[ln.index("DROPIN_TIMING"):]
                             f = ln.split()
                             secs = [float(x) for x in f[f.index("seconds=") + 1:f.index("seconds=") + 4]]
                             evs = [float(x) for x in f[f.index("eigenvalues=") + 1:f.index("eigenvalues=") + 4]]
                             out = {"first_call_seconds": round(secs[0], 4), "seconds": round(min(secs[1:]), 4), "iters": int(f[3].split("=")[1]),
                                    "iterations_per_s": round(int(f[3].split("=")[1]) / min(secs[1:]), 2), "eigenvalues": evs}
-                        if ln.startswith("davidson dense call:"):
+                        if "davidson dense call:" in ln:
                             out["symmetric_tiles"] = "symmetric tiles=T" in ln
                             out["phases_ms_create_upload_solve_destroy"] = [float(x) for x in ln.split("]=")[1].split()]
                     if not out:

@@ -36,6 +36,10 @@ int collect_events(E* e) {
       e->st.gram_ms += ms;
     } else if (e->ev_kind[i] == 2) {
       e->st.panel_ms += ms;
+    } else if (e->ev_kind[i] == 8) {           // sweep kernel of the second operator over stored tiles; ev_bytes = its bytes
+      e->st.b_stored_kernel_ms += ms; e->st.b_stored_bytes += e->ev_bytes[i]; e->st.b_stored_flops += e->ev_flops[i]; e->st.b_stored_launches += 1;
+    } else if (e->ev_kind[i] == 9) {           // ... over generated block rows; ev_bytes = entries evaluated
+      e->st.b_generated_kernel_ms += ms; e->st.b_generated_entries += e->ev_bytes[i]; e->st.b_generated_flops += e->ev_flops[i]; e->st.b_generated_launches += 1;
     } else {
       e->st.comm_ms += ms;
       if (e->ev_inside[i]) e->st.apply_comm_ms += ms;
@@ -59,7 +63,8 @@ int timed_begin_on(E* e, int kind, double bytes, int* slot, hipStream_t stream) 
   if (e->ev_open == 0 && e->ev_used > N_EVPAIRS - 12) CHK(collect_events(e));   // room for the inner pairs of one apply (<= 8 chunks + collectives)
   if (e->ev_used == N_EVPAIRS) { *slot = -1; return 0; }
   *slot = e->ev_used++;
-  e->ev_inside[*slot] = e->ev_open > 0 && kind >= 5;
+  e->ev_inside[*slot] = e->ev_open > 0 && kind >= 5 && kind <= 7;
+  e->ev_flops[*slot] = 0.0;
   ++e->ev_open;
   e->ev_done[*slot] = false;
   e->ev_kind[*slot] = kind;
@@ -228,44 +233,69 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   e->st.nranks = nranks;
   CHK(bind(e));
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  size_t pbytes = sizeof(double) * (size_t)e->ldp * e->cols_alloc;
-  for (int p = 0; p < 6; ++p) {
-    if (p == DAV_PANEL_BV && !e->gev) continue;
-    HIPCHK(hipMalloc(&e->panel[p], pbytes));
-    HIPCHK(hipMemsetAsync(e->panel[p], 0, pbytes, e->stream));
-  }
+  // sizes first, then ONE device allocation and ONE pinned allocation carved up (256-byte aligned pieces)
+  const size_t pbytes = sizeof(double) * (size_t)e->ldp * e->cols_alloc;
   e->xt_group_stride = std::max(e->ncols_pad, e->nloc_pad) * 16;   // sym-tiled sweeps index whole 256-row blocks
-  HIPCHK(hipMalloc(&e->xt, sizeof(double) * e->xt_group_stride * 4));
-  HIPCHK(hipMemsetAsync(e->xt, 0, sizeof(double) * e->xt_group_stride * 4, e->stream));
   int nsplit, jc;
   matvec_plan(e->nloc_pad, e->ncols_pad, 4, &nsplit, &jc, e->tune.mv_target, e->tune.mv_nsplit);
-  size_t s1 = matvec_slab_doubles(e->nloc_pad, 4, nsplit);
-  size_t s2 = gram_scratch_doubles(e->cols_alloc, e->cols_alloc, e->nloc_pad);
+  const size_t s1 = matvec_slab_doubles(e->nloc_pad, 4, nsplit);
+  const size_t s2 = gram_scratch_doubles(e->cols_alloc, e->cols_alloc, e->nloc_pad);
   e->scratch_doubles = std::max(s1, s2);
-  HIPCHK(hipMalloc(&e->scratch, sizeof(double) * e->scratch_doubles));
   e->gram_doubles = 2 * (size_t)e->cols_alloc * e->cols_alloc;      // H and S blocks of one projection side by side
-  HIPCHK(hipMalloc(&e->gram_dev, sizeof(double) * e->gram_doubles));
-  HIPCHK(hipHostMalloc(&e->gram_host, sizeof(double) * e->gram_doubles, hipHostMallocMapped));
-  HIPCHK(hipHostGetDevicePointer((void**)&e->gram_host_dev, e->gram_host, 0));
-  HIPCHK(hipMalloc(&e->gather_dev, sizeof(double) * (size_t)e->ncols_pad));
-  HIPCHK(hipHostMalloc(&e->agree_pin, sizeof(double) * 16 * (size_t)e->nranks, hipHostMallocDefault));
-  HIPCHK(hipMalloc(&e->idx_dev, sizeof(int64_t) * e->cols_alloc));
-  HIPCHK(hipMalloc(&e->norm_partial, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc));
-  HIPCHK(hipMalloc(&e->counters, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8)));
-  HIPCHK(hipMemsetAsync(e->counters, 0, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8), e->stream));
   e->small_doubles = 3 * (size_t)roundup(e->cols_alloc, 4) * roundup(e->cols_alloc, 64);
+  size_t dev_total = 0, host_total = 0;
+  auto carve = [](size_t& total, size_t bytes) { const size_t off = total; total += (bytes + 255) / 256 * 256; return off; };
+  size_t off_panel[6] = {0, 0, 0, 0, 0, 0};
+  for (int p = 0; p < 6; ++p)
+    if (p != DAV_PANEL_BV || e->gev) off_panel[p] = carve(dev_total, pbytes);
+  const size_t off_xt = carve(dev_total, sizeof(double) * e->xt_group_stride * 4);
+  const size_t off_diag0 = carve(dev_total, sizeof(double) * e->nloc_pad), off_diag1 = carve(dev_total, sizeof(double) * e->nloc_pad);
+  const size_t off_counters = carve(dev_total, sizeof(unsigned) * (GRAM_MAX_COUNTERS + 8));
+  const size_t zeroed = dev_total;                                  // everything up to here starts as zeros
+  const size_t off_scratch = carve(dev_total, sizeof(double) * e->scratch_doubles);
+  const size_t off_gram = carve(dev_total, sizeof(double) * e->gram_doubles);
+  const size_t off_gather = carve(dev_total, sizeof(double) * (size_t)e->ncols_pad);
+  const size_t off_idx = carve(dev_total, sizeof(int64_t) * e->cols_alloc);
+  const size_t off_norm = carve(dev_total, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc);
+  size_t off_sm[N_SMALL], off_smh[N_SMALL];
+  for (int i = 0; i < N_SMALL; ++i) off_sm[i] = carve(dev_total, sizeof(double) * e->small_doubles);
+  const size_t off_gramh = carve(host_total, sizeof(double) * e->gram_doubles);
+  const size_t off_agree = carve(host_total, sizeof(double) * 16 * (size_t)e->nranks);
+  for (int i = 0; i < N_SMALL; ++i) off_smh[i] = carve(host_total, sizeof(double) * e->small_doubles);
+  {
+    hipError_t r = hipMalloc(&e->arena, dev_total);
+    if (r != hipSuccess) {
+      (void)hipGetLastError();
+      e->arena = nullptr;
+      return fail("dav_create: hipMalloc of the engine's panels and work space (" + std::to_string(dev_total >> 20) + " MiB) failed: " + hipGetErrorString(r));
+    }
+  }
+  HIPCHK(hipHostMalloc(&e->arena_host, host_total, hipHostMallocMapped));
+  char* host_dev = nullptr;
+  HIPCHK(hipHostGetDevicePointer((void**)&host_dev, e->arena_host, 0));
+  HIPCHK(hipMemsetAsync(e->arena, 0, zeroed, e->stream));
+  for (int p = 0; p < 6; ++p)
+    if (p != DAV_PANEL_BV || e->gev) e->panel[p] = (double*)(e->arena + off_panel[p]);
+  e->xt = (double*)(e->arena + off_xt);
+  e->op[0].diag = (double*)(e->arena + off_diag0);
+  e->op[1].diag = (double*)(e->arena + off_diag1);
+  e->counters = (unsigned*)(e->arena + off_counters);
+  e->scratch = (double*)(e->arena + off_scratch);
+  e->gram_dev = (double*)(e->arena + off_gram);
+  e->gather_dev = (double*)(e->arena + off_gather);
+  e->idx_dev = (int64_t*)(e->arena + off_idx);
+  e->norm_partial = (double*)(e->arena + off_norm);
+  e->gram_host = (double*)(e->arena_host + off_gramh);
+  e->gram_host_dev = (double*)(host_dev + off_gramh);
+  e->agree_pin = (double*)(e->arena_host + off_agree);
   for (int i = 0; i < N_SMALL; ++i) {
-    HIPCHK(hipMalloc(&e->sm[i].dev, sizeof(double) * e->small_doubles));
-    HIPCHK(hipHostMalloc(&e->sm[i].host, sizeof(double) * e->small_doubles, hipHostMallocDefault));
+    e->sm[i].dev = (double*)(e->arena + off_sm[i]);
+    e->sm[i].host = (double*)(e->arena_host + off_smh[i]);
     HIPCHK(hipEventCreateWithFlags(&e->sm[i].done, hipEventDisableTiming));
   }
   for (int i = 0; i < N_EVPAIRS; ++i) {
     HIPCHK(hipEventCreate(&e->ev[i][0]));
     HIPCHK(hipEventCreate(&e->ev[i][1]));
-  }
-  for (int w = 0; w < 2; ++w) {
-    HIPCHK(hipMalloc(&e->op[w].diag, sizeof(double) * e->nloc_pad));
-    HIPCHK(hipMemsetAsync(e->op[w].diag, 0, sizeof(double) * e->nloc_pad, e->stream));
   }
   HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
@@ -276,17 +306,8 @@ extern "C" int dav_destroy(dav_handle_t e) {
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->comm && g_rccl.lib) g_rccl.CommDestroy(e->comm);
-  for (int p = 0; p < 6; ++p)
-    if (e->panel[p]) hipFree(e->panel[p]);
-  hipFree(e->xt);
-  hipFree(e->scratch);
-  hipFree(e->gram_dev);
-  if (e->gram_host) hipHostFree(e->gram_host);
-  if (e->agree_pin) hipHostFree(e->agree_pin);
-  hipFree(e->gather_dev);
-  hipFree(e->idx_dev);
-  hipFree(e->norm_partial);
-  hipFree(e->counters);
+  if (e->arena) hipFree(e->arena);
+  if (e->arena_host) hipHostFree(e->arena_host);
   hipFree(e->gjd_ws);
   ingest_release(e);
   shm_release(e);
@@ -313,11 +334,8 @@ extern "C" int dav_destroy(dav_handle_t e) {
   sym_set_release(e->sym);
   hipFree(e->sym_wpart);
   hipFree(e->sym_wrecv);
-  for (int i = 0; i < N_SMALL; ++i) {
-    hipFree(e->sm[i].dev);
-    if (e->sm[i].host) hipHostFree(e->sm[i].host);
+  for (int i = 0; i < N_SMALL; ++i)
     if (e->sm[i].done) hipEventDestroy(e->sm[i].done);
-  }
   for (int i = 0; i < N_EVPAIRS; ++i) {
     if (e->ev[i][0]) hipEventDestroy(e->ev[i][0]);
     if (e->ev[i][1]) hipEventDestroy(e->ev[i][1]);
@@ -327,7 +345,6 @@ extern "C" int dav_destroy(dav_handle_t e) {
     hipFree(e->op[w].a);
     hipFree(e->op[w].a32);
     hipFree(e->op[w].e_table);
-    hipFree(e->op[w].diag);
   }
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;

@@ -258,6 +258,15 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
         CHK(grp.end("all-gather of the new block", e->stream));
       }
       if (timed && which == DAV_OP_A) CHK(timed_begin(e, 4, 2.0 * (double)e->n * (double)e->n * kk / e->nranks, &kslot));
+      if (timed && which == DAV_OP_B) {
+        // the second operator's sweep kernels by what they read (level 2): stored tiles -> bytes, generated block rows -> entries
+        // evaluated (once per 16 columns; once per 32 where the generating variant of the wide kernel runs)
+        const double tiles_entries = (double)set.ntiles * SYM_TB * SYM_TB;
+        const bool gen_shared = o.kind == DAV_KIND_HASHED && R == 2 && kk > 16 && e->tune.sym_wide > 0 && e->tune.sym_gen_wide;
+        if (o.kind == DAV_KIND_DENSE) CHK(timed_begin(e, 8, (use32 ? 4.0 : 8.0) * tiles_entries + 16.0 * (double)e->n * kk, &kslot));
+        else CHK(timed_begin(e, 9, tiles_entries * (gen_shared ? (npair + 1) / 2 : npair), &kslot));
+        if (kslot >= 0) e->ev_flops[kslot] = 4.0 * tiles_entries * kk;          // every stored / generated entry is used twice
+      }
       double* slabT = e->sym_slab + (int64_t)npair * dstride;
       const int nitems = R > 1 ? pl->nitems : set.nitems;
       if (nitems > 0) {                      // a rank can be left without a block row (more ranks than groups of block rows)

@@ -162,6 +162,12 @@ struct dav_engine {
   int rank = 0, nranks = 1, gev = 0;
   int max_cols = 0, cols_alloc = 0;
   int m = 0;
+  // Everything dav_create allocates lives in TWO allocations (round 5): `arena` (device: panels, Xt, scratch, small results,
+  // staging twins, diagonals, counters) and `arena_host` (pinned, device-visible: result target, small-matrix staging).  A
+  // hipFree / hipHostFree costs ~0.2 ms whatever its size (it synchronises the device): 25 of them were most of what
+  // dav_destroy took - and with it a sixth of a drop-in call at N=20000.  The members below point into the arenas.
+  char* arena = nullptr;
+  char* arena_host = nullptr;
   double* panel[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t ldp = 0;
   double* xt = nullptr;
@@ -230,6 +236,7 @@ struct dav_engine {
   dav_stats st{};
   hipEvent_t ev[N_EVPAIRS][2];
   double ev_bytes[N_EVPAIRS];
+  double ev_flops[N_EVPAIRS];     // kinds 8 / 9 (sweep kernels of the second operator): flops next to bytes / entries
   int ev_kind[N_EVPAIRS];
   bool ev_done[N_EVPAIRS];        // end event recorded (a call that fails between begin and end leaves a pair without one)
   bool ev_inside[N_EVPAIRS];      // a collective's pair opened inside another pair (the end-to-end pair of an apply)

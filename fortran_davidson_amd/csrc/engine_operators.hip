@@ -257,9 +257,13 @@ int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind 
     // (two panels alternate, so the copy of column J + 1 is queued behind the cut of column J), then cut into tiles
     const int nb = e->sym_nb;
     const int64_t ldp_stage = (int64_t)nb * SYM_TB;
+    // G block columns per copy (round 5): a 2-D copy from pageable host memory carries a fixed cost (the runtime pins the pages it
+    // touches), 79 copies of one block column each ran at 48 GB/s where one copy of the whole matrix reaches 53; four block columns
+    // per copy (the part of the group above its diagonal blocks - 6 tiles in 4 block columns - crosses the link for nothing)
+    const int G = (size_t)ldp_stage * SYM_TB * 4 * sizeof(double) <= ((size_t)512 << 20) ? 4 : 1;
     double* stage[2] = {nullptr, nullptr};
     for (int b = 0; b < 2; ++b) {
-      hipError_t r = hipMalloc(&stage[b], sizeof(double) * (size_t)ldp_stage * SYM_TB);
+      hipError_t r = hipMalloc(&stage[b], sizeof(double) * (size_t)ldp_stage * SYM_TB * G);
       if (r != hipSuccess) {
         (void)hipGetLastError();
         if (stage[0]) hipFree(stage[0]);
@@ -267,20 +271,23 @@ int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind 
       }
     }
     int rc = 0;
-    for (int J = 0; J < nb && rc == 0; ++J) {
-      const int64_t r0 = (int64_t)J * SYM_TB, nr = e->n - r0;
-      const int nc = (int)std::min<int64_t>(SYM_TB, e->n - r0);
-      if (nr <= 0) {                                    // block rows / columns wholly in the padding: zero tiles
-        launch_retile_panel(e->stream, stage[J & 1], ldp_stage, 0, 0, J, nb, e->sym.row_off, o.a);
-        continue;
-      }
-      if (hipMemcpy2DAsync(stage[J & 1], sizeof(double) * ldp_stage, a + r0 + r0 * lda, sizeof(double) * lda, sizeof(double) * nr,
-                           (size_t)nc, kind, e->stream) != hipSuccess) {
+    for (int J0 = 0, grp = 0; J0 < nb && rc == 0; J0 += G, ++grp) {
+      double* st = stage[grp & 1];
+      const int64_t r0 = (int64_t)J0 * SYM_TB, nr = e->n - r0;
+      const int64_t ncg = std::min<int64_t>((int64_t)G * SYM_TB, e->n - r0);       // columns of the group inside the matrix
+      if (nr > 0 && hipMemcpy2DAsync(st, sizeof(double) * ldp_stage, a + r0 + r0 * lda, sizeof(double) * lda, sizeof(double) * nr,
+                                     (size_t)ncg, kind, e->stream) != hipSuccess) {
         (void)hipGetLastError();
-        rc = fail("dav_set_dense: copy of a block column failed");
+        rc = fail("dav_set_dense: copy of a group of block columns failed");
         break;
       }
-      launch_retile_panel(e->stream, stage[J & 1], ldp_stage, nr, nc, J, nb, e->sym.row_off, o.a);
+      for (int J = J0; J < std::min(nb, J0 + G); ++J) {
+        const int64_t d = (int64_t)(J - J0) * SYM_TB;                            // the block column starts d rows down and d columns in
+        const int64_t nrj = e->n - (int64_t)J * SYM_TB;
+        const int ncj = (int)std::max<int64_t>(0, std::min<int64_t>(SYM_TB, nrj));
+        // (block rows / columns wholly in the padding: zero tiles)
+        launch_retile_panel(e->stream, st + d + d * ldp_stage, ldp_stage, std::max<int64_t>(nrj, 0), ncj, J, nb, e->sym.row_off, o.a);
+      }
     }
     hipStreamSynchronize(e->stream);
     hipFree(stage[0]);

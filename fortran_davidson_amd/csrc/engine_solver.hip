@@ -155,10 +155,14 @@ extern "C" int dav_project_ortho(dav_handle_t e, int m, int k, double* H_raw, in
   int slot;
   CHK(timed_begin(e, 1, 0, &slot));
   const double* Vp = panel_ptr(e, DAV_PANEL_V, 0);
-  launch_gram(e->stream, Vp, e->ldp, p, panel_ptr(e, DAV_PANEL_W, m), e->ldp, k, e->nloc_pad, e->scratch, result_target(e), e->counters, e->tune.gram_wgs);
-  launch_gram(e->stream, Vp, e->ldp, p, panel_ptr(e, DAV_PANEL_V, m), e->ldp, k, e->nloc_pad, e->scratch, result_target(e) + blk, e->counters, e->tune.gram_wgs);
-  if (both)
-    launch_gram(e->stream, Vp, e->ldp, p, panel_ptr(e, DAV_PANEL_BV, m), e->ldp, k, e->nloc_pad, e->scratch, result_target(e) + 2 * blk, e->counters, e->tune.gram_wgs);
+  const double* Qs[3] = {panel_ptr(e, DAV_PANEL_W, m), panel_ptr(e, DAV_PANEL_V, m), both ? panel_ptr(e, DAV_PANEL_BV, m) : nullptr};
+  if (gram_scratch_doubles(p, nblk * k, e->nloc_pad) <= e->scratch_doubles) {
+    // ONE launch and one reduction for all blocks: the right-hand side's columns come from the three panels
+    launch_gram_multi(e->stream, Vp, e->ldp, p, Qs, nblk, k, e->ldp, e->nloc_pad, e->scratch, result_target(e), e->counters, e->tune.gram_wgs);
+  } else {
+    for (int b = 0; b < nblk; ++b)
+      launch_gram(e->stream, Vp, e->ldp, p, Qs[b], e->ldp, k, e->nloc_pad, e->scratch, result_target(e) + b * blk, e->counters, e->tune.gram_wgs);
+  }
   CHK(timed_end(e, slot));
   if (e->nranks > 1) CHK(need_comm(e));
   CHK(result_fetch(e, nblk * blk));
@@ -391,8 +395,13 @@ static int ortho_apply_impl(E* e, int m, int kt, const double* C, int64_t ldc, c
   CHK(timed_begin(e, 2, 0, &slot));
   const int panels[3] = {DAV_PANEL_V, DAV_PANEL_W, DAV_PANEL_BV};
   const int npanels = with_images ? (e->gev ? 3 : 2) : 1;
-  for (int i = 0; i < npanels; ++i) {
+  // the basis panel and its images are neighbours in the engine's arena: one batched launch (blockIdx.z = panel) where the
+  // product runs in place
+  const int64_t pstride = e->panel[DAV_PANEL_W] - e->panel[DAV_PANEL_V];
+  const bool batched = npanels > 1 && kt <= PG_INPLACE_COLS && (!e->gev || e->panel[DAV_PANEL_BV] - e->panel[DAV_PANEL_W] == pstride);
+  for (int i = 0; i < (batched ? 1 : npanels); ++i) {
     PanelGemmArgs a{};
+    if (batched) { a.batch = npanels; a.batch_stride = pstride; }
     a.P1 = panel_ptr(e, panels[i], m); a.ld1 = e->ldp; a.p1 = kt; a.M1 = sm2[0].dev; a.tp1 = ld_m;
     a.P2 = panel_ptr(e, panels[i], 0); a.ld2 = e->ldp; a.p2 = m; a.M2 = sm2[1].dev; a.tp2 = ld_cm;
     // in place where one workgroup covers all kt output columns (k_panel.hip: a wave has read its rows of every input column before

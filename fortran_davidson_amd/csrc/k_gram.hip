@@ -34,9 +34,12 @@ __device__ __forceinline__ double dpp_row(double v) {
 }
 }  // namespace
 
+// columns [qeach * s, qeach * (s + 1)) of the right-hand side come from base[s] (launch_gram: one block, qeach = q)
+struct GramQ { const double* base[3]; int qeach; };
+
 template <int PF, int QF, int U>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P, int64_t ldp, int p,
-                                                   const double* __restrict__ Q, int64_t ldq, int q,
+                                                   GramQ Qs, int64_t ldq, int q,
                                                    int64_t nrows_pad, int ptiles, int qtiles, int nchunks,
                                                    double* __restrict__ slab, int ppad, int qpad, int rows_per_wg,
                                                    double* __restrict__ out, unsigned* __restrict__ counters) {
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ P,
   for (int f = 0; f < QF; ++f) {
     int col = qc0 + 4 * f + i4;
     if (col >= q) col = q - 1;
-    qp[f] = Q + (int64_t)col * ldq + roff;
+    const int src = col / Qs.qeach;
+    qp[f] = Qs.base[src] + (int64_t)(col - src * Qs.qeach) * ldq + roff;
   }
 
   double acc[PF][QF];
@@ -215,7 +219,7 @@ size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
 }
 
 template <int PF, int QF, int U>
-static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
+static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int p, const GramQ& Q, int64_t ldq, int q,
                               int64_t nrows_pad, double* scratch, int ppad, int qpad, double* out_dev, unsigned* counters, int wg_target) {
   const int ptiles = (p + 4 * PF - 1) / (4 * PF), qtiles = (q + 4 * QF - 1) / (4 * QF);
   // rows per workgroup: ONE workgroup per CU where the panels are long enough (wg_target = 256 workgroups over all output tiles:
@@ -239,8 +243,8 @@ static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int 
 }
 
 // counters: GRAM_MAX_COUNTERS zeroed device words (nullptr: always the two-kernel route)
-void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
-                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters, int wg_target) {
+static void launch_gram_q(hipStream_t st, const double* P, int64_t ldp, int p, const GramQ& Q, int64_t ldq, int q,
+                          int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters, int wg_target) {
   int ppad = pad16(p), qpad = pad16(q);
   if (wg_target <= 0) wg_target = 256;
   // register tile of a wave: 32 x 32 (64 accumulators), 32 x 16, 16 x 16 columns
@@ -250,4 +254,16 @@ void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const doub
     launch_gram_tiles<8, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters, wg_target);
   else
     launch_gram_tiles<4, 4, 4>(st, P, ldp, p, Q, ldq, q, nrows_pad, scratch, ppad, qpad, out_dev, counters, wg_target);
+}
+
+void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
+                 int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters, int wg_target) {
+  GramQ src{{Q, Q, Q}, q > 0 ? q : 1};
+  launch_gram_q(st, P, ldp, p, src, ldq, q, nrows_pad, scratch, out_dev, counters, wg_target);
+}
+
+void launch_gram_multi(hipStream_t st, const double* P, int64_t ldp, int p, const double* const* Qs, int nq, int qeach, int64_t ldq,
+                       int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters, int wg_target) {
+  GramQ src{{Qs[0], Qs[nq > 1 ? 1 : 0], Qs[nq > 2 ? 2 : 0]}, qeach > 0 ? qeach : 1};
+  launch_gram_q(st, P, ldp, p, src, ldq, nq * qeach, nrows_pad, scratch, out_dev, counters, wg_target);
 }

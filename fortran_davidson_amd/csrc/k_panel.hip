@@ -101,6 +101,12 @@ __device__ __forceinline__ void pg_term(const double* P, int64_t ld, int p, cons
 template <int QT, int U, bool PIN>
 __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
   __shared__ double nrm[4][16 * QT];
+  if (A.batch > 1) {                                  // panel blockIdx.z of a batched launch (uniform)
+    const int64_t shift = (int64_t)blockIdx.z * A.batch_stride;
+    A.P1 += shift;
+    if (A.p2 > 0) A.P2 += shift;
+    A.out += shift;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int64_t i0 = (int64_t)blockIdx.x * PG_ROWS + wave * 32;
@@ -173,10 +179,11 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(PanelGemmArgs A) {
 // a.pin: the pinned schedule (MFMAs of step s, then the requests of step s + U) or the compiler's own order of a round
 void launch_panel_gemm(hipStream_t st, const PanelGemmArgs& a) {
   unsigned gx = (unsigned)(a.nrows_pad / PG_ROWS);
+  const unsigned gz = a.batch > 1 ? (unsigned)a.batch : 1u;
 #define DAV_PG_LAUNCH(QT, GY)                                                                                              \
   do {                                                                                                                      \
-    if (a.pin) hipLaunchKernelGGL((panel_gemm_kernel<QT, 8, true>), dim3(gx, GY), dim3(256), 0, st, a);                    \
-    else hipLaunchKernelGGL((panel_gemm_kernel<QT, 8, false>), dim3(gx, GY), dim3(256), 0, st, a);                         \
+    if (a.pin) hipLaunchKernelGGL((panel_gemm_kernel<QT, 8, true>), dim3(gx, GY, gz), dim3(256), 0, st, a);                \
+    else hipLaunchKernelGGL((panel_gemm_kernel<QT, 8, false>), dim3(gx, GY, gz), dim3(256), 0, st, a);                     \
   } while (0)
   if (a.q <= 16) DAV_PG_LAUNCH(1, (a.q + 15) / 16);
   else if (a.q <= 32) DAV_PG_LAUNCH(2, (a.q + 31) / 32);

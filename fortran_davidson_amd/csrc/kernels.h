@@ -35,6 +35,10 @@ constexpr int GRAM_MAX_COUNTERS = 256;
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
                  int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr, int wg_target = 0);
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
+// C = P^T [Q0 | Q1 | Q2] (p x nq*qeach): the columns of the right-hand side come from up to three blocks of qeach columns each
+// (same leading dimension) - the projection and the Gram blocks of one iteration in ONE launch and one reduction (round 5)
+void launch_gram_multi(hipStream_t st, const double* P, int64_t ldp, int p, const double* const* Qs, int nq, int qeach, int64_t ldq,
+                       int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr, int wg_target = 0);
 
 // ---- K3/K4/K5: panel x small matrix ---------------------------------------------------------------
 // The small matrices are passed as MFMA-B OPERAND IMAGES (pg_image_index): for step s (panel columns 4 s .. 4 s + 3) and column
@@ -58,6 +62,10 @@ struct PanelGemmArgs {
   // workgroups of N=200000 (and +0.28 ms per sweep when the row-slab block matvec summed its column chunks this way: removed)
   double* norm_out; unsigned* counter;
   int pin;                                  // 1: the pinned software pipeline of the k loop (k_panel.hip), 0: the compiler's order
+  // batch > 1 (round 5): the same product on `batch` panels in ONE launch (blockIdx.z): P1, P2 and out of panel z lie batch_stride
+  // doubles behind those of panel z - 1 (the basis panel, its image under A and - generalized - under B are neighbours in the
+  // engine's arena); same small matrices.  Epilogue 0 only.
+  int batch; int64_t batch_stride;
 };
 // doubles of the operand image of a p x q matrix, its tiles per step, and the index of M[i][j] in it
 static inline int64_t pg_image_tiles(int q) { return ((int64_t)(q > 0 ? q : 1) + 63) / 64 * 4; }

@@ -26,7 +26,10 @@ class Stats(C.Structure):
                 ("apply_launches", C.c_int64), ("restarts", C.c_int64),
                 ("allgather_ms", C.c_double), ("reduce_scatter_ms", C.c_double), ("allreduce_ms", C.c_double),
                 ("allgather_bytes", C.c_double), ("reduce_scatter_bytes", C.c_double), ("allreduce_bytes", C.c_double),
-                ("collectives", C.c_int64), ("comm_ranks", C.c_int32), ("comm_overlap", C.c_int32), ("apply_comm_ms", C.c_double)]
+                ("collectives", C.c_int64), ("comm_ranks", C.c_int32), ("comm_overlap", C.c_int32), ("apply_comm_ms", C.c_double),
+                ("b_stored_kernel_ms", C.c_double), ("b_stored_bytes", C.c_double), ("b_stored_flops", C.c_double),
+                ("b_generated_kernel_ms", C.c_double), ("b_generated_entries", C.c_double), ("b_generated_flops", C.c_double),
+                ("b_stored_launches", C.c_int64), ("b_generated_launches", C.c_int64)]
 
 
 ABI_VERSION = 104      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors

@@ -49,7 +49,7 @@ module davidson_device
   end type davidson_engine
 
   !> Correction policies of the outer loop (see davidson_device_loop)
-  integer, parameter, public :: POLICY_ALL = 0, POLICY_UNCONVERGED = 1
+  integer, parameter, public :: POLICY_ALL = 0, POLICY_UNCONVERGED = 1, POLICY_LOCKING = 2
 
   abstract interface
      function block_operator(input_vect) result(output_vect)
@@ -95,26 +95,34 @@ contains
     end if
   end function env_storage
 
-  !> Is the matrix symmetric where it is looked at?  Exact comparison of up to 12 whole rows with their columns (the first, the
-  !> last, and rows spread over the order by a fixed stride), both triangles of each: O(24 n) loads, independent of what the rest
-  !> of the call costs.  A matrix with a single asymmetric entry outside the sampled rows passes - as it passes the reference,
-  !> which never looks; what the probe guards against is an input that is not meant to be symmetric at all.
+  !> Is the matrix symmetric where it is looked at?  Exact comparison of 8 sampled rows (the first, the last, six spread over the
+  !> order) with their columns at up to 512 positions each (the row's neighbourhood of the diagonal excluded: stride over the whole
+  !> order) - ~4000 pairs, a fraction of a millisecond whatever the order (a walk along a ROW of a column-major matrix is one cache
+  !> miss per entry: whole rows cost 3.5 ms at N=20000, a tenth of the upload they are meant to halve).  A matrix with a single
+  !> asymmetric entry outside the sample passes - as it passes the reference, which never looks; what the probe guards against is an
+  !> input that is not meant to be symmetric at all.
   function symmetry_probe(matrix) result(symmetric)
     real(dp), dimension(:, :), intent(in) :: matrix
     logical :: symmetric
-    integer :: n, k, i, j, nsample
+    integer :: n, k, i, j, nsample, step
     n = size(matrix, 1)
     symmetric = size(matrix, 2) == n
     if (.not. symmetric) return
-    nsample = min(n, 12)
+    nsample = min(n, 8)
+    step = max(1, n / 512)
     do k = 0, nsample - 1
        i = 1 + int(int(k, c_int64_t) * int(n - 1, c_int64_t) / int(max(nsample - 1, 1), c_int64_t))
-       do j = 1, n
+       do j = 1 + mod(k, step), n, step
           if (matrix(i, j) /= matrix(j, i)) then
              symmetric = .false.
              return
           end if
        end do
+       ! the two corners of the row: the entries a one-sided (triangular) input would leave different
+       if (matrix(i, 1) /= matrix(1, i) .or. matrix(i, n) /= matrix(n, i)) then
+          symmetric = .false.
+          return
+       end if
     end do
   end function symmetry_probe
 
@@ -201,7 +209,11 @@ contains
   !> the `lowest` wanted pairs whose residual is still above the tolerance are corrected, convergence is
   !> tested on all wanted pairs at once, and the basis grows by at most `lowest` columns per iteration -
   !> narrower panels, one 16-column pass of the symmetric sweep per iteration, and GJD inner solves only for
-  !> the pairs that need them.
+  !> the pairs that need them.  "locking" (opt-in; standard problems; the deflation the reference's header cites and never
+  !> implements, src/davidson.f90:7-8): a wanted pair whose residual is below the tolerance is locked - its Ritz vector leaves the
+  !> active basis, which is kept orthogonal to it, its value is final - and the Rayleigh-Ritz problem, the corrections and the
+  !> restarts only concern the pairs still wanted (locking_loop in davidson_device_loop; oracle:
+  !> generalized_eigensolver_dense_locking).
   subroutine engine_set_correction_policy(eng, policy)
     type(davidson_engine), intent(inout) :: eng
     character(len=*), intent(in) :: policy
@@ -210,8 +222,10 @@ contains
        eng%policy = POLICY_ALL
     case ("unconverged")
        eng%policy = POLICY_UNCONVERGED
+    case ("locking")
+       eng%policy = POLICY_LOCKING
     case default
-       print *, "engine_set_correction_policy: policy must be 'all' or 'unconverged', got '", trim(policy), "'"
+       print *, "engine_set_correction_policy: policy must be 'all', 'unconverged' or 'locking', got '", trim(policy), "'"
        error stop
     end select
   end subroutine engine_set_correction_policy
@@ -506,7 +520,14 @@ contains
 
     iters = max_iterations + 1
     done = .false.
-    outer_loop: do i = 1, max_iterations
+    if (pol == POLICY_LOCKING) then
+       if (gev .or. host_ops .or. drr) then
+          print *, "generalized_eigensolver: the 'locking' policy serves standard problems on device operators (generalized: 'unconverged')"
+          error stop
+       end if
+       call locking_loop()
+    end if
+    outer_loop: do i = 1, merge(0, max_iterations, pol == POLICY_LOCKING)
        ! 3. Rayleigh-Ritz on the host (the only LAPACK call on the path)
        if (allocated(theta)) deallocate(theta, y)
        allocate(theta(m), y(m, m))
@@ -825,6 +846,173 @@ contains
       end if
     end subroutine project_with_last_pass
 
+    !> Opt-in policy "locking" (see engine_set_correction_policy; oracle/davidson_oracle.py: generalized_eigensolver_dense_locking
+    !> states the same loop in the reference's building blocks).  Basis columns 1..nlock are the locked Ritz vectors (W carries
+    !> their images), nlock+1..m the active basis; hm is the projected matrix of all m columns, of which only the active block is
+    !> ever solved.  A contraction V <- V Z, W <- W Z (dav_restart with the m x keep matrix Z) does the locking rotation and the
+    !> collapse restart in one product.
+    subroutine locking_loop()
+      integer :: nlock, want, ma, nconv, want_new, m_rest, keep_a, keep, jj, col, it
+      real(dp), allocatable :: th(:), ya(:, :), yfull(:, :), err(:), theta_lock(:), z(:, :), lam(:), ysel(:, :), th_sel(:)
+      integer, allocatable :: rest(:), order(:)
+      logical, allocatable :: conv(:)
+      logical :: grow
+      allocate(theta_lock(lowest), lam(lowest))
+      nlock = 0
+      do it = 1, max_iterations
+         want = lowest - nlock
+         ma = m - nlock
+         call check_dav(dav_agree_next(h, [real(it, dp), real(m, dp), real(nlock, dp), real(want, dp), tolerance, real(pol, dp), &
+              real(meth, dp)], 7_c_int), "dav_agree_next")
+         if (allocated(th)) deallocate(th, ya, yfull, err, conv)
+         allocate(th(ma), ya(ma, ma), yfull(m, want), err(want), conv(want))
+         call lapack_rayleigh_ritz(hm(nlock + 1:m, nlock + 1:m), th, ya, ma)
+         call lap(2)
+         yfull = 0.0_dp
+         yfull(nlock + 1:m, :) = ya(:, 1:want)
+         call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(want, c_int), int(want, c_int), yfull, &
+              int(m, c_int64_t), th, int(meth, c_int), err), "dav_ritz_residual_correction")
+         call lap(3)
+         conv = err < tolerance
+         nconv = count(conv)
+         if (trace_iterations()) print "(a, i0, a, i0, a, i0, a, es10.3, a, i0)", "davidson trace (locking): iteration ", it, " m=", m, &
+              " locked=", nlock, " max residual ", maxval(err), " newly below tolerance ", nconv
+         want_new = want - nconv
+         m_rest = ma - nconv
+         ! Ritz vectors that stay active, in ascending order of their values
+         if (allocated(rest)) deallocate(rest)
+         allocate(rest(m_rest))
+         col = 0
+         do jj = 1, ma
+            if (jj <= want) then
+               if (conv(jj)) cycle
+            end if
+            col = col + 1
+            rest(col) = jj
+         end do
+         if (want_new == 0) then
+            ! every wanted pair is locked or has just converged: Ritz vectors in ascending order of the eigenvalues
+            lam(1:nlock) = theta_lock(1:nlock)
+            lam(nlock + 1:lowest) = th(1:want)
+            allocate(order(lowest), ysel(m, lowest))
+            call ascending_order(lam, order)
+            ysel = 0.0_dp
+            do jj = 1, lowest
+               if (order(jj) <= nlock) then
+                  ysel(order(jj), jj) = 1.0_dp
+               else
+                  ysel(:, jj) = yfull(:, order(jj) - nlock)
+               end if
+            end do
+            eigenvalues = lam(order)
+            call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), ysel, int(m, c_int64_t)), "dav_ritz_vectors")
+            iters = it
+            done = .true.
+            return
+         end if
+         kt = min(want_new, n - m)
+         grow = ((m_rest + want_new <= max_dim) .or. (m_rest <= 2 * want_new)) .and. (m + kt <= cap) .and. kt > 0
+         if (grow) then
+            ! the corrections of the pairs that stay wanted, compacted to the front of the block behind the basis
+            if (allocated(sel)) deallocate(sel, th_sel)
+            allocate(sel(kt), th_sel(kt))
+            col = 0
+            do jj = 1, want
+               if (.not. conv(jj) .and. col < kt) then
+                  col = col + 1
+                  sel(col) = int(jj - 1, c_int)
+                  th_sel(col) = th(jj)
+               end if
+            end do
+            if (meth == DAV_METHOD_GJD) then
+               call check_dav(dav_panel_select(h, DAV_PANEL_X, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
+               call check_dav(dav_panel_select(h, DAV_PANEL_R, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
+               if (allocated(tols)) deallocate(tols)
+               allocate(tols(kt))
+               do jj = 1, kt
+                  tols(jj) = gjd_tol_wanted(err(sel(jj) + 1), tolerance, adaptive_c)
+               end do
+               call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), th_sel, 300_c_int, 1.0e-10_dp, tols, inner), &
+                    "dav_gjd_correction")
+               call lap(8)
+            else
+               call check_dav(dav_panel_select(h, DAV_PANEL_V, int(m, c_int), int(kt, c_int), sel), "dav_panel_select")
+            end if
+            keep_a = m_rest
+         else
+            keep_a = min(2 * want_new, m_rest)          ! collapse restart of the active basis (src/davidson.f90:218)
+         end if
+         keep = nlock + nconv + keep_a
+         if (nconv > 0 .or. keep < m) then
+            ! Z = [e_1 .. e_nlock | Ritz vectors just locked | Ritz vectors kept active]
+            if (allocated(z)) deallocate(z)
+            allocate(z(m, keep))
+            z = 0.0_dp
+            do jj = 1, nlock
+               z(jj, jj) = 1.0_dp
+            end do
+            col = nlock
+            do jj = 1, want
+               if (conv(jj)) then
+                  col = col + 1
+                  z(nlock + 1:m, col) = ya(:, jj)
+                  theta_lock(col) = th(jj)
+               end if
+            end do
+            do jj = 1, keep_a
+               z(nlock + 1:m, col + jj) = ya(:, rest(jj))
+            end do
+            if (grow .and. keep == m .and. kt > 0) then
+               ! the correction block sits behind column m and stays there
+               continue
+            end if
+            call check_dav(dav_restart(h, int(m, c_int), int(keep, c_int), z, int(m, c_int64_t)), "dav_restart")
+            hm(1:keep, 1:keep) = lapack_matmul("T", "N", z, lapack_matmul("N", "N", hm(1:m, 1:m), z))
+            if (keep < m) hm(keep + 1:m, :) = 0.0_dp
+            if (keep < m) hm(:, keep + 1:m) = 0.0_dp
+            nlock = nlock + nconv
+            if (grow .and. keep < m) then
+               print *, "locking_loop: internal error (a growing iteration keeps every active Ritz vector)"
+               error stop
+            end if
+            m = keep
+            nrestart = nrestart + 1
+            if (mod(nrestart, refresh_every) == 0) then
+               ! W was contracted, not recomputed: every refresh_every-th contraction re-applies the operator (as after restarts)
+               call check_dav(dav_expand(h, 0_c_int, int(m, c_int)), "dav_expand")
+               call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
+            end if
+            call lap(7)
+         end if
+         if (grow) then
+            call block_orthonormalise(h, n, m, kt, only_first=.true., last_pass=opass)
+            call lap(4)
+            call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+            call lap(5)
+            call project_with_last_pass(opass + 1)
+            call lap(6)
+            m = m + kt
+         end if
+      end do
+      ! not converged: what is locked plus the current Ritz pairs of the active basis (the caller prints the warning)
+      lam(1:nlock) = theta_lock(1:nlock)
+      if (nlock < lowest) lam(nlock + 1:lowest) = th(1:lowest - nlock)
+      allocate(order(lowest), ysel(m, lowest))
+      call ascending_order(lam, order)
+      eigenvalues = lam(order)
+      ysel = 0.0_dp
+      if (size(yfull, 1) == m) then
+         do jj = 1, lowest
+            if (order(jj) <= nlock) then
+               ysel(order(jj), jj) = 1.0_dp
+            else if (order(jj) - nlock <= size(yfull, 2)) then
+               ysel(:, jj) = yfull(:, order(jj) - nlock)
+            end if
+         end do
+         call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), ysel, int(m, c_int64_t)), "dav_ritz_vectors")
+      end if
+    end subroutine locking_loop
+
     !> X(:, 1:lowest) = V(:, 1:m) * Y(:, 1:lowest) for the Ritz pairs of this iteration (see lazy_x above)
     subroutine finish_ritz_vectors()
       if (lazy_x) call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), y, int(size(y, 1), c_int64_t)), &
@@ -889,6 +1077,26 @@ contains
        if (stat /= 0) c = 0.01_dp
     end if
   end function gjd_adaptive_factor
+
+  !> order(k) = index of the k-th smallest entry (stable insertion sort: a handful of eigenvalues)
+  subroutine ascending_order(x, order)
+    real(dp), intent(in) :: x(:)
+    integer, intent(out) :: order(size(x))
+    integer :: a, b, t
+    do a = 1, size(x)
+       order(a) = a
+    end do
+    do a = 2, size(x)
+       t = order(a)
+       b = a - 1
+       do while (b >= 1)
+          if (x(order(b)) <= x(t)) exit
+          order(b + 1) = order(b)
+          b = b - 1
+       end do
+       order(b + 1) = t
+    end do
+  end subroutine ascending_order
 
   function tick() result(t)
     real(dp) :: t

@@ -166,6 +166,8 @@ contains
     call c_f_pointer(p, eng)
     if (code == 1) then
        call engine_set_correction_policy(eng, "unconverged")
+    else if (code == 2) then
+       call engine_set_correction_policy(eng, "locking")
     else
        call engine_set_correction_policy(eng, "all")
     end if

@@ -23,6 +23,8 @@ module davidson_hip_c
      integer(c_int64_t) :: collectives
      integer(c_int32_t) :: comm_ranks, comm_overlap
      real(c_double) :: apply_comm_ms
+     real(c_double) :: b_stored_kernel_ms, b_stored_bytes, b_stored_flops, b_generated_kernel_ms, b_generated_entries, b_generated_flops
+     integer(c_int64_t) :: b_stored_launches, b_generated_launches
   end type dav_stats
   !> DAV_HIP_ABI_VERSION of include/davidson_hip.h these interfaces were written against: engine_create checks that the
   !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101, 102 and 104)

@@ -111,8 +111,9 @@ class DavidsonEngine:
 
     def set_correction_policy(self, policy):
         """"all" = the reference's policy (default); "unconverged" = opt-in: correct only the wanted pairs
-        that have not converged (Fortran: engine_set_correction_policy)."""
-        self.lib.fd_engine_set_policy(self.p, C.c_int({"all": 0, "unconverged": 1}[policy]))
+        that have not converged; "locking" = opt-in (standard problems): converged wanted pairs are locked and the
+        search space is kept orthogonal to them (Fortran: engine_set_correction_policy)."""
+        self.lib.fd_engine_set_policy(self.p, C.c_int({"all": 0, "unconverged": 1, "locking": 2}[policy]))
 
     def set_inner_precision(self, bits):
         """32: the sweeps inside the GJD correction read an fp32 copy of the stored symmetric tiles (Fortran:

@@ -74,6 +74,12 @@ typedef struct dav_stats {
   int32_t comm_overlap;    /* 1 = wide blocks run their collectives on a second stream under the sweeps */
   double apply_comm_ms;    /* (ABI 104) the part of the collectives' time that lies INSIDE apply_ms (all-gather / reduce-scatter of the */
                            /* applies, timing level 2): apply_ms - apply_comm_ms = packing + kernel + reduction of this rank            */
+  /* (ABI 104) sweep kernels of the SECOND operator by what they read (timing level 2): stored tiles (a dense B, or the resident  */
+  /* block rows of a generated one) - bytes = 8 * stored entries + 16 N k per launch - and generated block rows - entries =       */
+  /* operator entries evaluated per launch                                                                                        */
+  double b_stored_kernel_ms, b_stored_bytes, b_stored_flops;
+  double b_generated_kernel_ms, b_generated_entries, b_generated_flops;
+  int64_t b_stored_launches, b_generated_launches;
 } dav_stats;
 
 /* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */

@@ -314,6 +314,75 @@ def generalized_eigensolver_dense_unconverged(matrix, lowest, method, max_iterat
     return eigenvalues, eigenvectors, iters
 
 
+def generalized_eigensolver_dense_locking(matrix, lowest, method, max_iterations, tolerance, max_dim_sub=None, trace=None):
+    """NOT in the reference: CPU statement of the engine's OPT-IN correction policy "locking" (the deflation the
+    reference's header cites, src/davidson.f90:7-8, and never implements; fortran_davidson_amd/fortran/davidson.f90,
+    POLICY_LOCKING), kept here as its checker.  Standard problems only.  Same building blocks as generalized_eigensolver_dense
+    (davidson.f90:51-246):
+      * a wanted Ritz pair whose residual is below the tolerance is LOCKED: its Ritz vector joins Q, its value is final, and the
+        active basis is rotated to the remaining Ritz vectors (V <- V Y(:, not locked): orthonormal and orthogonal to Q);
+      * the Rayleigh-Ritz problem is that of the active basis alone (H = V^T A V), for the lowest - len(Q) pairs still wanted;
+      * corrections only for the wanted pairs that are not locked; the new block is orthonormalised against Q AND V (QR of
+        [Q V T], davidson.f90:210-213), so the search space stays orthogonal to what is locked;
+      * the active basis grows while m + wanted <= max_dim (one of 2*wanted columns or fewer always grows), else it collapses to its
+        2*wanted lowest Ritz vectors (:218); the solve ends when `lowest` pairs are locked; eigenvalues returned in ascending order."""
+    A = np.asarray(matrix, dtype=np.float64)
+    n = A.shape[0]
+    max_dim = max_dim_sub if max_dim_sub is not None else 10 * lowest
+    if method not in ("DPR", "GJD"):
+        raise ValueError("method must be DPR or GJD")
+    V = generate_preconditioner(diagonal(A), 2 * lowest)
+    Q = np.zeros((n, 0), order="F")
+    locked = []
+    iters = max_iterations + 1
+    theta = np.zeros(0)
+    X = np.zeros((n, 0))
+    for i in range(1, max_iterations + 1):
+        want = lowest - len(locked)
+        H = V.T @ (A @ V)
+        theta, Y = lapack_generalized_eigensolver(H, None)
+        m = V.shape[1]
+        X = np.asfortranarray(V @ Y[:, :want])
+        R = np.asfortranarray(A @ X - X * theta[None, :want])
+        errors = np.array([norm(R[:, j]) for j in range(want)])
+        if trace is not None:
+            trace.widths.append(m + len(locked))
+            trace.errors.append(errors)
+        conv = errors < tolerance
+        rest = [j for j in range(m) if not (j < want and conv[j])]          # Ritz vectors that stay active
+        if conv.any():
+            Q = np.asfortranarray(np.hstack([Q, X[:, conv]]))
+            locked.extend(float(t) for t in theta[:want][conv])
+        if len(locked) == lowest:
+            iters = i
+            if trace is not None:
+                trace.converged = True
+            break
+        want_new = lowest - len(locked)
+        sel = np.nonzero(~conv)[0]
+        m_rest = len(rest)
+        if m_rest + want_new <= max_dim or m_rest <= 2 * want_new:
+            if conv.any():
+                V = np.asfortranarray(V @ Y[:, rest])
+            if method == "DPR":
+                T = compute_DPR_generalized_dense(A, theta[sel], np.asfortranarray(R[:, sel]), None)
+            else:
+                T = compute_GJD_generalized_dense(A, theta[sel], np.asfortranarray(X[:, sel]), np.asfortranarray(R[:, sel]), None)
+            T = T[:, :max(0, n - len(locked) - V.shape[1])]                  # never more columns than the space has left
+            W = lapack_qr(concatenate(concatenate(Q, V) if Q.shape[1] else V, T))
+            V = np.asfortranarray(W[:, Q.shape[1]:])
+        else:
+            V = np.asfortranarray(V @ Y[:, rest[:2 * want_new]])
+    order = np.argsort(np.array(locked)) if len(locked) == lowest else None
+    if order is not None:
+        return np.array(locked)[order], np.asfortranarray(Q[:, order]), iters
+    # not converged: what is locked plus the current Ritz pairs of the active basis
+    lam = np.concatenate([np.array(locked), theta[:lowest - len(locked)]])
+    vec = np.hstack([Q, X[:, :lowest - len(locked)]])
+    order = np.argsort(lam)
+    return lam[order], np.asfortranarray(vec[:, order]), iters
+
+
 # --------------------------------------------------------------------------------------------
 # matrix-free solver, davidson.f90:277-460
 # --------------------------------------------------------------------------------------------

@@ -1,7 +1,8 @@
-"""Opt-in correction policy "unconverged" (not in the reference, so it is never the default):
-corrections only for the wanted Ritz pairs that have not converged.  Same eigenpairs as the reference path
-(golden eigenvalues, residuals below the tolerance); iteration counts equal to the CPU statement of the
-policy in oracle/davidson_oracle.py."""
+"""Opt-in correction policies (not in the reference, so never the default): "unconverged" - corrections only
+for the wanted Ritz pairs that have not converged - and "locking" - converged wanted pairs are locked, the search space is
+kept orthogonal to them (the deflation the reference's header cites, src/davidson.f90:7-8).  Same eigenpairs as the
+reference path (golden eigenvalues, residuals below the tolerance); iteration counts equal to the CPU statements of the
+policies in oracle/davidson_oracle.py."""
 import ctypes as C
 import threading
 
@@ -48,6 +49,85 @@ def test_unconverged_policy_same_eigenpairs_and_oracle_iteration_count(golden, n
     assert iters == it_o, (iters, it_o, tr.widths)
     assert np.abs(lam - lam_o).max() < EV_TOL
     assert iters_all == case["iters"] and np.abs(lam_all - arrays[f"{name}__evals"]).max() < EV_TOL
+
+
+LOCKING_CASES = [c for c in CASES if "gev" not in c]
+
+
+@pytest.mark.parametrize("name", LOCKING_CASES)
+def test_locking_policy_same_eigenpairs_and_oracle_iteration_count(golden, name):
+    """"locking" on the standard golden cases: eigenvalues of the reference, residuals below the tolerance, orthonormal vectors, the
+    iteration count of the oracle's statement of the policy; and back to the reference's policy on the same engine."""
+    manifest, arrays = golden
+    case = manifest["dense"][name]
+    A, _ = case_matrices(case, arrays)
+    L, tol = case["lowest"], case["tol"]
+    with fd.DavidsonEngine(case["n"], L, case["max_dim"]) as eng:
+        eng.set_correction_policy("locking")
+        eng.set_dense(1, A)
+        lam, vec, iters = eng.solve(case["method"], case["max_it"], tol)
+        eng.set_correction_policy("all")
+        lam_all, _, iters_all = eng.solve(case["method"], case["max_it"], tol)
+    assert np.abs(lam - arrays[f"{name}__evals"]).max() < EV_TOL
+    assert (residuals(A, None, lam, vec) < tol).all()
+    assert np.abs(vec.T @ vec - np.eye(L)).max() < 1e-7          # locked vectors are Ritz vectors of different bases: orthogonal to ~tol
+    lam_o, _, it_o = O.generalized_eigensolver_dense_locking(A, L, case["method"], case["max_it"], tol, case["max_dim"])
+    assert iters == it_o, (iters, it_o)
+    assert np.abs(lam - lam_o).max() < EV_TOL
+    assert iters_all == case["iters"] and np.abs(lam_all - arrays[f"{name}__evals"]).max() < EV_TOL
+
+
+@pytest.mark.parametrize("nranks,storage", [(1, "symmetric"), (3, "full"), (3, "symmetric")])
+def test_locking_policy_through_restarts_on_one_and_three_ranks(nranks, storage):
+    """A problem that locks its pairs at three different iterations and collapses the active basis on the way (lowest = 8,
+    max_dim_sub = 28, a clustered and a spread part of the spectrum), on one rank and on three (loopback transport, both
+    storages): the oracle's iteration count, its eigenvalues."""
+    n, L, sp, md = 1500, 8, 3e-2, 28
+    A = O.generate_diagonal_dominant(n, sp, seed=4)
+    d = np.arange(1, n + 1, dtype=float) + 2.0
+    d[:8] = [1.0, 1.08, 1.16, 2.5, 4.0, 4.1, 7.0, 9.5]          # a cluster and well separated values: the pairs converge at different times
+    A[np.arange(n), np.arange(n)] = d
+    tr = O.Trace()
+    lam_o, _, it_o = O.generalized_eigensolver_dense_locking(A, L, "DPR", 300, 1e-8, md, trace=tr)
+    assert it_o < 300 and len(set(len(e) for e in tr.errors)) > 2          # pairs were locked at different iterations
+    engs = [fd.DavidsonEngine(n, L, md, rank=r, nranks=nranks, storage=storage) for r in range(nranks)]
+    if nranks > 1:
+        handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+        assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            engs[r].set_correction_policy("locking")
+            engs[r].set_dense(1, A)
+            out[r] = engs[r].solve("DPR", 300, 1e-8)
+        except Exception as exc:      # noqa: BLE001
+            err[r] = exc
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in threads]
+    [t.join(timeout=300) for t in threads]
+    for e in engs:
+        e.close()
+    assert all(x is None for x in err), err
+    for lam, vec, iters in out:
+        assert iters == it_o, (iters, it_o)
+        assert np.abs(lam - lam_o).max() < EV_TOL
+        assert (residuals(A, None, lam, vec) < 1e-8).all()
+        assert (np.diff(lam) > 0).all()
+
+
+def test_locking_policy_refuses_generalized_problems():
+    import subprocess
+    import sys
+    code = ("import fortran_davidson_amd as fd\n"
+            "e = fd.DavidsonEngine(300, 3, gev=True)\n"
+            "e.generate_diagonal_dominant(1, 1e-3, seed=1); e.generate_diagonal_dominant(2, 1e-3, 1.0, seed=2)\n"
+            "e.set_correction_policy('locking'); e.solve('DPR', 50, 1e-8)\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, PYTHONPATH=root))
+    assert res.returncode != 0 and "standard problems" in (res.stdout + res.stderr)
 
 
 def test_policy_through_the_environment_reaches_the_dense_and_free_front_ends(monkeypatch):
