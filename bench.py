@@ -903,12 +903,12 @@ def main():
                             f = ln.split()
                             secs = [float(x) for x in f[f.index("seconds=") + 1:f.index("seconds=") + 4]]
                             evs = [float(x) for x in f[f.index("eigenvalues=") + 1:f.index("eigenvalues=") + 4]]
-                            out = {"first_call_seconds": round(secs[0], 4), "seconds": round(min(secs[1:]), 4), "iters": int(f[3].split("=")[1]),
-                                   "iterations_per_s": round(int(f[3].split("=")[1]) / min(secs[1:]), 2), "eigenvalues": evs}
+                            out.update({"first_call_seconds": round(secs[0], 4), "seconds": round(min(secs[1:]), 4), "iters": int(f[3].split("=")[1]),
+                                        "iterations_per_s": round(int(f[3].split("=")[1]) / min(secs[1:]), 2), "eigenvalues": evs})
                         if "davidson dense call:" in ln:
                             out["symmetric_tiles"] = "symmetric tiles=T" in ln
                             out["phases_ms_create_upload_solve_destroy"] = [float(x) for x in ln.split("]=")[1].split()]
-                    if not out:
+                    if "seconds" not in out:
                         raise RuntimeError((res.stdout + res.stderr)[-300:])
                     return out
                 try:
