@@ -775,7 +775,8 @@ def main():
                         "seconds": round(dt_m, 4), "iters": it_m, "sweeps_of_A": int(sm_.applies),
                         "ms_per_sweep_of_A_end_to_end": round(sm_.apply_ms / max(sm_.applies, 1), 3),
                         "max_abs_eigenvalue_diff_vs_fp64_inner": float(np.abs(lam_m - lam_g).max()),
-                        "note": "engine_set_inner_precision(eng, 32): inner MINRES sweeps of A of up to 16 columns (the byte-bound ones) on fp32 tiles (fp64 accumulation); not the default"}
+                        "note": "engine_set_inner_precision(eng, 32): inner MINRES sweeps of A of up to 16 columns on fp32 tiles (fp64 accumulation); kept as an option for orders where "
+                                "the fp32 copy fits next to B's resident tiles - at N=200000 it competes with them for the same memory and buys nothing (DESIGN section 11); not the default"}
                 except Exception as exc:   # noqa: BLE001  (e.g. no room for the fp32 copy)
                     extras["configs3_gjd"]["inner_fp32"] = {"error": repr(exc)[:300]}
                 g.close()

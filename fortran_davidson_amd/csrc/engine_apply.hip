@@ -152,7 +152,7 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     // partial of the whole product of this chunk (the buffer of this parity was last read by the reduce-scatter of chunk
     // i - 2, whose completion the main stream waited for when it finished chunk i - 2 below)
     for (int g = 0; g < npair; ++g)
-      launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, e->sym.row_off, R,
+      launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, e->sym.row_off, pl->next_owned, R,
                          e->sym_nb, e->nloc, std::min(16, kk - 16 * g), e->sym_wpart2[p] + (size_t)g * (size_t)total_rows * 16, e->ldp,
                          e->nslab, total_rows);
     HIPCHK(hipEventRecord(e->ov_reduced[p], e->stream));
@@ -284,7 +284,7 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
         const int kg = std::min(16, kk - 16 * g);
         double* out = multi ? e->sym_wpart + (size_t)g * (size_t)total_rows * 16 : dst + (int64_t)(c + 16 * g) * e->ldp;
         if (R > 1)
-          launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, owned, R, e->sym_nb,
+          launch_sym9_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, pl->row_begin, pl->zslot_begin, owned, pl->next_owned, R, e->sym_nb,
                              e->nloc, kg, out, e->ldp, multi ? e->nslab : 0, total_rows, accumulate && !multi);
         else
           launch_sym_reduce(e->stream, e->sym_slab + g * dstride, slabT + g * tstride, set.row_begin, owned, e->sym_nb, e->nloc, kg,

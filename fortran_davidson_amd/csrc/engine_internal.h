@@ -79,6 +79,7 @@ struct SymPlan {
   int* items = nullptr;             // device: (super row, J0, J1, slab slot) per item, longest first
   int* row_begin = nullptr;         // device: first item of each super row (nsuper + 1)
   int* zslot_begin = nullptr;       // device: first slot of each super row (nsuper + 1)
+  int* next_owned = nullptr;        // device: smallest super row >= S of this set (nsuper + 1; nsuper = none): the reduction walks only those
 };
 // Work lists of the symmetric sweep over a SET of block rows: all block rows of this rank (dav_engine::sym), or - for a
 // generated operator that is kept partly resident (OpDesc::res / gen) - the stored and the generated ones.  Several ranks: the

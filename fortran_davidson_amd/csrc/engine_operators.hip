@@ -66,7 +66,7 @@ std::vector<int> sym_group_owners(int nb, int nranks) {
 
 void sym_set_release(SymSet& s) {
   hipFree(s.row_off); hipFree(s.items); hipFree(s.row_begin);
-  for (SymPlan& pl : s.plan) { hipFree(pl.items); hipFree(pl.row_begin); hipFree(pl.zslot_begin); }
+  for (SymPlan& pl : s.plan) { hipFree(pl.items); hipFree(pl.row_begin); hipFree(pl.zslot_begin); hipFree(pl.next_owned); }
   s = SymSet();
 }
 
@@ -154,6 +154,11 @@ int sym_build_set(E* e, int first, int end, SymSet& out) {
     HIPCHK(hipMemcpy(pl.items, pitems.data(), sizeof(int) * pitems.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pl.row_begin, prow.data(), sizeof(int) * prow.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pl.zslot_begin, zbeg.data(), sizeof(int) * zbeg.size(), hipMemcpyHostToDevice));
+    // the super rows of this set, as a skip list for the fixed-order reduction (several ranks: 7 of 8 super rows are another rank's)
+    std::vector<int> nxt(pl.nsuper + 1, pl.nsuper);
+    for (int S = pl.nsuper - 1; S >= 0; --S) nxt[S] = owned(S * pl.R) ? S : nxt[S + 1];
+    HIPCHK(hipMalloc(&pl.next_owned, sizeof(int) * nxt.size()));
+    HIPCHK(hipMemcpy(pl.next_owned, nxt.data(), sizeof(int) * nxt.size(), hipMemcpyHostToDevice));
   }
   out.built = true;
   return 0;

@@ -400,24 +400,36 @@ void launch_tiles_to_f32(hipStream_t st, const double* src, float* dst, int64_t 
 // layout of the reduce-scatter that follows, [rank p][column][row of p's slab] (chunk_rows = nslab).
 __global__ __launch_bounds__(256) void sym9_reduce_kernel(const double* __restrict__ slabD, const double* __restrict__ slabT,
                                                           const int* __restrict__ row_item_begin, const int* __restrict__ zslot_begin,
-                                                          const int64_t* __restrict__ owned, int R, int nb, int nsuper, int64_t nloc,
-                                                          int k, double* __restrict__ dst, int64_t ldd, int64_t chunk_rows,
-                                                          int64_t total_rows, int accumulate) {
+                                                          const int64_t* __restrict__ owned, const int* __restrict__ next_owned, int R, int nb,
+                                                          int nsuper, int64_t nloc, int k, double* __restrict__ dst, int64_t ldd,
+                                                          int64_t chunk_rows, int64_t total_rows, int accumulate) {
   const int J = blockIdx.x, col = blockIdx.y, r = threadIdx.x;
   if (col >= k) return;
   double sum = 0.0;
   const int Sown = J / R, sub = J % R;
   for (int it = row_item_begin[Sown]; it < row_item_begin[Sown + 1]; ++it)
     sum += slabD[(((int64_t)it * R + sub) * 16 + col) * SYM_TB + r];
-  auto zt = [&](int S) {
-    return (!owned || owned[S * R] >= 0) ? slabT[(((int64_t)zslot_begin[S] + J) * 16 + col) * SYM_TB + r] : 0.0;
-  };
+  auto zt = [&](int S) { return slabT[(((int64_t)zslot_begin[S] + J) * 16 + col) * SYM_TB + r]; };
   // super row S holds a partial for tile column J iff its last existing block row lies below J
-  int S = (J + 1) / R;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   const int Send = (nb - 1 > J) ? nsuper : 0;       // the last super row is clamped to nb - 1
-  for (; S + 3 < Send; S += 4) { s0 += zt(S); s1 += zt(S + 1); s2 += zt(S + 2); s3 += zt(S + 3); }
-  for (; S < Send; ++S) s0 += zt(S);
+  if (!owned) {
+    int S = (J + 1) / R;
+    for (; S + 3 < Send; S += 4) { s0 += zt(S); s1 += zt(S + 1); s2 += zt(S + 2); s3 += zt(S + 3); }
+    for (; S < Send; ++S) s0 += zt(S);
+  } else {
+    // only the super rows of this set (several ranks / a part of an operator), in ascending order, four interleaved partial sums
+    int S = (J + 1) / R < nsuper ? next_owned[(J + 1) / R] : nsuper;
+    while (S < Send) {
+      s0 += zt(S); S = next_owned[S + 1];
+      if (S >= Send) break;
+      s1 += zt(S); S = next_owned[S + 1];
+      if (S >= Send) break;
+      s2 += zt(S); S = next_owned[S + 1];
+      if (S >= Send) break;
+      s3 += zt(S); S = next_owned[S + 1];
+    }
+  }
   sum += (s0 + s1) + (s2 + s3);
   const int64_t row = (int64_t)J * SYM_TB + r;
   if (chunk_rows > 0) {
@@ -428,9 +440,9 @@ __global__ __launch_bounds__(256) void sym9_reduce_kernel(const double* __restri
 }
 
 void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,
-                        const int* zslot_begin_dev, const int64_t* owned, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd,
-                        int64_t chunk_rows, int64_t total_rows, bool accumulate) {
+                        const int* zslot_begin_dev, const int64_t* owned, const int* next_owned, int R, int nb, int64_t nloc, int k, double* dst,
+                        int64_t ldd, int64_t chunk_rows, int64_t total_rows, bool accumulate) {
   const int nsuper = (nb + R - 1) / R;
-  hipLaunchKernelGGL(sym9_reduce_kernel, dim3(nb, k), dim3(256), 0, st, slabD, slabT, row_item_begin_dev, zslot_begin_dev, owned, R,
+  hipLaunchKernelGGL(sym9_reduce_kernel, dim3(nb, k), dim3(256), 0, st, slabD, slabT, row_item_begin_dev, zslot_begin_dev, owned, next_owned, R,
                      nb, nsuper, nloc, k, dst, ldd, chunk_rows, total_rows, accumulate && chunk_rows == 0 ? 1 : 0);
 }

@@ -149,8 +149,8 @@ void launch_matvec_symw_generated(hipStream_t st, OpParams op, int64_t n, int nb
 // fp32 copy of `count` stored tile entries (count a multiple of 4)
 void launch_tiles_to_f32(hipStream_t st, const double* src, float* dst, int64_t count);
 void launch_sym9_reduce(hipStream_t st, const double* slabD, const double* slabT, const int* row_item_begin_dev,
-                        const int* zslot_begin_dev, const int64_t* owned, int R, int nb, int64_t nloc, int k, double* dst, int64_t ldd,
-                        int64_t chunk_rows, int64_t total_rows, bool accumulate = false);
+                        const int* zslot_begin_dev, const int64_t* owned, const int* next_owned, int R, int nb, int64_t nloc, int k, double* dst,
+                        int64_t ldd, int64_t chunk_rows, int64_t total_rows, bool accumulate = false);
 void launch_generate_sym_tiles(hipStream_t st, double* tiles, const int64_t* row_off_host, int nb, int64_t n, uint64_t seed,
                                double sparsity, int use_diag, double diag_val);
 void launch_retile_panel(hipStream_t st, const double* panel, int64_t ldp, int64_t nrows, int ncols, int J, int nb,
