@@ -70,7 +70,7 @@ def test_bench_single_gpu_default_shape_of_the_line():
                          "--free-n", "6000", "--harness-n", "6000", "--harness-n2", "9000", "--no-cpu-baseline"])
     assert line["config"]["storage"] == "symmetric" and line["config"]["N"] == 8000
     assert len(line["config"]["workload"]) < 120 and "sparsity" in line["config"]["workload"] and "storage=symmetric" in line["config"]["workload"]
-    for key in ("roofline", "apply", "configs3_gjd", "configs4_free", "benchmark_free", "small", "dropin", "opt_in_policy", "scaling_model"):
+    for key in ("roofline", "apply", "configs3_gjd", "configs4_free", "configs4_free_harness", "small", "dropin", "opt_in_policy", "scaling_model"):
         assert key in line and "error" not in line[key], (key, line.get(key))
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["launches"] > 0
@@ -78,7 +78,7 @@ def test_bench_single_gpu_default_shape_of_the_line():
     head = list(r)[:20]
     assert all(k in head for k in ("frac", "traffic", "hbm_N", "hbm_k", "hbm_frac", "hbm_traffic", "non_kernel_ms_per_solve", "hbm_algorithmic_bytes"))
     assert all(len(v) < 120 for v in r.values() if isinstance(v, str))
-    bf = line["benchmark_free"]
+    bf = line["configs4_free_harness"]
     assert bf["reference_configuration"]["iters_per_solve"] >= 2 and abs(bf["reference_configuration"]["eigenvalues"][0] - 1.0000992) < 1e-6
     assert 0 < bf["roofline"]["frac"] < 1.2 and bf["large"]["iters"] > 0 and bf["sweep_at_configs4_order"]["ms"] > 0
     assert line["scaling_model"]["P8"]["symmetric_all_links_ms"] <= line["scaling_model"]["P8"]["symmetric_ms"]
