@@ -206,6 +206,7 @@ Tune tune_from_env() {
   t.mv_target = std::max(0, geti("DAV_MV_TARGET", 0));
   t.mv_nsplit = std::max(0, geti("DAV_MV_NSPLIT", 0));
   t.b_resident = geti("DAV_B_RESIDENT", t.b_resident);
+  t.coll_direct = geti("DAV_COLL_DIRECT", t.coll_direct);
   t.pg_pin = geti("DAV_PG_PIN", t.pg_pin);
   t.gram_wgs = geti("DAV_GRAM_WGS", t.gram_wgs);
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
@@ -333,6 +334,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   }
   sym_set_release(e->sym);
   hipFree(e->sym_wpart);
+  hipFree(e->coll_stage);
   hipFree(e->sym_wrecv);
   for (int i = 0; i < N_SMALL; ++i)
     if (e->sm[i].done) hipEventDestroy(e->sm[i].done);

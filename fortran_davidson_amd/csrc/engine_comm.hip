@@ -19,6 +19,8 @@ int rccl_load() {
   SYM(AllReduce, "ncclAllReduce")
   SYM(Broadcast, "ncclBroadcast")
   SYM(ReduceScatter, "ncclReduceScatter")
+  SYM(Send, "ncclSend")
+  SYM(Recv, "ncclRecv")
   SYM(GroupStart, "ncclGroupStart")
   SYM(GroupEnd, "ncclGroupEnd")
   SYM(GetErrorString, "ncclGetErrorString")
@@ -445,7 +447,21 @@ int coll_allgather(E* e, const double* send, double* recv, size_t count) {
     CHK(test_allgather(e, send, recv, count));
     return timed_end(e, slot);
   }
-  NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
+  if (e->tune.coll_direct) {
+    // opt-in (DAV_COLL_DIRECT=1): a direct exchange - this rank's slab to each of its P - 1 peers, theirs into place - so that the
+    // P - 1 point-to-point links of the xGMI mesh carry the all-gather at once, whatever schedule RCCL would pick for ncclAllGather
+    NCCLCHK(g_rccl.GroupStart());
+    for (int p = 0; p < e->nranks; ++p) {
+      if (p == e->rank) continue;
+      NCCLCHK(g_rccl.Send(send, count, ncclDouble, p, e->comm, e->stream));
+      NCCLCHK(g_rccl.Recv(recv + (size_t)p * count, count, ncclDouble, p, e->comm, e->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    if (recv + (size_t)e->rank * count != send)
+      HIPCHK(hipMemcpyAsync(recv + (size_t)e->rank * count, send, sizeof(double) * count, hipMemcpyDeviceToDevice, e->stream));
+  } else {
+    NCCLCHK(g_rccl.AllGather(send, recv, count, ncclDouble, e->comm, e->stream));
+  }
   CHK(timed_end(e, slot));
   return watch_mark(e, "all-gather", e->stream);
 }
@@ -471,7 +487,34 @@ int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
     CHK(test_reduce_scatter(e, send, recv, count));
     return timed_end(e, slot);
   }
-  NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
+  if (e->tune.coll_direct) {
+    // opt-in (DAV_COLL_DIRECT=1): chunk p of this rank's contribution goes straight to rank p, the peers' chunks for this rank arrive
+    // in a staging buffer, and a fixed-order sum (rank order) leaves the result - the same volume as the ring, over all links at once.
+    // Inside a CollGroup the exchanges of its members are one NCCL group (they run when the group ends); every member has its own
+    // part of the staging buffer, so the sums can be enqueued behind the group... which they are NOT here: a sum needs the data
+    // the group has not moved yet.  Hence a direct reduce-scatter closes the NCCL group around itself (group_depth says whether one is open).
+    const size_t need = (size_t)std::max(e->nranks - 1, 1) * count;
+    if (need > e->coll_stage_doubles) {
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (e->coll_stage) HIPCHK(hipFree(e->coll_stage));
+      e->coll_stage = nullptr; e->coll_stage_doubles = 0;
+      HIPCHK(hipMalloc(&e->coll_stage, sizeof(double) * need));
+      e->coll_stage_doubles = need;
+    }
+    const bool reopen = e->group_depth > 0;
+    if (reopen) { NCCLCHK(g_rccl.GroupEnd()); }                 // what the open group holds so far goes out now
+    NCCLCHK(g_rccl.GroupStart());
+    for (int p = 0; p < e->nranks; ++p) {
+      if (p == e->rank) continue;
+      NCCLCHK(g_rccl.Send(send + (size_t)p * count, count, ncclDouble, p, e->comm, e->stream));
+      NCCLCHK(g_rccl.Recv(e->coll_stage + (size_t)(p < e->rank ? p : p - 1) * count, count, ncclDouble, p, e->comm, e->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    launch_sum_parts(e->stream, send + (size_t)e->rank * count, e->coll_stage, e->nranks, e->rank, count, recv);
+    if (reopen) { NCCLCHK(g_rccl.GroupStart()); }
+  } else {
+    NCCLCHK(g_rccl.ReduceScatter(send, recv, count, ncclDouble, ncclSum, e->comm, e->stream));
+  }
   CHK(timed_end(e, slot));
   return watch_mark(e, "reduce-scatter", e->stream);
 }

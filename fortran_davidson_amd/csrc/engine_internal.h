@@ -55,6 +55,8 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -149,6 +151,7 @@ struct Tune {
   int64_t mv_nsplit = 0;
   int gram_wgs = 0;       // DAV_GRAM_WGS: workgroups the Gram kernel's grid aims at (0 = default)
   int pg_pin = 1;         // DAV_PG_PIN: the panel kernel's k loop in the pinned order (1) or the compiler's (0) (A/B runs)
+  int coll_direct = 0;    // DAV_COLL_DIRECT=1: all-gather / reduce-scatter as direct exchanges (grouped send / receive to every peer) instead of RCCL's collectives (opt-in)
   int b_resident = 1;     // DAV_B_RESIDENT: keep what fits of a generated second operator resident as stored tiles (dav_set_operator_hashed, storage 1)
   bool gjd_trace = false; // DAV_GJD_TRACE
 };
@@ -196,7 +199,9 @@ struct dav_engine {
   // nest in), longest group first to the least loaded rank (sym_group_owners).  row_off[I] = first tile of block row I
   // in this rank's storage, -1 = another rank's.
   double* sym_wpart = nullptr;    // several ranks: this rank's partial of the whole product, [rank][column][row of its slab]
-  double* sym_wrecv = nullptr;    // ... and the summed chunk the reduce-scatter hands back (nslab x 32)
+  double* sym_wrecv = nullptr;    // ... and the summed chunk the reduce-scatter hands back (nslab x 64)
+  double* coll_stage = nullptr;   // DAV_COLL_DIRECT: the peers' chunks of a direct reduce-scatter before the fixed-order sum (grown on demand)
+  size_t coll_stage_doubles = 0;
   // RCCL only: a second stream for the collectives of the symmetric sweep, so that the all-gather of the NEXT 32 columns
   // and the reduce-scatter of the PREVIOUS ones run under the sweep of the current ones; buffers alternate by chunk parity
   Watchdog* wd = nullptr;         // watches the RCCL collectives of this engine (dav_comm_init)

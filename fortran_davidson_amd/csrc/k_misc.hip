@@ -208,3 +208,17 @@ __global__ __launch_bounds__(512) void harness_rate_kernel(double* __restrict__ 
 void launch_harness_rate(hipStream_t st, double* out, int wgs, int iters) {
   hipLaunchKernelGGL(harness_rate_kernel, dim3(wgs), dim3(512), 0, st, out, iters, 1.0, 1e-7);
 }
+
+// Fixed-order sum of the chunks of a direct reduce-scatter (DAV_COLL_DIRECT): rank order, the rank's own chunk read where it lies.
+__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ own, const double* __restrict__ stage, int nparts, int self,
+                                                        size_t count, double* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += p == self ? own[i] : stage[(size_t)(p < self ? p : p - 1) * count + i];
+    out[i] = s;
+  }
+}
+void launch_sum_parts(hipStream_t st, const double* own, const double* stage, int nparts, int self, size_t count, double* out) {
+  const unsigned grid = (unsigned)std::min<size_t>(4096, (count + 255) / 256);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, own, stage, nparts, self, count, out);
+}

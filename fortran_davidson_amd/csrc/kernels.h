@@ -95,6 +95,8 @@ void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double*
 // stream microbenchmark over n doubles (n even): mode 0: a = b, mode 1: a = b + s c
 void launch_stream(hipStream_t st, int mode, double* a, const double* b, const double* c, double s, int64_t n);
 void launch_harness_rate(hipStream_t st, double* out, int wgs, int iters);
+// out[i] = sum over p = 0 .. nparts-1 of part_p[i] in that order; part_p = own for p == self, stage + slot(p) * count otherwise (slot = p, minus one behind self)
+void launch_sum_parts(hipStream_t st, const double* own, const double* stage, int nparts, int self, size_t count, double* out);
 
 
 

@@ -719,6 +719,33 @@ def test_ranks_that_disagree_on_a_control_decision_stop_with_a_message():
     assert all("ranks disagree" in o for o in out), out
 
 
+def test_control_words_ride_on_the_next_all_reduced_result():
+    """dav_agree_next (round 5): the driver's control words wait in the engine and ride on the next all-reduced small result - no
+    collective of their own (the count shows it); identical words pass, different words fail the fetch ON EVERY RANK."""
+    nranks, n = 3, 700
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n, 8))
+
+    def work(r, e):
+        e.panel_put(PANEL_V, 0, X)
+        e.reset_stats()
+        e.agree_next([2.0, 16.0, 1.0, 1e-8])
+        G = e.gram(PANEL_V, 0, 8, PANEL_V, 0, 8)                 # the words travel with this result
+        assert relerr(G, X.T @ X) < 1e-12
+        assert e.stats().collectives == 1
+        G2 = e.gram(PANEL_V, 0, 8, PANEL_V, 0, 8)                # nothing pending: a plain fetch
+        assert np.array_equal(G, G2) and e.stats().collectives == 2
+        e.agree_next([2.0, 16.0, 1.0 if r != 1 else 0.0, 1e-8])
+        try:
+            e.gram(PANEL_V, 0, 8, PANEL_V, 0, 8)
+        except fd.DavidsonHipError as exc:
+            return str(exc)
+        return "no error"
+
+    out = _run_ranks(nranks, lambda r: fd.CEngine(n=n, max_cols=16, rank=r, nranks=nranks), work)
+    assert all("ranks disagree" in o for o in out), out
+
+
 def test_symmetric_sweep_with_collectives_overlapped_on_a_second_stream():
     """RCCL path of the multi-rank symmetric sweep for blocks wider than 32 columns with DAV_SYM_OVERLAP=1 (opt-in): the
     all-gather of the next 32 columns and the reduce-scatter of the previous ones run on a second stream under the sweep of

@@ -254,12 +254,14 @@ def test_against_oracle_on_fresh_inputs():
         assert (residuals(A, None, lam, vec) < 1e-8).all()
 
 
-@pytest.mark.parametrize("storage", ["full", "symmetric"])
-def test_sharded_code_path_through_rccl_single_rank(golden, monkeypatch, storage):
+@pytest.mark.parametrize("storage,direct", [("full", "0"), ("symmetric", "0"), ("symmetric", "1")])
+def test_sharded_code_path_through_rccl_single_rank(golden, monkeypatch, storage, direct):
     """DAVIDSON_FORCE_RCCL=1: a 1-rank RCCL communicator, so the all-gather of the packed basis block,
     the all-reduces of Gram blocks / norms, the gathered panel download and - symmetric storage - the reduce-scatter
-    of the partial products all run through RCCL."""
+    of the partial products all run through RCCL.  direct = 1 (DAV_COLL_DIRECT, opt-in): the all-gather and the reduce-scatter as
+    grouped send / receive exchanges with a fixed-order local sum - with one rank that is the plumbing only (no peer to talk to)."""
     monkeypatch.setenv("DAVIDSON_FORCE_RCCL", "1")
+    monkeypatch.setenv("DAV_COLL_DIRECT", direct)
     manifest, arrays = golden
     for name in ("n2000_std_dpr", "n1000_gev_restart_dpr"):
         case = manifest["dense"][name]
