@@ -402,6 +402,14 @@ def main():
     # that runs this whole multi-process flow on a single-GPU box (tests/test_bench_multiprocess_gpu.py).
     # The multi-GPU data path is RCCL, one GPU per rank.
     transport = os.environ.get("DAVIDSON_TRANSPORT", "rccl")
+    if transport == "rccl-one-gpu":
+        # Rehearsal of the REAL RCCL path on a one-GPU box (tests/test_rccl_one_gpu.py): every rank uses GPU 0 and poses as a host of
+        # its own (NCCL_HOSTID), so RCCL builds a genuine multi-rank communicator - its all-gather / reduce-scatter / all-reduce /
+        # send / receive kernels and proxy threads, over the loopback socket transport instead of xGMI.  Everything above the wire
+        # is what a multi-GPU run executes; the times mean nothing.
+        os.environ["NCCL_HOSTID"] = f"davidson-rehearsal-host-{rank}"
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     device = local_rank if transport == "rccl" else 0
     torch.cuda.set_device(device)
 

@@ -1,0 +1,130 @@
+"""The REAL RCCL path with more than one rank - on the one GPU of the test box.  Every rank is a process on GPU 0 that poses as a
+host of its own (NCCL_HOSTID), so RCCL builds a genuine multi-rank communicator and moves the data through its loopback socket
+transport (bench.py: DAVIDSON_TRANSPORT=rccl-one-gpu).  Everything above the wire is what a multi-GPU run executes: ncclCommInitRank
+with the broadcast id, grouped in-place all-gathers, reduce-scatters, all-reduces, the watchdog's events, the opt-in second-stream
+pipeline and the opt-in direct exchanges (ncclSend / ncclRecv) - none of which the loopback / shared-memory test transports or the
+1-rank communicator reach.  Launched exactly as the driver launches bench.py for N > 1."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_bench(nproc, extra, env_extra=None, expect_ok=True, timeout=600):
+    env = dict(os.environ, DAVIDSON_TRANSPORT="rccl-one-gpu", DAVIDSON_COLLECTIVE_TIMEOUT="120", **(env_extra or {}))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if nproc == 1:
+        env["DAVIDSON_TRANSPORT"] = "rccl"
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    if not expect_ok:
+        return res
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+HEAD = ["--steps", "2", "--warmup", "1", "--order", "6000", "--headline-only"]
+
+
+@pytest.mark.parametrize("nproc,storage", [(2, "symmetric"), (2, "full"), (3, "symmetric"), (4, "symmetric")])
+def test_real_rccl_communicator_of_several_ranks_matches_one_rank(nproc, storage):
+    one = run_bench(1, HEAD + ["--storage", storage])
+    many = run_bench(nproc, HEAD + ["--storage", storage])
+    c = many["comm"]
+    assert many["n_gpus"] == nproc and c["transport"] == "rccl-one-gpu" and c["ranks_reported_by_rccl"] == nproc
+    assert many["config"]["iters_per_solve"] == one["config"]["iters_per_solve"]
+    assert np.abs(np.array(many["eigenvalues"]) - np.array(one["eigenvalues"])).max() < 1e-10
+    assert c["collectives_per_solve"] > 0 and c["allgather_ms_per_solve"] > 0 and c["allreduce_ms_per_solve"] > 0
+    if storage == "symmetric":
+        assert c["reduce_scatter_ms_per_solve"] > 0
+
+
+def test_wide_blocks_in_program_order_on_a_second_stream_and_as_direct_exchanges():
+    """lowest = 16 makes the 64-column expansion (two-block-row schedule forced at this small order).  Three ways to move its
+    collectives over a real 2- and 3-rank communicator: in program order on the engine's stream (the default: one all-gather, one
+    64-column launch, one reduce-scatter), on a second stream under the sweeps of the 32-column chunks (DAV_SYM_OVERLAP=1: the
+    pipeline had only ever run over a 1-rank communicator), and as direct exchanges (DAV_COLL_DIRECT=1: grouped ncclSend / ncclRecv
+    and a fixed-order local sum).  Same iteration count as one rank, eigenvalues to 1e-10."""
+    extra = ["--steps", "1", "--warmup", "1", "--order", "6000", "--lowest", "16", "--storage", "symmetric", "--headline-only"]
+    one = run_bench(1, extra, {"DAV_SYM_R": "2"})
+    for nproc in (2, 3):
+        lams = {}
+        for name, env in (("program order", {}), ("second stream", {"DAV_SYM_OVERLAP": "1"}), ("direct exchange", {"DAV_COLL_DIRECT": "1"})):
+            many = run_bench(nproc, extra, dict(env, DAV_SYM_R="2"))
+            assert many["comm"]["ranks_reported_by_rccl"] == nproc, name
+            assert many["comm"]["collectives_overlapped_with_sweeps"] == (name == "second stream"), name
+            assert many["config"]["iters_per_solve"] == one["config"]["iters_per_solve"], name
+            assert np.abs(np.array(many["eigenvalues"]) - np.array(one["eigenvalues"])).max() < 1e-10, name
+            lams[name] = many["eigenvalues"]
+        # the pipeline changes the order of launches, not a single sum (same ring reductions): the same bits as program order
+        assert lams["second stream"] == lams["program order"]
+
+
+def test_matrix_free_and_generalized_legs_over_a_real_communicator():
+    """The other legs of the bench over a real 2-rank communicator at small orders: configs[1] shape (row slabs), configs[3] shape
+    (generalized, GJD, the generated second operator partly resident: its passes agreed on by an all-reduce), configs[4] shape
+    (matrix-free, symmetric generation)."""
+    extra = ["--steps", "1", "--warmup", "1", "--order", "6000", "--storage", "symmetric", "--small-n", "3000", "--gjd-n", "2000", "--free-n", "4000",
+             "--restart-sparsity", "0", "--harness-n", "0", "--no-cpu-baseline", "--no-dropin"]
+    one, two = run_bench(1, extra), run_bench(2, extra)
+    for key in ("small", "configs3_gjd", "configs4_free"):
+        a, b = one[key], two[key]
+        assert "error" not in a and "error" not in b, (key, a, b)
+        assert np.abs(np.array(a["eigenvalues"]) - np.array(b["eigenvalues"])).max() < 1e-8, key
+    assert two["small"]["iters_per_solve"] == one["small"]["iters_per_solve"] and two["configs4_free"]["iters"] == one["configs4_free"]["iters"]
+
+
+def test_a_rank_that_dies_inside_a_real_communicator_ends_the_launch_within_the_bound():
+    """One rank of two ends abruptly in the middle of a long run (tests/rank_killer.py: a timer in rank 1): its peer must not wait
+    in an RCCL collective for ever - the engine's watchdog (DAVIDSON_COLLECTIVE_TIMEOUT) or the launcher ends it, and the launch
+    returns a non-zero code well inside the bound."""
+    env = dict(os.environ, DAVIDSON_TRANSPORT="rccl-one-gpu", DAVIDSON_COLLECTIVE_TIMEOUT="20")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.time()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "rank_killer.py"), "1", "40", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1000000",
+           "--warmup", "1", "--order", "6000", "--headline-only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert res.returncode != 0
+    assert time.time() - t0 < 300
+
+
+def test_configs2_at_full_order_over_a_real_four_rank_communicator():
+    """configs[2] at N=200000 on FOUR ranks of a real RCCL communicator (four processes sharing the one GPU: 40 GB of tiles each; the
+    box allows six processes on a card, so eight ranks run as threads over the loopback transport instead - tests/test_full_size_gpu.py):
+    the iteration count and the eigenvalues of the one-rank run, 11 collectives per solve, 153.6 MB gathered and 204.8 MB
+    reduce-scattered per rank and solve through RCCL itself."""
+    line = run_bench(4, ["--steps", "1", "--warmup", "1", "--headline-only"], timeout=900)
+    c = line["comm"]
+    assert line["n_gpus"] == 4 and c["ranks_reported_by_rccl"] == 4 and line["config"]["N"] == 200000 and line["config"]["storage"] == "symmetric"
+    assert line["config"]["iters_per_solve"] == 3
+    assert np.abs(np.array(line["eigenvalues"]) - np.array([0.9999951655277628, 1.9999960491572697, 2.9999969540010114])).max() < 1e-10
+    assert c["collectives_per_solve"] == 11
+    assert abs(c["allgather_MB_per_solve"] - 153.6) < 1.0 and abs(c["reduce_scatter_MB_per_solve"] - 204.8) < 1.0
+    try:                                                  # kept for profiles/experiments/ (gpurun_out/ travels back from the GPU box)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r05_rccl_one_gpu_4ranks_n200000.json"), "w") as f:
+            json.dump({"note": "bench.py --gpus 4 --headline-only at N=200000 over a REAL 4-rank RCCL communicator whose ranks share one GPU (loopback "
+                               "socket transport: the times are of that transport and of four processes time-slicing one device)",
+                       "value": line["value"], "iters_per_solve": line["config"]["iters_per_solve"], "eigenvalues": line["eigenvalues"], "comm": c}, f, indent=1)
+    except OSError:
+        pass
