@@ -962,10 +962,7 @@ contains
             do jj = 1, keep_a
                z(nlock + 1:m, col + jj) = ya(:, rest(jj))
             end do
-            if (grow .and. keep == m .and. kt > 0) then
-               ! the correction block sits behind column m and stays there
-               continue
-            end if
+            ! (a growing iteration keeps every active Ritz vector, keep = m: the correction block behind column m stays where it is)
             call check_dav(dav_restart(h, int(m, c_int), int(keep, c_int), z, int(m, c_int64_t)), "dav_restart")
             hm(1:keep, 1:keep) = lapack_matmul("T", "N", z, lapack_matmul("N", "N", hm(1:m, 1:m), z))
             if (keep < m) hm(keep + 1:m, :) = 0.0_dp

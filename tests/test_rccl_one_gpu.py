@@ -27,6 +27,9 @@ def free_port():
 def run_bench(nproc, extra, env_extra=None, expect_ok=True, timeout=600):
     env = dict(os.environ, DAVIDSON_TRANSPORT="rccl-one-gpu", DAVIDSON_COLLECTIVE_TIMEOUT="120", **(env_extra or {}))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the PRODUCT library (no test transport is involved): not the test build tests/conftest.py points this process at
+    env.pop("DAVIDSON_HIP_LIB", None)
+    env["LD_LIBRARY_PATH"] = ":".join(p for p in env.get("LD_LIBRARY_PATH", "").split(":") if p and not p.endswith(os.path.join("lib", "test")))
     if nproc == 1:
         env["DAVIDSON_TRANSPORT"] = "rccl"
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
@@ -99,6 +102,7 @@ def test_a_rank_that_dies_inside_a_real_communicator_ends_the_launch_within_the_
     returns a non-zero code well inside the bound."""
     env = dict(os.environ, DAVIDSON_TRANSPORT="rccl-one-gpu", DAVIDSON_COLLECTIVE_TIMEOUT="20")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("DAVIDSON_HIP_LIB", None)
     t0 = time.time()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "rank_killer.py"), "1", "40", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1000000",
