@@ -4,6 +4,8 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Several GPUs: the timed workload only, unless --all-legs (see its help).
+
 A "step" is one complete `generalized_eigensolver` solve (Fortran driver loop on the HIP engine) of the
 largest BASELINE.json configuration that fits one GPU: configs[2] = N=200000 dense fp64, lowest=16, DPR,
 subspace restart at 80 (max_dim_sub=80), tol=1e-8, generate_diagonal_dominant(N, 1e-3).  The matrix is
@@ -83,6 +85,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="only the timed workload and its roofline objects")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="several GPUs: also run the configs[1] / [3] / [4] legs (default there: the timed workload only - a leg that fails on ONE "
+                         "rank would leave its peers in a collective, and the watchdog's exit would take the headline measurement with it)")
     ap.add_argument("--control-plane-only", action="store_true",
                     help="exercise the launch plumbing (rendezvous, id broadcast, barrier, max over ranks) without a GPU")
     ap.add_argument("--cpu-n", type=int, default=0, help="order for the CPU baseline (0 = same as --small-n)")
@@ -379,6 +384,8 @@ def main():
         # legitimate wait is for the slowest rank to finish generating its tiles (seconds)
         os.environ.setdefault("DAVIDSON_COLLECTIVE_TIMEOUT", "180")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if world > 1 and not args.all_legs:
+        args.headline_only = True
     if args.control_plane_only:
         # CPU-testable part of the multi-GPU launch: what bench.py does around the engine
         ident = [bytes(range(128)) if rank == 0 else None]

@@ -42,7 +42,7 @@ def test_bench_multi_rank_flow_matches_single_rank(nproc, storage):
     # row slabs / the lower block triangle dealt out over the ranks: all-gather + reduce-scatter per sweep);
     # the configs[1] / configs[3] / configs[4] legs at small orders
     extra = ["--steps", "2", "--warmup", "1", "--order", "6000", "--storage", storage, "--small-n", "3000", "--gjd-n", "2000",
-             "--free-n", "4000", "--harness-n", "0", "--no-cpu-baseline", "--no-dropin"]
+             "--free-n", "4000", "--harness-n", "0", "--no-cpu-baseline", "--no-dropin", "--all-legs"]
     one = run_bench(1, extra)
     many = run_bench(nproc, extra)
     assert many["n_gpus"] == nproc and many["steps"] == 2 and many["scaling"] == "strong"

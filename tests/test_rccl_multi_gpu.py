@@ -68,7 +68,7 @@ def test_two_gpus_matrix_free_configs4_shape():
         pytest.skip("needs two GPUs")
     for storage in ("symmetric", "full"):
         extra = ["--steps", "1", "--warmup", "0", "--order", "4000", "--storage", storage, "--free-n", "60000", "--small-n", "0", "--gjd-n", "0",
-                 "--restart-sparsity", "0", "--no-dropin", "--no-cpu-baseline"]
+                 "--restart-sparsity", "0", "--no-dropin", "--no-cpu-baseline", "--all-legs"]
         one, two = _bench(1, extra), _bench(2, extra)
         f1, f2 = one["configs4_free"], two["configs4_free"]
         assert "error" not in f1 and "error" not in f2, (f1, f2)

@@ -87,7 +87,7 @@ def test_matrix_free_and_generalized_legs_over_a_real_communicator():
     (generalized, GJD, the generated second operator partly resident: its passes agreed on by an all-reduce), configs[4] shape
     (matrix-free, symmetric generation)."""
     extra = ["--steps", "1", "--warmup", "1", "--order", "6000", "--storage", "symmetric", "--small-n", "3000", "--gjd-n", "2000", "--free-n", "4000",
-             "--restart-sparsity", "0", "--harness-n", "0", "--no-cpu-baseline", "--no-dropin"]
+             "--restart-sparsity", "0", "--harness-n", "0", "--no-cpu-baseline", "--no-dropin", "--all-legs"]
     one, two = run_bench(1, extra), run_bench(2, extra)
     for key in ("small", "configs3_gjd", "configs4_free"):
         a, b = one[key], two[key]
