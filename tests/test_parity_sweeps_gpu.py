@@ -29,6 +29,15 @@ def test_dpr_solves_against_the_oracle_on_a_fixed_seed_slice():
     assert len([ln for ln in out.splitlines() if "oracle iters" in ln]) >= 15
 
 
+def test_locking_policy_against_its_oracle_statement_on_a_fixed_seed_slice():
+    """16 random standard problems (DPR and GJD, clustered and plain diagonals, restart widths, both storages) under the opt-in
+    "locking" policy: iteration counts equal to the oracle's statement of the policy, eigenvalues to 1e-8, residuals below the
+    tolerance."""
+    out = run_tool("locking_parity_sweep.py", 16, 3)
+    assert re.search(r"mismatches: 0\b", out), out[-3000:]
+    assert len([ln for ln in out.splitlines() if "oracle iters" in ln]) >= 10
+
+
 def test_fresh_problems_against_the_compiled_reference_on_a_fixed_seed_slice():
     """12 dense + 3 matrix-free random problems solved by the reference binary (oracle/_ref: flang + MKL build of /root/reference) in a
     child process and by the engine.  DPR and matrix-free: equal iteration counts; GJD: never MORE outer iterations than the
