@@ -490,9 +490,9 @@ int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
   if (e->tune.coll_direct) {
     // opt-in (DAV_COLL_DIRECT=1): chunk p of this rank's contribution goes straight to rank p, the peers' chunks for this rank arrive
     // in a staging buffer, and a fixed-order sum (rank order) leaves the result - the same volume as the ring, over all links at once.
-    // Inside a CollGroup the exchanges of its members are one NCCL group (they run when the group ends); every member has its own
-    // part of the staging buffer, so the sums can be enqueued behind the group... which they are NOT here: a sum needs the data
-    // the group has not moved yet.  Hence a direct reduce-scatter closes the NCCL group around itself (group_depth says whether one is open).
+    // The sum needs the data its exchange moves, and an NCCL group only moves data when it ends: a direct reduce-scatter that is a
+    // member of an open CollGroup therefore closes that group in front of itself, runs its exchange as a group of its own, enqueues
+    // its sum, and reopens the group for the members behind it (the staging buffer is reused member by member, in stream order).
     const size_t need = (size_t)std::max(e->nranks - 1, 1) * count;
     if (need > e->coll_stage_doubles) {
       HIPCHK(hipStreamSynchronize(e->stream));
