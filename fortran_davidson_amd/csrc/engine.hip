@@ -209,6 +209,7 @@ Tune tune_from_env() {
   t.coll_direct = geti("DAV_COLL_DIRECT", t.coll_direct);
   t.pg_pin = geti("DAV_PG_PIN", t.pg_pin);
   t.gram_wgs = geti("DAV_GRAM_WGS", t.gram_wgs);
+  gram_set_fuse_chunks(geti("DAV_GRAM_FUSE", 0));
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
   return t;
 }

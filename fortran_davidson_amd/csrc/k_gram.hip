@@ -212,6 +212,8 @@ __global__ __launch_bounds__(1024) void gram_reduce_kernel(const double* __restr
 }
 
 static inline int pad16(int x) { return (x + 15) / 16 * 16; }
+static int g_fuse_chunks = GRAM_FUSE_CHUNKS;        // A/B knob (DAV_GRAM_FUSE at dav_create): row chunks up to which the last workgroup sums the partial tiles
+void gram_set_fuse_chunks(int n) { g_fuse_chunks = n > 0 ? n : GRAM_FUSE_CHUNKS; }
 
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad) {
   int64_t nchunks = (nrows_pad + GRAM_MIN_ROWS - 1) / GRAM_MIN_ROWS;      // worst case of gram_rows_per_wg
@@ -233,7 +235,7 @@ static void launch_gram_tiles(hipStream_t st, const double* P, int64_t ldp, int 
   const int nchunks = (int)((nrows_pad + rows_per_wg - 1) / rows_per_wg);
   // last-workgroup finish where the sum over the chunks is short and a second launch is what costs (<= GRAM_FUSE_CHUNKS row
   // chunks, one counter per output tile); the two-kernel route where hundreds of chunks want more than one workgroup per tile
-  const bool fuse = counters && nchunks <= GRAM_FUSE_CHUNKS && ptiles * qtiles <= GRAM_MAX_COUNTERS;
+  const bool fuse = counters && nchunks <= g_fuse_chunks && ptiles * qtiles <= GRAM_MAX_COUNTERS;
   hipLaunchKernelGGL((gram_kernel<PF, QF, U>), dim3(ptiles * qtiles * nchunks), dim3(256), 0, st, P, ldp, p, Q, ldq, q, nrows_pad, ptiles,
                      qtiles, nchunks, scratch, ppad, qpad, rows_per_wg, out_dev, fuse ? counters : (unsigned*)nullptr);
   if (!fuse) {

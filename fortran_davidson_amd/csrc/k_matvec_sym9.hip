@@ -219,8 +219,12 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
 
   double b[4][2], bn[4][2];
   load_b(0, b);
+  // (the transcendental test operator is evaluated where it is consumed: there is no load latency to run ahead of, and the ring's
+  // 64 registers are what its four library calls per entry need - with the ring the kernel spilled 150-230 bytes per lane)
+  if constexpr (!HARN) {
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) load_hs(d, ra[d]);
+    for (int d = 0; d < DEPTH; ++d) load_hs(d, ra[d]);
+  }
 
   for (int q = 0; q < nunits; ++q) {
     load_b(q + 1, bn);
@@ -236,9 +240,16 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs) {
       f64x2 a[4];
+      if constexpr (HARN) {
+        RingT now[4];
+        load_hs(q * 4 + hs, now);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)ra[hs][u].x, (double)ra[hs][u].y};
-      load_hs(q * 4 + hs + DEPTH, ra[(hs + DEPTH) & 3]);
+        for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)now[u].x, (double)now[u].y};
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)ra[hs][u].x, (double)ra[hs][u].y};
+        load_hs(q * 4 + hs + DEPTH, ra[(hs + DEPTH) & 3]);
+      }
       f64x2 p[2][2], xb[2][2], xb1[2][2];
 #pragma unroll
       for (int u = 0; u < 4; ++u) *reinterpret_cast<f64x2*>(tw + (4 * u + g) * TRS + 2 * c) = a[u];

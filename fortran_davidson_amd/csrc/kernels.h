@@ -35,6 +35,7 @@ constexpr int GRAM_MAX_COUNTERS = 256;
 void launch_gram(hipStream_t st, const double* P, int64_t ldp, int p, const double* Q, int64_t ldq, int q,
                  int64_t nrows_pad, double* scratch, double* out_dev, unsigned* counters = nullptr, int wg_target = 0);
 size_t gram_scratch_doubles(int p, int q, int64_t nrows_pad);
+void gram_set_fuse_chunks(int n);
 // C = P^T [Q0 | Q1 | Q2] (p x nq*qeach): the columns of the right-hand side come from up to three blocks of qeach columns each
 // (same leading dimension) - the projection and the Gram blocks of one iteration in ONE launch and one reduction (round 5)
 void launch_gram_multi(hipStream_t st, const double* P, int64_t ldp, int p, const double* const* Qs, int nq, int qeach, int64_t ldq,
