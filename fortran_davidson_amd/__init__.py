@@ -15,5 +15,5 @@ any compute call without one raises.
 from .solver import (DavidsonEngine, generalized_eigensolver, generate_diagonal_dominant,  # noqa: F401
                      lapack_generalized_eigensolver, lapack_qr, lapack_sort, generate_preconditioner,
                      lapack_matmul, lapack_solver, norm)
-from .engine_c import CEngine, DavidsonHipError  # noqa: F401
+from .engine_c import CEngine, DavidsonHipError, free_buffers  # noqa: F401
 from ._lib import hip_lib, fortran_lib, build  # noqa: F401

@@ -214,7 +214,157 @@ Tune tune_from_env() {
   return t;
 }
 
+// ---- buffer cache (engine_internal.h) -------------------------------------------------------------------------------------------
+namespace {
+struct PoolBlock { void* p; size_t bytes; int device; int kind; uint64_t gen; };      // kind 0: device, 1 + flags: pinned host
+struct Pool {
+  std::mutex mu;
+  std::vector<PoolBlock> live, idle;
+  std::vector<std::pair<int, hipStream_t>> streams;      // idle engine streams (device, stream), synchronised before they came here
+  uint64_t gen = 0;
+  int enabled = -1;
+};
+Pool& pool() { static Pool* p = new Pool; return *p; }                               // never destroyed: outlives every engine
+constexpr size_t POOL_MIN_BYTES = 64 << 10;
+
+bool pool_enabled(Pool& P) {
+  if (P.enabled < 0) { const char* v = getenv("DAVIDSON_BUFFER_CACHE"); P.enabled = (v && atoi(v) == 0) ? 0 : 1; }
+  return P.enabled == 1;
+}
+void pool_release_block(const PoolBlock& b) { if (b.kind == 0) (void)hipFree(b.p); else (void)hipHostFree(b.p); }
+// idle blocks older than `before` (all of them: UINT64_MAX) leave the cache; called with the lock held, frees outside of it
+std::vector<PoolBlock> pool_take_idle(Pool& P, uint64_t before) {
+  std::vector<PoolBlock> out;
+  for (size_t i = 0; i < P.idle.size();)
+    if (P.idle[i].gen < before) { out.push_back(P.idle[i]); P.idle[i] = P.idle.back(); P.idle.pop_back(); } else ++i;
+  return out;
+}
+hipError_t pool_get(void** p, size_t bytes, int kind, unsigned flags) {
+  Pool& P = pool();
+  int device = 0;
+  (void)hipGetDevice(&device);
+  const bool cached = bytes >= POOL_MIN_BYTES;
+  if (cached) {
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (pool_enabled(P))
+      for (size_t i = 0; i < P.idle.size(); ++i)
+        if (P.idle[i].bytes == bytes && P.idle[i].kind == kind && (kind != 0 || P.idle[i].device == device)) {
+          *p = P.idle[i].p;
+          P.live.push_back(P.idle[i]);
+          P.idle[i] = P.idle.back();
+          P.idle.pop_back();
+          return hipSuccess;
+        }
+  }
+  hipError_t r = kind == 0 ? hipMalloc(p, bytes) : hipHostMalloc(p, bytes, flags);
+  if (r != hipSuccess) {                                   // give the idle blocks back and try once more
+    (void)hipGetLastError();
+    std::vector<PoolBlock> drop;
+    { std::lock_guard<std::mutex> lk(P.mu); drop = pool_take_idle(P, UINT64_MAX); }
+    if (!drop.empty()) {
+      for (const PoolBlock& b : drop) pool_release_block(b);
+      r = kind == 0 ? hipMalloc(p, bytes) : hipHostMalloc(p, bytes, flags);
+    }
+  }
+  if (r == hipSuccess && cached) {
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live.push_back(PoolBlock{*p, bytes, device, kind, 0});
+  }
+  return r;
+}
+hipError_t pool_put(void* p, int kind) {
+  if (!p) return hipSuccess;
+  Pool& P = pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (size_t i = 0; i < P.live.size(); ++i)
+      if (P.live[i].p == p) {
+        PoolBlock b = P.live[i];
+        P.live[i] = P.live.back();
+        P.live.pop_back();
+        if (!pool_enabled(P)) break;
+        b.gen = P.gen;
+        P.idle.push_back(b);
+        return hipSuccess;
+      }
+  }
+  return kind == 0 ? hipFree(p) : hipHostFree(p);
+}
+}  // namespace
+
+hipError_t pool_malloc_raw(void** p, size_t bytes) { return pool_get(p, bytes, 0, 0); }
+hipError_t pool_host_malloc_raw(void** p, size_t bytes, unsigned flags) { return pool_get(p, bytes, 1 + (int)flags, flags); }
+hipError_t pool_free(void* p) { return pool_put(p, 0); }
+hipError_t pool_host_free(void* p) { return pool_put(p, 1); }
+// hipStreamCreate / hipStreamDestroy cost 1.5-2.7 ms each on this runtime (measured, DAV_TIME_LIFECYCLE): the engine's stream is kept too
+hipError_t pool_stream_get(hipStream_t* st) {
+  Pool& P = pool();
+  int device = 0;
+  (void)hipGetDevice(&device);
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (pool_enabled(P))
+      for (size_t i = 0; i < P.streams.size(); ++i)
+        if (P.streams[i].first == device) {
+          *st = P.streams[i].second;
+          P.streams[i] = P.streams.back();
+          P.streams.pop_back();
+          return hipSuccess;
+        }
+  }
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+void pool_stream_put(hipStream_t st, int device) {
+  if (!st) return;
+  Pool& P = pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (pool_enabled(P) && P.streams.size() < 2) { P.streams.emplace_back(device, st); return; }
+  }
+  (void)hipStreamDestroy(st);
+}
+size_t pool_idle_device_bytes(int device) {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  size_t sum = 0;
+  for (const PoolBlock& b : P.idle) if (b.kind == 0 && b.device == device) sum += b.bytes;
+  return sum;
+}
+// end of a dav_destroy: what this engine returned stays; what was idle before the engine before it was destroyed goes
+void pool_end_of_destroy() {
+  Pool& P = pool();
+  std::vector<PoolBlock> drop;
+  { std::lock_guard<std::mutex> lk(P.mu); ++P.gen; if (P.gen >= 2) drop = pool_take_idle(P, P.gen - 1); }
+  for (const PoolBlock& b : drop) pool_release_block(b);
+}
+extern "C" int dav_free_buffers(void) {
+  Pool& P = pool();
+  std::vector<PoolBlock> drop;
+  std::vector<std::pair<int, hipStream_t>> streams;
+  { std::lock_guard<std::mutex> lk(P.mu); drop = pool_take_idle(P, UINT64_MAX); streams.swap(P.streams); }
+  for (const PoolBlock& b : drop) pool_release_block(b);
+  for (auto& s : streams) (void)hipStreamDestroy(s.second);
+  return 0;
+}
+
+// DAV_TIME_LIFECYCLE=1: where dav_create / dav_destroy spend their time (stderr; the drop-in call pays both per eigenproblem)
+struct LapTimer {
+  bool on = getenv("DAV_TIME_LIFECYCLE") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  std::string line;
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[96];
+    snprintf(buf, sizeof buf, " %s=%.3f", what, std::chrono::duration<double, std::milli>(now - t).count());
+    line += buf;
+    t = now;
+  }
+  void print(const char* head) { if (on) fprintf(stderr, "%s ms:%s\n", head, line.c_str()); }
+};
+
 int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, int nranks) {
+  LapTimer lt;
   e->tune = tune_from_env();
   e->device = device;
   e->n = n;
@@ -234,7 +384,9 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   e->st.rank = rank;
   e->st.nranks = nranks;
   CHK(bind(e));
-  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  lt.lap("bind");
+  HIPCHK(pool_stream_get(&e->stream));
+  lt.lap("stream");
   // sizes first, then ONE device allocation and ONE pinned allocation carved up (256-byte aligned pieces)
   const size_t pbytes = sizeof(double) * (size_t)e->ldp * e->cols_alloc;
   e->xt_group_stride = std::max(e->ncols_pad, e->nloc_pad) * 16;   // sym-tiled sweeps index whole 256-row blocks
@@ -265,14 +417,16 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   const size_t off_agree = carve(host_total, sizeof(double) * 16 * (size_t)e->nranks);
   for (int i = 0; i < N_SMALL; ++i) off_smh[i] = carve(host_total, sizeof(double) * e->small_doubles);
   {
-    hipError_t r = hipMalloc(&e->arena, dev_total);
+    hipError_t r = pool_malloc(&e->arena, dev_total);
     if (r != hipSuccess) {
       (void)hipGetLastError();
       e->arena = nullptr;
       return fail("dav_create: hipMalloc of the engine's panels and work space (" + std::to_string(dev_total >> 20) + " MiB) failed: " + hipGetErrorString(r));
     }
   }
-  HIPCHK(hipHostMalloc(&e->arena_host, host_total, hipHostMallocMapped));
+  lt.lap("arena");
+  HIPCHK(pool_host_malloc(&e->arena_host, host_total, hipHostMallocMapped));
+  lt.lap("arena_host");
   char* host_dev = nullptr;
   HIPCHK(hipHostGetDevicePointer((void**)&host_dev, e->arena_host, 0));
   HIPCHK(hipMemsetAsync(e->arena, 0, zeroed, e->stream));
@@ -295,34 +449,44 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
     e->sm[i].host = (double*)(e->arena_host + off_smh[i]);
     HIPCHK(hipEventCreateWithFlags(&e->sm[i].done, hipEventDisableTiming));
   }
+  lt.lap("carve");
   for (int i = 0; i < N_EVPAIRS; ++i) {
     HIPCHK(hipEventCreate(&e->ev[i][0]));
     HIPCHK(hipEventCreate(&e->ev[i][1]));
   }
+  lt.lap("events");
   HIPCHK(hipStreamSynchronize(e->stream));
+  lt.lap("memset_sync");
+  lt.print("dav_create");
   return 0;
 }
 
 extern "C" int dav_destroy(dav_handle_t e) {
   if (!e) return 0;
+  LapTimer lt;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->comm_stream) hipStreamSynchronize(e->comm_stream);   // (hipFree used to wait for the device; a cached block is handed on without)
+  lt.lap("sync");
   if (e->comm && g_rccl.lib) g_rccl.CommDestroy(e->comm);
-  if (e->arena) hipFree(e->arena);
-  if (e->arena_host) hipHostFree(e->arena_host);
-  hipFree(e->gjd_ws);
+  lt.lap("comm");
+  if (e->arena) pool_free(e->arena);
+  if (e->arena_host) pool_host_free(e->arena_host);
+  lt.lap("arenas");
+  pool_free(e->gjd_ws);
   ingest_release(e);
   shm_release(e);
-  hipFree(e->sym_slab);
-  hipFree(e->rr_H); hipFree(e->rr_S); hipFree(e->rr_Y); hipFree(e->rr_theta); hipFree(e->rr_work); hipFree(e->rr_info);
-  hipFree(e->rr_Ypk); hipFree(e->rr_Y2pk); hipFree(e->rr_thpk);
+  pool_free(e->sym_slab);
+  pool_free(e->rr_H); pool_free(e->rr_S); pool_free(e->rr_Y); pool_free(e->rr_theta); pool_free(e->rr_work); pool_free(e->rr_info);
+  pool_free(e->rr_Ypk); pool_free(e->rr_Y2pk); pool_free(e->rr_thpk);
+  lt.lap("ingest_shm_slab_rr");
   for (int i = 0; i < 2; ++i) {
     if (e->ov_packed[i]) hipEventDestroy(e->ov_packed[i]);
     if (e->ov_gathered[i]) hipEventDestroy(e->ov_gathered[i]);
     if (e->ov_reduced[i]) hipEventDestroy(e->ov_reduced[i]);
     if (e->ov_scattered[i]) hipEventDestroy(e->ov_scattered[i]);
-    hipFree(e->sym_wpart2[i]);
-    hipFree(e->sym_wrecv2[i]);
+    pool_free(e->sym_wpart2[i]);
+    pool_free(e->sym_wrecv2[i]);
   }
   if (e->comm_stream) hipStreamDestroy(e->comm_stream);
   if (e->wd) {
@@ -333,24 +497,32 @@ extern "C" int dav_destroy(dav_handle_t e) {
     delete e->wd;
     e->wd = nullptr;
   }
+  lt.lap("overlap_watchdog");
   sym_set_release(e->sym);
-  hipFree(e->sym_wpart);
-  hipFree(e->coll_stage);
-  hipFree(e->sym_wrecv);
+  lt.lap("sym_set");
+  pool_free(e->sym_wpart);
+  pool_free(e->coll_stage);
+  pool_free(e->sym_wrecv);
   for (int i = 0; i < N_SMALL; ++i)
     if (e->sm[i].done) hipEventDestroy(e->sm[i].done);
   for (int i = 0; i < N_EVPAIRS; ++i) {
     if (e->ev[i][0]) hipEventDestroy(e->ev[i][0]);
     if (e->ev[i][1]) hipEventDestroy(e->ev[i][1]);
   }
+  lt.lap("wpart_events");
   for (int w = 0; w < 2; ++w) {
     sym_resident_release(e->op[w]);
-    hipFree(e->op[w].a);
-    hipFree(e->op[w].a32);
-    hipFree(e->op[w].e_table);
+    pool_free(e->op[w].a);
+    pool_free(e->op[w].a32);
+    pool_free(e->op[w].e_table);
   }
-  if (e->stream) hipStreamDestroy(e->stream);
+  lt.lap("operators");
+  if (e->stream) { (void)hipStreamSynchronize(e->stream); pool_stream_put(e->stream, e->device); }
+  lt.lap("stream");
   delete e;
+  pool_end_of_destroy();
+  lt.lap("pool");
+  lt.print("dav_destroy");
   return 0;
 }
 

@@ -10,7 +10,7 @@ bool inner_f32_tiles(E* e, OpDesc& o) {
   if (e->inner_bits != 32 || o.kind != DAV_KIND_DENSE || o.storage != 1 || o.a32_refused) return false;
   if (o.a32_valid) return true;
   const size_t count = (size_t)std::max<int64_t>(e->sym.ntiles, 1) * SYM_TB * SYM_TB;
-  if (!o.a32 && hipMalloc(&o.a32, sizeof(float) * count) != hipSuccess) {
+  if (!o.a32 && pool_malloc(&o.a32, sizeof(float) * count) != hipSuccess) {
     (void)hipGetLastError();
     o.a32 = nullptr;
     o.a32_refused = true;
@@ -73,7 +73,7 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     double* bufs[4] = {};
     auto undo = [&]() {
       for (hipEvent_t v : evs) if (v) (void)hipEventDestroy(v);
-      for (double* b : bufs) if (b) (void)hipFree(b);
+      for (double* b : bufs) if (b) (void)pool_free(b);
       if (cs) (void)hipStreamDestroy(cs);
     };
     // highest priority: the collective's few workgroups take the first CUs the sweep's work items give back, instead of queueing
@@ -83,8 +83,8 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
     bool ok = hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i) {
-      ok = hipMalloc(&bufs[i], sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32) == hipSuccess &&
-           hipMalloc(&bufs[2 + i], sizeof(double) * (size_t)e->nslab * 32) == hipSuccess;
+      ok = pool_malloc(&bufs[i], sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 32) == hipSuccess &&
+           pool_malloc(&bufs[2 + i], sizeof(double) * (size_t)e->nslab * 32) == hipSuccess;
     }
     if (!ok) {
       (void)hipGetLastError();
@@ -215,8 +215,8 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
     // 64 columns costs two collectives, not four.
     if (e->tune.sym_quad && pair_ok && o.kind == DAV_KIND_DENSE && k >= 64 && !inner && !e->sym_no_quad && sym_schedule(e, 32, true) == 2) step = 64;
     if (multi && !e->sym_wpart) {
-      HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 64));
-      HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 64));
+      HIPCHK(pool_malloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 64));
+      HIPCHK(pool_malloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 64));
     }
     const int64_t* owned = (multi || partial) ? set.row_off : nullptr;
     const int64_t total_rows = (int64_t)e->nranks * e->nslab;
@@ -391,8 +391,8 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
 int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst) {
   CHK(need_comm(e));
   if (!e->sym_wpart) {
-    HIPCHK(hipMalloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 64));
-    HIPCHK(hipMalloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 64));
+    HIPCHK(pool_malloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 64));
+    HIPCHK(pool_malloc(&e->sym_wrecv, sizeof(double) * (size_t)e->nslab * 64));
   }
   const int64_t total_rows = (int64_t)e->nranks * e->nslab;
   for (int c = 0; c < ncols; c += 32) {
@@ -487,11 +487,11 @@ extern "C" int dav_bench_stream3(dav_handle_t e, int64_t doubles, int reps, doub
   double *a = nullptr, *b = nullptr, *c = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
   auto cleanup = [&]() {
-    hipFree(a); hipFree(b); hipFree(c);
+    pool_free(a); pool_free(b); pool_free(c);
     for (hipEvent_t v : ev) if (v) hipEventDestroy(v);
   };
-  if (hipMalloc(&a, sizeof(double) * n) != hipSuccess || hipMalloc(&b, sizeof(double) * n) != hipSuccess ||
-      hipMalloc(&c, sizeof(double) * n) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
+  if (pool_malloc(&a, sizeof(double) * n) != hipSuccess || pool_malloc(&b, sizeof(double) * n) != hipSuccess ||
+      pool_malloc(&c, sizeof(double) * n) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
     (void)hipGetLastError();
     cleanup();
     return fail("dav_bench_stream: could not allocate three arrays of " + std::to_string(n) + " doubles");
@@ -533,8 +533,8 @@ extern "C" int dav_bench_harness_rate(dav_handle_t e, int iters, double* entries
   const int wgs = 512;
   double* out = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
-  HIPCHK(hipMalloc(&out, sizeof(double) * (size_t)wgs * 512));
-  auto cleanup = [&]() { hipFree(out); for (hipEvent_t v : ev) if (v) hipEventDestroy(v); };
+  HIPCHK(pool_malloc(&out, sizeof(double) * (size_t)wgs * 512));
+  auto cleanup = [&]() { pool_free(out); for (hipEvent_t v : ev) if (v) hipEventDestroy(v); };
   auto run = [&]() -> int {
     HIPCHK(hipEventCreate(&ev[0]));
     HIPCHK(hipEventCreate(&ev[1]));

@@ -496,9 +496,9 @@ int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
     const size_t need = (size_t)std::max(e->nranks - 1, 1) * count;
     if (need > e->coll_stage_doubles) {
       HIPCHK(hipStreamSynchronize(e->stream));
-      if (e->coll_stage) HIPCHK(hipFree(e->coll_stage));
+      if (e->coll_stage) HIPCHK(pool_free(e->coll_stage));
       e->coll_stage = nullptr; e->coll_stage_doubles = 0;
-      HIPCHK(hipMalloc(&e->coll_stage, sizeof(double) * need));
+      HIPCHK(pool_malloc(&e->coll_stage, sizeof(double) * need));
       e->coll_stage_doubles = need;
     }
     const bool reopen = e->group_depth > 0;

@@ -81,7 +81,7 @@ extern "C" int dav_gjd_correction_n(dav_handle_t e, int mbasis, int m, const dou
   const int wcols = e->cols_alloc / 2 + 8;
   if (!e->gjd_ws) {
     size_t bytes = sizeof(double) * (size_t)e->ldp * wcols * 9;
-    HIPCHK(hipMalloc(&e->gjd_ws, bytes));
+    HIPCHK(pool_malloc(&e->gjd_ws, bytes));
     HIPCHK(hipMemsetAsync(e->gjd_ws, 0, bytes, e->stream));
   }
   auto ws = [&](int i) { return e->gjd_ws + (size_t)i * e->ldp * wcols; };

@@ -45,6 +45,23 @@ int fail(const std::string& msg);
     if (r_ != 0) return r_;  \
   } while (0)
 
+// Buffer cache (engine.hip).  The blocks of the engine destroyed last (>= 64 KiB: tiles, panels, slabs, pinned staging) stay allocated and
+// are handed to the next engine that asks for exactly those sizes: the drop-in call creates and destroys an engine per call, and
+// hipMalloc / hipFree of gigabytes cost it 5 ms of 40 at N=20000.  Blocks that sat idle through a whole create-destroy cycle are freed;
+// an allocation that fails frees the idle blocks and tries again, so the cache never turns into an out-of-memory of this process.
+// DAVIDSON_BUFFER_CACHE=0 turns it off; dav_free_buffers() gives the idle blocks back (mkl_free_buffers' role).
+hipError_t pool_malloc_raw(void** p, size_t bytes);
+hipError_t pool_host_malloc_raw(void** p, size_t bytes, unsigned flags);
+hipError_t pool_free(void* p);
+hipError_t pool_host_free(void* p);
+size_t pool_idle_device_bytes(int device);
+void pool_end_of_destroy();
+hipError_t pool_stream_get(hipStream_t* st);          // the engine's stream (non-blocking): created, or the one of the engine destroyed last
+void pool_stream_put(hipStream_t st, int device);
+template <class T> inline hipError_t pool_malloc(T** p, size_t bytes) { return pool_malloc_raw((void**)p, bytes); }
+template <class T> inline hipError_t pool_host_malloc(T** p, size_t bytes, unsigned flags) { return pool_host_malloc_raw((void**)p, bytes, flags); }
+
+
 // ---- RCCL, loaded lazily so that single-GPU use never touches it ------------------------------------
 struct Rccl {
   void* lib = nullptr;

@@ -65,8 +65,8 @@ std::vector<int> sym_group_owners(int nb, int nranks) {
 }
 
 void sym_set_release(SymSet& s) {
-  hipFree(s.row_off); hipFree(s.items); hipFree(s.row_begin);
-  for (SymPlan& pl : s.plan) { hipFree(pl.items); hipFree(pl.row_begin); hipFree(pl.zslot_begin); hipFree(pl.next_owned); }
+  pool_free(s.row_off); pool_free(s.items); pool_free(s.row_begin);
+  for (SymPlan& pl : s.plan) { pool_free(pl.items); pool_free(pl.row_begin); pool_free(pl.zslot_begin); pool_free(pl.next_owned); }
   s = SymSet();
 }
 
@@ -89,7 +89,7 @@ int sym_build_set(E* e, int first, int end, SymSet& out) {
   for (int I = first; I < std::min(end, nb); ++I)
     if (gowner[I / 4] == e->rank) { out.row_off_h[I] = ntiles; ntiles += I + 1; }
   out.ntiles = ntiles;
-  HIPCHK(hipMalloc(&out.row_off, sizeof(int64_t) * nb));
+  HIPCHK(pool_malloc(&out.row_off, sizeof(int64_t) * nb));
   HIPCHK(hipMemcpy(out.row_off, out.row_off_h.data(), sizeof(int64_t) * nb, hipMemcpyHostToDevice));
   auto owned = [&](int I) { return out.row_off_h[I] >= 0; };
   // One-block-row kernel: runs of <= C consecutive tiles of one block row.
@@ -116,8 +116,8 @@ int sym_build_set(E* e, int first, int end, SymSet& out) {
   for (const Item& it : list) { items.push_back(it.I); items.push_back(it.J0); items.push_back(it.J1); items.push_back(it.slot); }
   items.resize(std::max<size_t>(items.size(), 4), 0);
   out.nitems = row_begin[nb];
-  HIPCHK(hipMalloc(&out.items, sizeof(int) * items.size()));
-  HIPCHK(hipMalloc(&out.row_begin, sizeof(int) * row_begin.size()));
+  HIPCHK(pool_malloc(&out.items, sizeof(int) * items.size()));
+  HIPCHK(pool_malloc(&out.row_begin, sizeof(int) * row_begin.size()));
   HIPCHK(hipMemcpy(out.items, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(out.row_begin, row_begin.data(), sizeof(int) * row_begin.size(), hipMemcpyHostToDevice));
   // Super-row schedules: items = (super row of R block rows) x (run of C tile columns).  Per tile the schedule
@@ -148,16 +148,16 @@ int sym_build_set(E* e, int first, int end, SymSet& out) {
     pitems.resize(std::max<size_t>(pitems.size(), 4), 0);
     pl.nitems = prow[pl.nsuper];
     pl.zslots = zbeg[pl.nsuper];
-    HIPCHK(hipMalloc(&pl.items, sizeof(int) * pitems.size()));
-    HIPCHK(hipMalloc(&pl.row_begin, sizeof(int) * prow.size()));
-    HIPCHK(hipMalloc(&pl.zslot_begin, sizeof(int) * zbeg.size()));
+    HIPCHK(pool_malloc(&pl.items, sizeof(int) * pitems.size()));
+    HIPCHK(pool_malloc(&pl.row_begin, sizeof(int) * prow.size()));
+    HIPCHK(pool_malloc(&pl.zslot_begin, sizeof(int) * zbeg.size()));
     HIPCHK(hipMemcpy(pl.items, pitems.data(), sizeof(int) * pitems.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pl.row_begin, prow.data(), sizeof(int) * prow.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(pl.zslot_begin, zbeg.data(), sizeof(int) * zbeg.size(), hipMemcpyHostToDevice));
     // the super rows of this set, as a skip list for the fixed-order reduction (several ranks: 7 of 8 super rows are another rank's)
     std::vector<int> nxt(pl.nsuper + 1, pl.nsuper);
     for (int S = pl.nsuper - 1; S >= 0; --S) nxt[S] = owned(S * pl.R) ? S : nxt[S + 1];
-    HIPCHK(hipMalloc(&pl.next_owned, sizeof(int) * nxt.size()));
+    HIPCHK(pool_malloc(&pl.next_owned, sizeof(int) * nxt.size()));
     HIPCHK(hipMemcpy(pl.next_owned, nxt.data(), sizeof(int) * nxt.size(), hipMemcpyHostToDevice));
   }
   out.built = true;
@@ -185,10 +185,10 @@ int sym_diag(E* e, OpDesc& o) {
 int sym_ensure_slabs(E* e, size_t doubles) {
   if (doubles <= e->sym_slab_doubles) return 0;
   HIPCHK(hipStreamSynchronize(e->stream));
-  if (e->sym_slab) HIPCHK(hipFree(e->sym_slab));
+  if (e->sym_slab) HIPCHK(pool_free(e->sym_slab));
   e->sym_slab = nullptr;
   e->sym_slab_doubles = 0;
-  hipError_t r = hipMalloc(&e->sym_slab, sizeof(double) * doubles);
+  hipError_t r = pool_malloc(&e->sym_slab, sizeof(double) * doubles);
   if (r != hipSuccess) {
     (void)hipGetLastError();
     e->sym_slab = nullptr;
@@ -204,7 +204,7 @@ int alloc_dense(E* e, int which) {
   o.res_decided = false;
   o.a32_valid = false;       // new contents: the fp32 copy is rebuilt when the next inner sweep asks for it
   o.a32_refused = false;
-  if (o.a && o.storage != e->storage) { hipFree(o.a); o.a = nullptr; }
+  if (o.a && o.storage != e->storage) { pool_free(o.a); o.a = nullptr; }
   o.storage = e->storage;
   if (!o.a) {
     size_t bytes;
@@ -214,7 +214,7 @@ int alloc_dense(E* e, int which) {
     } else {
       bytes = sizeof(double) * (size_t)e->nloc_pad * (size_t)e->ncols_pad;
     }
-    hipError_t r = hipMalloc(&o.a, bytes);
+    hipError_t r = pool_malloc(&o.a, bytes);
     if (r != hipSuccess) {
       (void)hipGetLastError();
       return fail("hipMalloc of the dense matrix (" + std::to_string(bytes >> 20) + " MiB) failed: " + hipGetErrorString(r));
@@ -268,10 +268,10 @@ int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind 
     const int G = (size_t)ldp_stage * SYM_TB * 4 * sizeof(double) <= ((size_t)512 << 20) ? 4 : 1;
     double* stage[2] = {nullptr, nullptr};
     for (int b = 0; b < 2; ++b) {
-      hipError_t r = hipMalloc(&stage[b], sizeof(double) * (size_t)ldp_stage * SYM_TB * G);
+      hipError_t r = pool_malloc(&stage[b], sizeof(double) * (size_t)ldp_stage * SYM_TB * G);
       if (r != hipSuccess) {
         (void)hipGetLastError();
-        if (stage[0]) hipFree(stage[0]);
+        if (stage[0]) pool_free(stage[0]);
         return fail("hipMalloc of the upload staging panel failed: " + std::string(hipGetErrorString(r)));
       }
     }
@@ -295,8 +295,8 @@ int set_dense_from(E* e, int which, const double* a, int64_t lda, hipMemcpyKind 
       }
     }
     hipStreamSynchronize(e->stream);
-    hipFree(stage[0]);
-    hipFree(stage[1]);
+    pool_free(stage[0]);
+    pool_free(stage[1]);
     if (rc != 0) return rc;
     HIPCHK(hipGetLastError());
     CHK(sym_diag(e, o));
@@ -324,8 +324,8 @@ extern "C" int dav_set_dense_dev(dav_handle_t e, int which, const double* a_dev,
 void ingest_release(E* e) {
   for (int b = 0; b < 2; ++b) {
     if (e->ing_done[b]) { hipEventSynchronize(e->ing_done[b]); hipEventDestroy(e->ing_done[b]); e->ing_done[b] = nullptr; }
-    if (e->ing_host[b]) { hipHostFree(e->ing_host[b]); e->ing_host[b] = nullptr; }
-    if (e->ing_dev[b]) { hipFree(e->ing_dev[b]); e->ing_dev[b] = nullptr; }
+    if (e->ing_host[b]) { pool_host_free(e->ing_host[b]); e->ing_host[b] = nullptr; }
+    if (e->ing_dev[b]) { pool_free(e->ing_dev[b]); e->ing_dev[b] = nullptr; }
     e->ing_pending[b] = false;
   }
   e->ing_which = -1;
@@ -346,8 +346,8 @@ extern "C" int dav_dense_begin(dav_handle_t e, int which) {
   cap = std::min<int64_t>(cap, roundup(e->n, 32));
   e->ing_cap_rows = cap;
   for (int b = 0; b < 2; ++b) {
-    HIPCHK(hipHostMalloc(&e->ing_host[b], sizeof(double) * (size_t)(cap * e->n), hipHostMallocDefault));
-    HIPCHK(hipMalloc(&e->ing_dev[b], sizeof(double) * (size_t)(cap * e->n)));
+    HIPCHK(pool_host_malloc(&e->ing_host[b], sizeof(double) * (size_t)(cap * e->n), hipHostMallocDefault));
+    HIPCHK(pool_malloc(&e->ing_dev[b], sizeof(double) * (size_t)(cap * e->n)));
     HIPCHK(hipEventCreateWithFlags(&e->ing_done[b], hipEventDisableTiming));
   }
   e->ing_flip = 0;
@@ -517,7 +517,7 @@ extern "C" int dav_set_operator_harness(dav_handle_t e, int which, const double*
   o.kind = DAV_KIND_HARNESS; o.trig = which == DAV_OP_A ? 0 : 1;
   o.storage = e->storage == 1 ? 1 : 0;      // symmetric mode: each entry generated once
   if (o.storage == 1) CHK(sym_setup(e));
-  if (!o.e_table) HIPCHK(hipMalloc(&o.e_table, sizeof(double) * e->n));
+  if (!o.e_table) HIPCHK(pool_malloc(&o.e_table, sizeof(double) * e->n));
   HIPCHK(hipMemcpyAsync(o.e_table, e_table, sizeof(double) * e->n, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
@@ -571,7 +571,7 @@ extern "C" int dav_get_diagonal(dav_handle_t e, int which, double* out) {
 void sym_resident_release(OpDesc& o) {
   if (o.res) { sym_set_release(*o.res); delete o.res; o.res = nullptr; }
   if (o.gen) { sym_set_release(*o.gen); delete o.gen; o.gen = nullptr; }
-  hipFree(o.res_a);
+  pool_free(o.res_a);
   o.res_a = nullptr;
   o.res_tiles = 0;
   o.res_first = 0;
@@ -588,6 +588,7 @@ int sym_resident_split(E* e, int which) {
   const double tile_bytes = 8.0 * SYM_TB * SYM_TB;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  free_b += pool_idle_device_bytes(e->device);            // idle blocks of the buffer cache are given back when an allocation needs them
   // what the sweeps may still allocate: the slabs of a paired 32-column launch of the two-block-row schedule (a 64-column launch
   // that then finds no room for its four column groups runs as two paired launches - 1 % slower on that sweep, which is far less
   // than what the extra resident block rows save on every sweep of this operator), the fp32 copy
@@ -627,7 +628,7 @@ int sym_resident_split(E* e, int which) {
   o.gen = new SymSet();
   int rc = sym_build_set(e, first, nb, *o.res);
   if (rc == 0) rc = sym_build_set(e, 0, first, *o.gen);
-  if (rc == 0 && hipMalloc(&o.res_a, (size_t)(tile_bytes * (double)std::max<int64_t>(o.res->ntiles, 1))) != hipSuccess) {
+  if (rc == 0 && pool_malloc(&o.res_a, (size_t)(tile_bytes * (double)std::max<int64_t>(o.res->ntiles, 1))) != hipSuccess) {
     (void)hipGetLastError();
     o.res_a = nullptr;
     rc = fail("hipMalloc of the resident tiles of a generated operator failed (" + std::to_string((size_t)(tile_bytes * (double)o.res->ntiles) >> 20) +
@@ -661,6 +662,7 @@ extern "C" int dav_device_memory(dav_handle_t e, int64_t* free_bytes, int64_t* t
   CHK(bind(e));
   size_t f = 0, t = 0;
   HIPCHK(hipMemGetInfo(&f, &t));
+  f += pool_idle_device_bytes(e->device);                 // (the buffer cache's idle blocks are free memory to this library)
   if (free_bytes) *free_bytes = (int64_t)f;
   if (total_bytes) *total_bytes = (int64_t)t;
   return 0;

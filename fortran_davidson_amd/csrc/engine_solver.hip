@@ -514,15 +514,15 @@ extern "C" int dav_rr_enable(dav_handle_t e, int on) {
     // for a wider basis can still run narrower solves with it: the device-resident matrices are sized to what it can use
     e->rr_ld = std::min<int64_t>(e->cols_alloc, 160);
     const size_t sq = (size_t)e->rr_ld * e->rr_ld, pk = (size_t)roundup(e->rr_ld, 4) * roundup(e->rr_ld, 64);
-    HIPCHK(hipMalloc(&e->rr_H, sizeof(double) * sq));
-    HIPCHK(hipMalloc(&e->rr_S, sizeof(double) * sq));
-    HIPCHK(hipMalloc(&e->rr_Y, sizeof(double) * sq));
-    HIPCHK(hipMalloc(&e->rr_theta, sizeof(double) * e->rr_ld));
-    HIPCHK(hipMalloc(&e->rr_work, sizeof(double) * small_eig_work_doubles((int)e->rr_ld)));
-    HIPCHK(hipMalloc(&e->rr_info, sizeof(double) * 8));
-    HIPCHK(hipMalloc(&e->rr_Ypk, sizeof(double) * pk));
-    HIPCHK(hipMalloc(&e->rr_Y2pk, sizeof(double) * pk));
-    HIPCHK(hipMalloc(&e->rr_thpk, sizeof(double) * (roundup(e->rr_ld, 64) + e->rr_ld + 8)));
+    HIPCHK(pool_malloc(&e->rr_H, sizeof(double) * sq));
+    HIPCHK(pool_malloc(&e->rr_S, sizeof(double) * sq));
+    HIPCHK(pool_malloc(&e->rr_Y, sizeof(double) * sq));
+    HIPCHK(pool_malloc(&e->rr_theta, sizeof(double) * e->rr_ld));
+    HIPCHK(pool_malloc(&e->rr_work, sizeof(double) * small_eig_work_doubles((int)e->rr_ld)));
+    HIPCHK(pool_malloc(&e->rr_info, sizeof(double) * 8));
+    HIPCHK(pool_malloc(&e->rr_Ypk, sizeof(double) * pk));
+    HIPCHK(pool_malloc(&e->rr_Y2pk, sizeof(double) * pk));
+    HIPCHK(pool_malloc(&e->rr_thpk, sizeof(double) * (roundup(e->rr_ld, 64) + e->rr_ld + 8)));
     HIPCHK(hipMemsetAsync(e->rr_H, 0, sizeof(double) * sq, e->stream));
     HIPCHK(hipMemsetAsync(e->rr_S, 0, sizeof(double) * sq, e->stream));
   }

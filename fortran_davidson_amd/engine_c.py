@@ -32,7 +32,7 @@ class Stats(C.Structure):
                 ("b_stored_launches", C.c_int64), ("b_generated_launches", C.c_int64)]
 
 
-ABI_VERSION = 104      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
+ABI_VERSION = 105      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
 
 
 def _dp(a):
@@ -368,3 +368,8 @@ def parse_text_f64(data: bytes) -> np.ndarray:
     if lib.dav_parse_text_f64(data, C.c_size_t(len(data)), _dp(out), C.c_size_t(out.size), C.byref(n)) != 0:
         raise DavidsonHipError(lib.dav_last_error().decode())
     return out
+
+
+def free_buffers() -> None:
+    """Return the buffer cache's idle device / pinned blocks (kept from the engine destroyed last) to the device."""
+    hip_lib().dav_free_buffers()

@@ -25,7 +25,7 @@ module davidson_device
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
        engine_set_identity, engine_comm_unique_id, engine_comm_init, &
-       generalized_eigensolver_device, davidson_device_loop, basis_capacity
+       generalized_eigensolver_device, davidson_device_loop, basis_capacity, davidson_free_buffers
 
   !> Handle of a device-resident problem: operators A (and B) plus all work panels in HBM.
   type :: davidson_engine
@@ -60,6 +60,14 @@ module davidson_device
   end interface
 
 contains
+
+  !> Give the device and pinned blocks the library keeps from the engine destroyed last back to the device (the buffer cache of
+  !> include/davidson_hip.h: a call per eigenproblem - the reference's interface - otherwise pays hipMalloc / hipFree of the whole
+  !> problem every time).  What mkl_free_buffers is to MKL.
+  subroutine davidson_free_buffers()
+    integer(c_int) :: ierr
+    ierr = dav_free_buffers()
+  end subroutine davidson_free_buffers
 
   !> Device index from the environment (DAVIDSON_DEVICE, default 0): an engine knob that does not
   !> touch the reference's argument lists (dense and matrix-free front ends alike).
@@ -1622,10 +1630,10 @@ module davidson
   use numeric_kinds, only: dp
   use davidson_dense, only: generalized_eigensolver_dense
   use davidson_free, only: generalized_eigensolver_free
-  use davidson_device, only: generalized_eigensolver_device
+  use davidson_device, only: generalized_eigensolver_device, davidson_free_buffers
   implicit none
   private
-  public :: generalized_eigensolver
+  public :: generalized_eigensolver, davidson_free_buffers
 
   !> Generic of the reference (src/davidson.f90:601-625), resolved by the first argument: a matrix,
   !> a block-apply procedure, or (new) a device-resident `davidson_engine`.

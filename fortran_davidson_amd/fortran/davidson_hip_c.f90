@@ -28,7 +28,7 @@ module davidson_hip_c
   end type dav_stats
   !> DAV_HIP_ABI_VERSION of include/davidson_hip.h these interfaces were written against: engine_create checks that the
   !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101, 102 and 104)
-  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 104
+  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 105
 
   interface
      function dav_last_error() bind(C, name="dav_last_error") result(p)
@@ -77,6 +77,10 @@ module davidson_hip_c
        import :: c_ptr, c_int, c_int64_t
        type(c_ptr), value :: h
        integer(c_int64_t), intent(out) :: free_bytes, total_bytes
+       integer(c_int) :: ierr
+     end function
+     function dav_free_buffers() bind(C, name="dav_free_buffers") result(ierr)
+       import :: c_int
        integer(c_int) :: ierr
      end function
      function dav_set_storage(h, mode) bind(C, name="dav_set_storage") result(ierr)

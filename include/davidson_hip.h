@@ -83,9 +83,9 @@ typedef struct dav_stats {
 } dav_stats;
 
 /* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */
-/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next) must not    */
+/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next, 105 dav_free_buffers) must not    */
 /* use the unsized call - the sized one, which copies at most `bytes` bytes, is safe across versions.   */
-#define DAV_HIP_ABI_VERSION 104
+#define DAV_HIP_ABI_VERSION 105
 const char* dav_last_error(void);
 int dav_version(void);
 
@@ -122,6 +122,12 @@ int dav_set_storage(dav_handle_t h, int mode);
 /* Free and total memory of the engine's device in bytes (hipMemGetInfo) - what a front end needs to decide, before it uploads, whether
  * a dense operator fits as full rows (8 N^2 / nranks bytes) or only as symmetric tiles (half of that). */
 int dav_device_memory(dav_handle_t h, int64_t* free_bytes, int64_t* total_bytes);
+/* Buffer cache.  dav_destroy keeps the device and pinned blocks of the engine it destroys (>= 64 KiB) for the next dav_create of the
+ * same sizes - the reference's interface (src/davidson.f90:51-52) is one call per eigenproblem, so a caller in a loop creates and
+ * destroys an engine per call; blocks idle through a whole create-destroy cycle are freed, a failing allocation frees them all and
+ * tries again, dav_device_memory counts them as free.  dav_free_buffers() returns every idle block to the device now
+ * (what mkl_free_buffers is to MKL); DAVIDSON_BUFFER_CACHE=0 in the environment turns the cache off. */
+int dav_free_buffers(void);
 /* Dense matrix from host memory, full storage a(lda, n), the caller's array as passed to
  * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and
  * extracts the diagonal (replaces array_utils.f90:115-134). */

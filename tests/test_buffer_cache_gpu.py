@@ -1,0 +1,48 @@
+"""The buffer cache of include/davidson_hip.h (dav_free_buffers): the reference's interface is one call per eigenproblem
+(src/davidson.f90:51-52), so the drop-in creates and destroys an engine per call; the blocks of the engine destroyed last are kept
+for the next one of the same sizes."""
+import numpy as np
+import pytest
+
+import fortran_davidson_amd as fd
+from oracle import davidson_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def raw_free():
+    import torch
+    return torch.cuda.mem_get_info(0)[0]
+
+
+def test_blocks_are_kept_reused_and_given_back():
+    n, lowest = 6000, 4
+    a = O.generate_diagonal_dominant(n, 1e-3, seed=7)
+    fd.generalized_eigensolver(a[:400, :400].copy(), lowest, "DPR", 100, 1e-8)     # (the runtime loads the kernels: memory of its own)
+    fd.free_buffers()
+    before = raw_free()
+    lam1, vec1, it1 = fd.generalized_eigensolver(a, lowest, "DPR", 100, 1e-8)
+    held = before - raw_free()
+    assert held > 8 * n * n // 2                           # the tiles (at least the lower triangle) and the panels are still allocated
+    lam2, vec2, it2 = fd.generalized_eigensolver(a, lowest, "DPR", 100, 1e-8)
+    assert before - raw_free() <= held + (4 << 20)        # the second call took the first one's blocks, it did not allocate its own
+    assert it2 == it1 and np.array_equal(lam1, lam2) and np.array_equal(vec1, vec2)   # recycled memory, the same bits
+    # another size: the blocks of the first size sit idle through one create-destroy cycle and are then let go
+    b = O.generate_diagonal_dominant(3000, 1e-3, seed=8)
+    fd.generalized_eigensolver(b, lowest, "DPR", 100, 1e-8)
+    fd.generalized_eigensolver(b, lowest, "DPR", 100, 1e-8)
+    assert before - raw_free() < held // 2                # (9 MB of tiles instead of 150)
+    fd.free_buffers()
+    assert before - raw_free() < (64 << 20)               # everything is back (the runtime keeps a little of its own)
+
+
+def test_engine_reports_idle_blocks_as_free_memory():
+    fd.free_buffers()
+    with fd.DavidsonEngine(5000, 4, None, storage="symmetric") as eng:
+        eng.generate_diagonal_dominant(1, 1e-3, seed=1)
+        eng.solve("DPR", 100, 1e-8)
+    idle = raw_free()
+    with fd.DavidsonEngine(64, 2, None) as eng:            # a small engine: asks the device, the big one's blocks are idle
+        free_seen, total = eng.c.device_memory()
+    fd.free_buffers()
+    assert free_seen > idle and free_seen <= total
