@@ -11,7 +11,12 @@ int fail(const std::string& msg) {
   return 1;
 }
 
-int bind(E* e) { HIPCHK(hipSetDevice(e->device)); return 0; }
+int bind(E* e) {
+  e->h0_take = e->h0_cols;        // only the call that directly follows dav_init_basis may use its H0 (engine_internal.h)
+  e->h0_cols = 0;
+  HIPCHK(hipSetDevice(e->device));
+  return 0;
+}
 
 // Called only where no pair can legitimately be open (API entry points, or timed_begin with ev_open == 0): a pair left
 // without its end event by a failed call is dropped here, and the open count starts from zero again - a failure does
@@ -411,10 +416,13 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   const size_t off_gather = carve(dev_total, sizeof(double) * (size_t)e->ncols_pad);
   const size_t off_idx = carve(dev_total, sizeof(int64_t) * e->cols_alloc);
   const size_t off_norm = carve(dev_total, sizeof(double) * (size_t)(e->nloc_pad / PG_ROWS) * e->cols_alloc);
+  e->h0_cap = std::min(e->cols_alloc, 128);
+  const size_t off_h0 = carve(dev_total, sizeof(double) * 2 * (size_t)e->h0_cap * e->h0_cap);
   size_t off_sm[N_SMALL], off_smh[N_SMALL];
   for (int i = 0; i < N_SMALL; ++i) off_sm[i] = carve(dev_total, sizeof(double) * e->small_doubles);
   const size_t off_gramh = carve(host_total, sizeof(double) * e->gram_doubles);
   const size_t off_agree = carve(host_total, sizeof(double) * 16 * (size_t)e->nranks);
+  const size_t off_h0h = carve(host_total, sizeof(double) * 2 * (size_t)e->h0_cap * e->h0_cap);
   for (int i = 0; i < N_SMALL; ++i) off_smh[i] = carve(host_total, sizeof(double) * e->small_doubles);
   {
     hipError_t r = pool_malloc(&e->arena, dev_total);
@@ -444,6 +452,8 @@ int create_impl(E* e, int device, int64_t n, int max_cols, int gev, int rank, in
   e->gram_host = (double*)(e->arena_host + off_gramh);
   e->gram_host_dev = (double*)(host_dev + off_gramh);
   e->agree_pin = (double*)(e->arena_host + off_agree);
+  e->h0_dev = (double*)(e->arena + off_h0);
+  e->h0_host = (double*)(e->arena_host + off_h0h);
   for (int i = 0; i < N_SMALL; ++i) {
     e->sm[i].dev = (double*)(e->arena + off_sm[i]);
     e->sm[i].host = (double*)(e->arena_host + off_smh[i]);

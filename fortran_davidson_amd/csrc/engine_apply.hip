@@ -388,7 +388,7 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
 // reduce-scatter layout of the sweeps and the same reduce-scatter leaves every rank its row slab.  One owner per entry, so the sum
 // is exact and equals the sweep's result (products with the zeros of e_p add nothing).  A sweep of 32 columns costs 42 ms / P at
 // N=200000 - a third of a configs[2] solve on several GPUs; this costs the reduce-scatter of 2 x N x 16 doubles.
-int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst) {
+int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst, double* h0) {
   CHK(need_comm(e));
   if (!e->sym_wpart) {
     HIPCHK(pool_malloc(&e->sym_wpart, sizeof(double) * (size_t)e->nranks * (size_t)e->nslab * 64));
@@ -400,11 +400,15 @@ int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst) {
     for (int g = 0; g < npair; ++g)
       launch_gather_columns_sym_rs(e->stream, o.a, e->sym.row_off, e->n, e->nslab, total_rows, e->idx_dev + c + 16 * g, std::min(16, kk - 16 * g),
                                    e->sym_wpart + (size_t)g * (size_t)total_rows * 16);
+    // h0 (dav_init_basis): the entries (idx_i, idx_j) this rank holds, summed over the ranks by an all-reduce that is a member of the
+    // first reduce-scatter's group - V0^T W0 without a collective (and a Gram product) of its own
+    if (h0 && c == 0) launch_entries_sym(e->stream, o.a, e->sym.row_off, e->idx_dev, ncols, h0);
     CollGroup grp(e);
     CHK(grp.begin(6, 8.0 * (double)e->nslab * kk * e->nranks));
     for (int g = 0; g < npair; ++g)
       CHK(coll_reduce_scatter(e, e->sym_wpart + (size_t)g * (size_t)total_rows * 16, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16,
                               (size_t)e->nslab * std::min(16, kk - 16 * g)));
+    if (h0 && c == 0) CHK(coll_allreduce(e, h0, (size_t)ncols * ncols));
     CHK(grp.end("reduce-scatter of the gathered columns", e->stream));
     for (int g = 0; g < npair; ++g)
       launch_chunk_to_panel(e->stream, e->sym_wrecv + (size_t)g * (size_t)e->nslab * 16, e->nslab, e->nloc, e->nloc_pad, std::min(16, kk - 16 * g),

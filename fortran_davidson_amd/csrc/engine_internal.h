@@ -227,6 +227,13 @@ struct dav_engine {
   long iter_hint = -1;            // outer iteration the driver is in (dav_ranks_agree), for the watchdog's message
   std::vector<double> agree_words;   // dav_agree_next: the driver's control words, riding on the next all-reduced small result
   double* agree_pin = nullptr;       // pinned staging of those words (16 x nranks doubles)
+  // H0 = V0^T (Op V0) of the unit columns of dav_init_basis is the operator's entries at (idx_i, idx_j): several ranks of dealt-out
+  // tiles sum what each holds of them in the SAME grouped collective that reduce-scatters W0 (one collective per solve fewer);
+  // h0_cols is what dav_init_basis left for the dav_project(0, ncols) that follows it - every other API call drops it (bind)
+  double* h0_dev = nullptr;          // 2 x h0_cap x h0_cap (operator A, operator B)
+  double* h0_host = nullptr;
+  int h0_cap = 0, h0_cols = 0, h0_take = 0;
+  int h0_kind[2] = {0, 0};           // per operator: 0 none, 1 summed entries in the stash, 2 identity
   hipStream_t comm_stream = nullptr;
   bool ov_ready = false;          // stream, events and buffers of apply_sym_overlapped all exist
   hipEvent_t ov_packed[2] = {nullptr, nullptr}, ov_gathered[2] = {nullptr, nullptr}, ov_reduced[2] = {nullptr, nullptr},
@@ -393,7 +400,7 @@ void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const SymPlan* pl, con
 int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, double* dst, bool timed, bool inner);
 int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed, bool inner = false);
 int apply_impl(E* e, int which, int src_panel, int c0, int k, int dst_panel, int d0, bool timed);
-int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst);
+int gather_columns_sym_multi(E* e, OpDesc& o, int ncols, double* dst, double* h0 = nullptr);
 // ---- engine_solver.hip -----------------------------------------------------------------------------------
 double* result_target(E* e);
 int result_fetch(E* e, size_t count);

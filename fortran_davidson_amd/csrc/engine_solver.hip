@@ -87,11 +87,26 @@ extern "C" int dav_gram(dav_handle_t e, int panel_p, int p0, int p, int panel_q,
 
 extern "C" int dav_project(dav_handle_t e, int c0, int k, double* H, int64_t ldh, double* S, int64_t lds) {
   CHK(bind(e));
+  const int h0_take = e->h0_take;
   int mt = c0 + k;
   CHK(check_panel(e, DAV_PANEL_V, 0, mt));
   if (k <= 0 || (H && ldh < mt)) return fail("dav_project: bad shape");
   const bool both = e->gev && (S != nullptr || (!H && e->rr_on));
   if (both && S && lds < mt) return fail("dav_project: bad shape");
+  if (h0_take > 0 && c0 == 0 && k == h0_take && H && !e->rr_on) {
+    // the projection of the unit columns dav_init_basis has just set up: it summed the operators' entries (idx_i, idx_j) over the
+    // ranks inside the reduce-scatter of W0 - no Gram product, no collective here
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t h0_blk = (size_t)e->h0_cap * e->h0_cap;
+    for (int pass = 0; pass < (both ? 2 : 1); ++pass) {
+      double* out = pass == 0 ? H : S;
+      const int64_t ld = pass == 0 ? ldh : lds;
+      for (int j = 0; j < k; ++j)
+        for (int i = 0; i < k; ++i)
+          out[j * ld + i] = e->h0_kind[pass] == 2 ? (i == j ? 1.0 : 0.0) : e->h0_host[pass * h0_blk + (size_t)j * k + i];
+    }
+    return 0;
+  }
   const size_t blk = (size_t)mt * k;
   if ((both ? 2 : 1) * blk > e->gram_doubles) return fail("gram result exceeds engine capacity");
   if (gram_scratch_doubles(mt, k, e->nloc_pad) > e->scratch_doubles) return fail("gram scratch too small");
@@ -200,18 +215,29 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
   HIPCHK(hipMemcpyAsync(e->idx_dev, order.data(), sizeof(int64_t) * ncols, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   launch_unit_columns(e->stream, e->idx_dev, ncols, e->row0, e->nloc, e->nloc_pad, panel_ptr(e, DAV_PANEL_V, 0), e->ldp);
+  // several ranks of dealt-out tiles: H0 (S0) rides on the reduce-scatter of W0 (B V0); see h0_dev in engine_internal.h
+  const bool h0_try = e->nranks > 1 && !e->rr_on && ncols <= e->h0_cap && getenv("DAV_NO_H0") == nullptr;
+  const size_t h0_blk = (size_t)e->h0_cap * e->h0_cap;
+  e->h0_kind[0] = e->h0_kind[1] = 0;
   for (int w = 0; w < (e->gev ? 2 : 1); ++w) {
     OpDesc& o = e->op[w];
     int dst = w == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
     if (o.kind == DAV_KIND_DENSE && o.storage == 1 && e->nranks == 1)
       launch_gather_columns_sym(e->stream, o.a, e->sym.row_off, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
-    else if (o.kind == DAV_KIND_DENSE && o.storage == 1)
-      CHK(gather_columns_sym_multi(e, o, ncols, panel_ptr(e, dst, 0)));           // several ranks: one reduce-scatter instead of a sweep
+    else if (o.kind == DAV_KIND_DENSE && o.storage == 1) {
+      CHK(gather_columns_sym_multi(e, o, ncols, panel_ptr(e, dst, 0), h0_try ? e->h0_dev + w * h0_blk : nullptr));   // several ranks: one reduce-scatter instead of a sweep
+      if (h0_try) {
+        HIPCHK(hipMemcpyAsync(e->h0_host + w * h0_blk, e->h0_dev + w * h0_blk, sizeof(double) * (size_t)ncols * ncols, hipMemcpyDeviceToHost, e->stream));
+        e->h0_kind[w] = 1;
+      }
+    }
     else if (o.kind == DAV_KIND_DENSE && o.storage == 0)
       launch_gather_columns(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
-    else if (o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS || o.kind == DAV_KIND_IDENTITY)
+    else if (o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS || o.kind == DAV_KIND_IDENTITY) {
       // a generated operator's columns are generated: N x ncols entries instead of a sweep of N^2 / 2 (configs[4]: one sweep in five)
       launch_gather_columns_free(e->stream, op_params(o), e->row0, e->nloc, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
+      if (o.kind == DAV_KIND_IDENTITY) e->h0_kind[w] = 2;                          // V0^T I V0 = I (distinct unit columns)
+    }
     else if (o.kind == DAV_KIND_HOST) {
       /* the driver fills W / BV through dav_panel_put */
     } else
@@ -221,6 +247,8 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
   if (idx_out)
     for (int i = 0; i < ncols; ++i) idx_out[i] = order[i] + 1;
   HIPCHK(hipGetLastError());
+  // valid for the call that follows: H0 from the stash, and for a generalized problem S0 from the stash or the identity
+  if (h0_try && e->h0_kind[0] == 1 && (!e->gev || e->h0_kind[1] != 0)) e->h0_cols = ncols;
   return 0;
 }
 

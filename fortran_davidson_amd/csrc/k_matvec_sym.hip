@@ -406,6 +406,15 @@ void launch_gather_columns_sym_rs(hipStream_t st, const double* tiles, const int
                      chunk_rows, total_rows, idx_dev, k, dst);
 }
 
+__global__ void entries_sym_kernel(const double* __restrict__ tiles, const int64_t* __restrict__ row_off, const int64_t* __restrict__ idx, int k,
+                                   double* __restrict__ h0) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < k * k) h0[t] = sym_entry(tiles, row_off, idx[t % k], idx[t / k]);
+}
+void launch_entries_sym(hipStream_t st, const double* tiles, const int64_t* row_off, const int64_t* idx_dev, int k, double* h0) {
+  hipLaunchKernelGGL(entries_sym_kernel, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, st, tiles, row_off, idx_dev, k, h0);
+}
+
 // Upload path of a host matrix into symmetric tiles: block column J arrives as ONE panel (rows J*256 .. n of its <= 256
 // columns, column-major with leading dimension ldp - a 2-D copy with long rows, which is what PCIe moves at full rate; a
 // tile-by-tile copy has 2 KB rows and runs at a third of it) and is cut into the tiles (I >= J, J) this rank stores.

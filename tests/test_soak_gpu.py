@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _free_mb():
+    """free device memory once the library has handed back what its buffer cache keeps of destroyed engines (dav_free_buffers)"""
     import torch
+    fd.free_buffers()
     torch.cuda.synchronize()
     return torch.cuda.mem_get_info()[0] / 2**20
 
