@@ -215,33 +215,40 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
   HIPCHK(hipMemcpyAsync(e->idx_dev, order.data(), sizeof(int64_t) * ncols, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   launch_unit_columns(e->stream, e->idx_dev, ncols, e->row0, e->nloc, e->nloc_pad, panel_ptr(e, DAV_PANEL_V, 0), e->ldp);
-  // several ranks of dealt-out tiles: H0 (S0) rides on the reduce-scatter of W0 (B V0); see h0_dev in engine_internal.h
-  const bool h0_try = e->nranks > 1 && !e->rr_on && ncols <= e->h0_cap && getenv("DAV_NO_H0") == nullptr;
+  // H0 = V0^T (Op V0) of unit columns is the operator's entries (idx_i, idx_j): read / generated here instead of a Gram product over
+  // N rows in dav_project; several ranks of dealt-out tiles sum what each holds of them inside the reduce-scatter group of W0
+  // (h0_dev in engine_internal.h), a generated operator's entries every rank generates for itself - no collective for H0 either way
+  const bool h0_try = !e->rr_on && ncols <= e->h0_cap && getenv("DAV_NO_H0") == nullptr;
   const size_t h0_blk = (size_t)e->h0_cap * e->h0_cap;
   e->h0_kind[0] = e->h0_kind[1] = 0;
   for (int w = 0; w < (e->gev ? 2 : 1); ++w) {
     OpDesc& o = e->op[w];
     int dst = w == 0 ? DAV_PANEL_W : DAV_PANEL_BV;
-    if (o.kind == DAV_KIND_DENSE && o.storage == 1 && e->nranks == 1)
+    double* h0 = h0_try ? e->h0_dev + w * h0_blk : nullptr;
+    bool stashed = false;
+    if (o.kind == DAV_KIND_DENSE && o.storage == 1 && e->nranks == 1) {
       launch_gather_columns_sym(e->stream, o.a, e->sym.row_off, e->n, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
-    else if (o.kind == DAV_KIND_DENSE && o.storage == 1) {
-      CHK(gather_columns_sym_multi(e, o, ncols, panel_ptr(e, dst, 0), h0_try ? e->h0_dev + w * h0_blk : nullptr));   // several ranks: one reduce-scatter instead of a sweep
-      if (h0_try) {
-        HIPCHK(hipMemcpyAsync(e->h0_host + w * h0_blk, e->h0_dev + w * h0_blk, sizeof(double) * (size_t)ncols * ncols, hipMemcpyDeviceToHost, e->stream));
-        e->h0_kind[w] = 1;
-      }
-    }
-    else if (o.kind == DAV_KIND_DENSE && o.storage == 0)
+      if (h0) { launch_entries_sym(e->stream, o.a, e->sym.row_off, e->idx_dev, ncols, h0); stashed = true; }
+    } else if (o.kind == DAV_KIND_DENSE && o.storage == 1) {
+      CHK(gather_columns_sym_multi(e, o, ncols, panel_ptr(e, dst, 0), h0));       // several ranks: one reduce-scatter instead of a sweep
+      stashed = h0 != nullptr;
+    } else if (o.kind == DAV_KIND_DENSE && o.storage == 0) {
       launch_gather_columns(e->stream, o.a, e->nloc_pad, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
-    else if (o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS || o.kind == DAV_KIND_IDENTITY) {
+      if (h0 && e->nranks == 1) { launch_entries_dense(e->stream, o.a, e->nloc_pad, e->idx_dev, ncols, h0); stashed = true; }
+    } else if (o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS || o.kind == DAV_KIND_IDENTITY) {
       // a generated operator's columns are generated: N x ncols entries instead of a sweep of N^2 / 2 (configs[4]: one sweep in five)
       launch_gather_columns_free(e->stream, op_params(o), e->row0, e->nloc, e->nloc_pad, e->idx_dev, ncols, panel_ptr(e, dst, 0), e->ldp);
       if (o.kind == DAV_KIND_IDENTITY) e->h0_kind[w] = 2;                          // V0^T I V0 = I (distinct unit columns)
+      else if (h0) { launch_entries_free(e->stream, op_params(o), e->idx_dev, ncols, h0); stashed = true; }
     }
     else if (o.kind == DAV_KIND_HOST) {
       /* the driver fills W / BV through dav_panel_put */
     } else
       CHK(apply_impl(e, w, DAV_PANEL_V, 0, ncols, dst, 0, false));
+    if (stashed) {
+      HIPCHK(hipMemcpyAsync(e->h0_host + w * h0_blk, h0, sizeof(double) * (size_t)ncols * ncols, hipMemcpyDeviceToHost, e->stream));
+      e->h0_kind[w] = 1;
+    }
   }
   e->m = ncols;
   if (idx_out)

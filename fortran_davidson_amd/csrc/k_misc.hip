@@ -87,6 +87,29 @@ void launch_gather_columns_free(hipStream_t st, OpParams op, int64_t row0, int64
                      idx_dev, dst, ldd);
 }
 
+// V0^T (Op V0) for unit columns V0 = e_idx is the operator's entries: h0[i + j * k] = Op(idx[i], idx[j]).  Generated operator: every
+// rank generates all of them; full rows of ONE rank: read from the matrix.
+__global__ void entries_free_kernel(OpParams op, const int64_t* __restrict__ idx, int k, double* __restrict__ h0) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= k * k) return;
+  const int64_t gi = idx[t % k], gj = idx[t / k];
+  double v;
+  if (op.kind == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
+  else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op.e_table, op.trig, gi, gj);
+  else v = gi == gj ? 1.0 : 0.0;
+  h0[t] = v;
+}
+void launch_entries_free(hipStream_t st, OpParams op, const int64_t* idx_dev, int k, double* h0) {
+  hipLaunchKernelGGL(entries_free_kernel, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, st, op, idx_dev, k, h0);
+}
+__global__ void entries_dense_kernel(const double* __restrict__ A, int64_t lda, const int64_t* __restrict__ idx, int k, double* __restrict__ h0) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < k * k) h0[t] = A[idx[t / k] * lda + idx[t % k]];
+}
+void launch_entries_dense(hipStream_t st, const double* A, int64_t lda, const int64_t* idx_dev, int k, double* h0) {
+  hipLaunchKernelGGL(entries_dense_kernel, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, st, A, lda, idx_dev, k, h0);
+}
+
 __global__ void unit_columns_kernel(const int64_t* __restrict__ idx, int64_t row0, int64_t nloc, int64_t nrows_pad,
                                     double* __restrict__ dst, int64_t ldd) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
