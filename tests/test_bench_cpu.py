@@ -34,7 +34,7 @@ def test_scaling_model_from_the_one_gpu_rehearsal_of_eight_ranks():
     eight = bench.scaling_model(200000, 16, 8)
     assert eight["speedup_symmetric_all_links"] >= 6.0
     assert 5.0 <= eight["speedup_symmetric"] < eight["speedup_symmetric_overlapped"] < eight["speedup_symmetric_all_links"]
-    assert eight["inputs"]["collectives_per_solve"] <= 11
+    assert eight["inputs"]["collectives_per_solve"] <= 10
     # inputs measured in the run itself take precedence (a faster box scales the per-rank times)
     fast = bench.scaling_model(200000, 16, 8, {"apply_ms": 0.9 * bench.rehearsal_inputs()[1]["apply_local_ms"], "host_ms": 1.0, "ms_per_solve": 113.0})
     assert fast["inputs"]["per_rank_sweeps_end_to_end_ms"] < eight["inputs"]["per_rank_sweeps_end_to_end_ms"]
