@@ -69,7 +69,7 @@ __device__ __forceinline__ double dav_harness_entry(const double* __restrict__ e
 }
 
 enum { DAV_KIND_NONE = 0, DAV_KIND_DENSE = 1, DAV_KIND_HASHED = 2, DAV_KIND_HARNESS = 3,
-       DAV_KIND_IDENTITY = 4, DAV_KIND_HOST = 5 };
+       DAV_KIND_IDENTITY = 4, DAV_KIND_HOST = 5, DAV_KIND_DEVICE = 6 };
 
 struct OpParams {          // passed by value to the matrix-free kernels
   int kind;

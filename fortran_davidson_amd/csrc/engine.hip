@@ -512,6 +512,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   lt.lap("sym_set");
   pool_free(e->sym_wpart);
   pool_free(e->coll_stage);
+  pool_free(e->cb_x);
   pool_free(e->sym_wrecv);
   for (int i = 0; i < N_SMALL; ++i)
     if (e->sm[i].done) hipEventDestroy(e->sm[i].done);
@@ -611,6 +612,20 @@ extern "C" int dav_panel_get(dav_handle_t e, int panel, int c0, int k, double* o
     }
     HIPCHK(hipStreamSynchronize(e->stream));
   }
+  return 0;
+}
+
+extern "C" int dav_panel_unit_column(dav_handle_t e, int panel, int col, int k) {
+  CHK(bind(e));
+  CHK(check_panel(e, panel, col, 1));
+  if (k < 0) return fail("dav_panel_unit_column: bad index");
+  if ((size_t)k >= e->basis_order.size()) return 1;                       // not an error: the caller falls back to another direction
+  const int64_t idx = e->basis_order[(size_t)k];
+  int64_t* slot = e->idx_dev + (e->cols_alloc - 1);                        // (dav_init_basis uses the front of idx_dev; stream order keeps them apart)
+  HIPCHK(hipMemcpyAsync(slot, &idx, sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));                                 // idx is a local
+  launch_unit_columns(e->stream, slot, 1, e->row0, e->nloc, e->nloc_pad, panel_ptr(e, panel, col), e->ldp);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -324,6 +324,37 @@ int apply_ptr(E* e, int which, const double* src, int k, double* dst, bool timed
     return 0;
   }
   CHK(need_comm(e));
+  if (o.kind == DAV_KIND_DEVICE) {
+    // the caller's kernel(s): the block as ONE column-major matrix of all n rows (several ranks: gathered column by column in one
+    // grouped collective - slab r of a column is rows [r * nslab, (r + 1) * nslab)), the result straight into this rank's panel rows
+    const double* x = src;
+    int64_t ldx = e->ldp;
+    int slot = -1;
+    if (timed) CHK(timed_begin(e, which == DAV_OP_A ? 0 : 2, 16.0 * (double)e->n * k, &slot));
+    if (has_comm(e)) {
+      ldx = (int64_t)e->nranks * e->nslab;
+      const size_t need = (size_t)ldx * k;
+      if (need > e->cb_x_doubles) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->cb_x) HIPCHK(pool_free(e->cb_x));
+        e->cb_x = nullptr; e->cb_x_doubles = 0;
+        HIPCHK(pool_malloc(&e->cb_x, sizeof(double) * need));
+        e->cb_x_doubles = need;
+      }
+      CollGroup grp(e);
+      CHK(grp.begin(5, 8.0 * (double)e->nslab * k * e->nranks));
+      for (int c = 0; c < k; ++c) CHK(coll_allgather(e, src + (int64_t)c * e->ldp, e->cb_x + (int64_t)c * ldx, (size_t)e->nslab));
+      CHK(grp.end("all-gather of the new block", e->stream));
+      x = e->cb_x;
+    }
+    const int rc = o.dev_fn(o.dev_ctx, (void*)e->stream, e->n, e->row0, e->nloc, k, x, ldx, dst, e->ldp);
+    if (rc != 0) return fail("dav_apply: the caller's device operator returned " + std::to_string(rc));
+    launch_zero_pad_rows(e->stream, dst, e->ldp, e->nloc, e->nloc_pad, k);     // the panels' padding rows stay zero whatever the callback left there
+    CHK(timed_end(e, slot));
+    if (which == DAV_OP_A) { e->st.applies += 1; e->st.apply_cols += k; }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if ((o.kind == DAV_KIND_DENSE || o.kind == DAV_KIND_HASHED || o.kind == DAV_KIND_HARNESS) && o.storage == 1) {
     // A generated second operator whose tiles (partly) fit next to everything else is kept resident for its longest block rows
     // (configs[3]: B = the unit-diagonal generator next to a stored A): those rows run the stored kernels - half the time per

@@ -138,6 +138,9 @@ struct OpDesc {
   bool pass_res = false, pass_gen = false;   // the passes every rank makes (agreed on across the ranks when the split was made)
   SymSet* res = nullptr;            // work lists over the resident block rows (tiles at res_a) ...
   SymSet* gen = nullptr;            // ... and over the generated ones
+  // DAV_KIND_DEVICE: the caller's own block apply on device memory (dav_set_operator_device)
+  dav_device_apply_fn dev_fn = nullptr;
+  void* dev_ctx = nullptr;
 };
 
 struct SmallBuf {            // device small matrix + pinned staging
@@ -231,6 +234,8 @@ struct dav_engine {
   // tiles sum what each holds of them in the SAME grouped collective that reduce-scatters W0 (one collective per solve fewer);
   // h0_cols is what dav_init_basis left for the dav_project(0, ncols) that follows it - every other API call drops it (bind)
   double* h0_dev = nullptr;          // 2 x h0_cap x h0_cap (operator A, operator B)
+  double* cb_x = nullptr;            // several ranks, DAV_KIND_DEVICE: the gathered block, column-major (nranks * nslab) x k
+  size_t cb_x_doubles = 0;
   double* h0_host = nullptr;
   int h0_cap = 0, h0_cols = 0, h0_take = 0;
   int h0_kind[2] = {0, 0};           // per operator: 0 none, 1 summed entries in the stash, 2 identity

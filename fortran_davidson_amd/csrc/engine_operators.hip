@@ -554,6 +554,16 @@ extern "C" int dav_set_operator_host(dav_handle_t e, int which, const double* di
   return 0;
 }
 
+extern "C" int dav_set_operator_device(dav_handle_t e, int which, dav_device_apply_fn fn, void* ctx, const double* diag) {
+  if (which < 0 || which > 1 || !diag || !fn) return fail("dav_set_operator_device: bad arguments");
+  CHK(dav_set_operator_host(e, which, diag));          // the diagonal: device slab, host copy, start-vector order
+  OpDesc& o = e->op[which];
+  o.kind = DAV_KIND_DEVICE;
+  o.dev_fn = fn;
+  o.dev_ctx = ctx;
+  return 0;
+}
+
 extern "C" int dav_get_diagonal(dav_handle_t e, int which, double* out) {
   if (which < 0 || which > 1 || e->diag_host[which].empty()) return fail("dav_get_diagonal: operator not set");
   std::memcpy(out, e->diag_host[which].data(), sizeof(double) * e->n);

@@ -110,6 +110,15 @@ void launch_entries_dense(hipStream_t st, const double* A, int64_t lda, const in
   hipLaunchKernelGGL(entries_dense_kernel, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, st, A, lda, idx_dev, k, h0);
 }
 
+__global__ void zero_pad_rows_kernel(double* __restrict__ dst, int64_t ldd, int64_t nloc, int64_t nrows_pad) {
+  const int64_t i = nloc + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nrows_pad) dst[(int64_t)blockIdx.y * ldd + i] = 0.0;
+}
+void launch_zero_pad_rows(hipStream_t st, double* dst, int64_t ldd, int64_t nloc, int64_t nrows_pad, int k) {
+  if (nrows_pad <= nloc || k <= 0) return;
+  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3((unsigned)((nrows_pad - nloc + 255) / 256), k), dim3(256), 0, st, dst, ldd, nloc, nrows_pad);
+}
+
 __global__ void unit_columns_kernel(const int64_t* __restrict__ idx, int64_t row0, int64_t nloc, int64_t nrows_pad,
                                     double* __restrict__ dst, int64_t ldd) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -163,6 +163,7 @@ void launch_gather_columns_sym_rs(hipStream_t st, const double* tiles, const int
                                   int64_t total_rows, const int64_t* idx_dev, int k, double* dst);
 // h0[i + j * k] = what this rank's tiles hold of the operator's entry (idx[i], idx[j]) (0 where another rank stores it)
 void launch_entries_sym(hipStream_t st, const double* tiles, const int64_t* row_off, const int64_t* idx_dev, int k, double* h0);
+void launch_zero_pad_rows(hipStream_t st, double* dst, int64_t ldd, int64_t nloc, int64_t nrows_pad, int k);
 void launch_entries_free(hipStream_t st, OpParams op, const int64_t* idx_dev, int k, double* h0);
 void launch_entries_dense(hipStream_t st, const double* A, int64_t lda, const int64_t* idx_dev, int k, double* h0);
 void launch_gather_columns_free(hipStream_t st, OpParams op, int64_t row0, int64_t nloc, int64_t nrows_pad, const int64_t* idx_dev, int k,

@@ -13,6 +13,10 @@ PANEL_V, PANEL_W, PANEL_BV, PANEL_X, PANEL_R, PANEL_S = range(6)
 METHOD_DPR, METHOD_GJD = 0, 1
 
 
+# int fn(ctx, hip_stream, n, row0, nloc, k, x_dev, ldx, y_dev, ldy) - include/davidson_hip.h: dav_device_apply_fn
+DEVICE_APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64)
+
+
 class DavidsonHipError(RuntimeError):
     pass
 
@@ -32,7 +36,7 @@ class Stats(C.Structure):
                 ("b_stored_launches", C.c_int64), ("b_generated_launches", C.c_int64)]
 
 
-ABI_VERSION = 105      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
+ABI_VERSION = 106      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
 
 
 def _dp(a):
@@ -170,6 +174,14 @@ class CEngine:
     def set_operator_host(self, which, diag):
         d = np.ascontiguousarray(diag, dtype=np.float64)
         self._chk(self.lib.dav_set_operator_host(self.h, C.c_int(which), _dp(d)))
+
+    def set_operator_device(self, which, fn, ctx, diag):
+        """The caller's own block apply on device memory (dav_device_apply_fn): `fn` a ctypes function pointer (DEVICE_APPLY_FN or a
+        symbol of a loaded library), `ctx` an integer / c_void_p passed through, `diag` the operator's diagonal (n)."""
+        d = np.ascontiguousarray(diag, dtype=np.float64)
+        self._device_ops = getattr(self, "_device_ops", {})
+        self._device_ops[which] = (fn, ctx)                # keep the callback alive as long as the engine
+        self._chk(self.lib.dav_set_operator_device(self.h, C.c_int(which), C.cast(fn, C.c_void_p), C.c_void_p(ctx if isinstance(ctx, int) else C.cast(ctx, C.c_void_p).value), _dp(d)))
 
     def get_diagonal(self, which):
         d = np.zeros(self.n)

@@ -24,7 +24,7 @@ module davidson_device
        engine_read_matrix, engine_dense_begin, engine_dense_put_rows, engine_dense_end, &
        engine_set_correction_policy, &
        engine_generate_diagonal_dominant, engine_set_hashed_operator, engine_set_harness_operator, &
-       engine_set_identity, engine_comm_unique_id, engine_comm_init, &
+       engine_set_identity, engine_set_device_operator, engine_comm_unique_id, engine_comm_init, &
        generalized_eigensolver_device, davidson_device_loop, basis_capacity, davidson_free_buffers
 
   !> Handle of a device-resident problem: operators A (and B) plus all work panels in HBM.
@@ -402,6 +402,23 @@ contains
     integer, intent(in) :: which
     call check_dav(dav_set_operator_identity(eng%h, int(which - 1, c_int)), "dav_set_operator_identity")
   end subroutine engine_set_identity
+
+  !> The caller's OWN operator as a block apply on device memory: the device counterpart of the reference's matrix-free interface
+  !> (src/davidson.f90:277-337 takes a procedure on host arrays).  `fn` = c_funloc of a bind(C) function with the signature
+  !> dav_device_apply_fn of include/davidson_hip.h - it enqueues Y = Op(row0 : row0 + nloc, :) X on the stream it is handed (its own
+  !> HIP kernels, hipBLAS, ...) - `ctx` is passed through to it, `diag` is the operator's diagonal (n entries).
+  subroutine engine_set_device_operator(eng, which, fn, ctx, diag)
+    type(davidson_engine), intent(inout) :: eng
+    integer, intent(in) :: which
+    type(c_funptr), intent(in) :: fn
+    type(c_ptr), intent(in) :: ctx
+    real(dp), intent(in) :: diag(:)
+    if (size(diag) /= eng%n) then
+       print *, "engine_set_device_operator: diag must have n entries"
+       error stop
+    end if
+    call check_dav(dav_set_operator_device(eng%h, int(which - 1, c_int), fn, ctx, diag), "dav_set_operator_device")
+  end subroutine engine_set_device_operator
 
   !> Solve with the operators already resident behind `eng` (third specific of the generic).
   !> Argument meaning as generalized_eigensolver_dense; `eigenvectors` is optional so that a
@@ -1179,14 +1196,17 @@ contains
     logical, intent(in), optional :: only_first
     integer, intent(out), optional :: last_pass
     integer, intent(in), optional :: first_pass
-    integer, parameter :: max_pass = 6
+    integer, parameter :: max_pass = 8
     real(dp), allocatable :: c(:, :), g(:, :), mm(:, :), vec(:)
     logical, allocatable :: null_cols(:)
-    integer :: pass, j, nnull, pass0
+    integer, allocatable :: tries(:), queue(:)
+    integer :: pass, j, nnull, pass0, nqueue, qpos
+    integer(c_int) :: ierr
     real(dp) :: wmax, wmin
     logical :: clean, stop_early
 
-    allocate(c(max(m, 1), kt), g(kt, kt), mm(kt, kt), null_cols(kt))
+    allocate(c(max(m, 1), kt), g(kt, kt), mm(kt, kt), null_cols(kt), tries(kt))
+    tries = 0
     clean = .false.
     stop_early = .false.
     if (present(only_first)) stop_early = only_first
@@ -1204,13 +1224,44 @@ contains
        call ortho_pass_transform(pass, m, kt, c, g, mm, wmin, wmax, null_cols, nnull)
        if (nnull > 0) then
           ! replace numerically null columns and repeat the pass
+          ! first the unit vector at the next entry of the start order (the (m + j)-th smallest diagonal entry: the direction the
+          ! initial guess would have taken next, and what the reference's Householder QR leaves in such a column when the diagonal
+          ! ascends with the index); a column that comes back null gets a pseudo-random vector
+          ! (a column whose own entry comes back null - it lay in the span of the healthy columns - takes the entries of THEIR
+          ! slots next, then the entries behind the block)
+          if (.not. allocated(queue)) then
+             allocate(queue(2 * kt))
+             nqueue = 0
+             do j = 1, kt
+                if (.not. null_cols(j)) then
+                   nqueue = nqueue + 1
+                   queue(nqueue) = m + j - 1
+                end if
+             end do
+             do j = 1, kt
+                nqueue = nqueue + 1
+                queue(nqueue) = m + kt + j - 1
+             end do
+             qpos = 0
+          end if
           do j = 1, kt
              if (null_cols(j)) then
-                allocate(vec(n))
-                call pseudo_random_vector(vec, m + j + 7919 * pass)
-                call check_dav(dav_panel_put(h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(n, c_int64_t)), &
-                     "dav_panel_put")
-                deallocate(vec)
+                tries(j) = tries(j) + 1
+                ierr = 1_c_int
+                if (tries(j) == 1) then
+                   ierr = dav_panel_unit_column(h, DAV_PANEL_V, int(m + j - 1, c_int), int(m + j - 1, c_int))
+                else if (tries(j) <= 3 .and. qpos < nqueue) then
+                   qpos = qpos + 1
+                   ierr = dav_panel_unit_column(h, DAV_PANEL_V, int(m + j - 1, c_int), int(queue(qpos), c_int))
+                end if
+                if (ierr /= 0_c_int .and. ierr /= 1_c_int) call check_dav(ierr, "dav_panel_unit_column")
+                if (ierr /= 0_c_int) then
+                   allocate(vec(n))
+                   call pseudo_random_vector(vec, m + j + 7919 * pass)
+                   call check_dav(dav_panel_put(h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(n, c_int64_t)), &
+                        "dav_panel_put")
+                   deallocate(vec)
+                end if
              end if
           end do
           cycle
@@ -1259,7 +1310,7 @@ contains
     real(dp), intent(out) :: mm(kt, kt), wmin, wmax
     logical, intent(out) :: null_cols(kt)
     integer, intent(out) :: nnull
-    real(dp), parameter :: floor_rel = 1.0e-14_dp
+    real(dp), parameter :: floor_rel = 1.0e-14_dp, again_rel = 1.0e-10_dp
     real(dp), allocatable :: gp(:, :), d(:), w(:), u(:, :)
     integer :: j, l, info
     logical :: chol_ok
@@ -1279,6 +1330,12 @@ contains
     nnull = 0
     do j = 1, kt
        null_cols(j) = .not. (gp(j, j) > tiny(1.0_dp) * 1.0e16_dp)
+       ! "twice is enough": a column that a pass has already orthogonalised and normalised, and that loses five digits of its norm
+       ! to V AGAIN, lies in span(V) to working precision - what is left of it is rounding noise.  (Corrections confined to the span
+       ! of the basis and a few more rows - banded or block-structured operators: t = r / (theta - d) has the support of r - never
+       ! leave it however often they are projected and rescaled; the reference's Householder QR completes the basis with arbitrary
+       ! orthonormal columns there, src/davidson.f90:197-215, this driver with pseudo-random ones.)
+       if (pass >= 2 .and. .not. null_cols(j)) null_cols(j) = gp(j, j) < again_rel * g(j, j)
        if (null_cols(j)) nnull = nnull + 1
     end do
     if (nnull > 0) return
@@ -1338,6 +1395,12 @@ contains
           wmin = 1.0_dp / (wmax * wmax)
           wmax = wmin * 1.0e8_dp
        else
+          if (pass >= 2) then
+             ! ... and the same for columns that depend on EACH OTHER after a pass has already orthonormalised the block: those the
+             ! pivoted factorisation cannot reach (remaining pivot below again_rel) are replaced, not rescaled
+             call dependent_columns(gp, kt, again_rel, null_cols, nnull)
+             if (nnull > 0) return
+          end if
           call lapack_rayleigh_ritz(gp, w, u, kt)
           wmax = maxval(w)
           wmin = minval(w)
@@ -1352,6 +1415,53 @@ contains
        end if
     end if
   end subroutine ortho_pass_transform
+
+  !> Greedy pivoted Cholesky of a Gram block with unit diagonal: the columns whose remaining pivot falls below thr once the larger
+  !> ones are eliminated depend on those to working precision (dep, ndep).
+  subroutine dependent_columns(gs, kt, thr, dep, ndep)
+    integer, intent(in) :: kt
+    real(dp), intent(in) :: gs(kt, kt), thr
+    logical, intent(out) :: dep(kt)
+    integer, intent(out) :: ndep
+    real(dp) :: l(kt, kt), rem(kt), piv
+    logical :: done(kt)
+    integer :: step, i, jmax
+    l = 0.0_dp
+    done = .false.
+    dep = .false.
+    ndep = 0
+    do i = 1, kt
+       rem(i) = gs(i, i)
+    end do
+    do step = 1, kt
+       jmax = 0
+       do i = 1, kt
+          if (done(i)) cycle
+          if (jmax == 0) then
+             jmax = i
+          else if (rem(i) > rem(jmax)) then
+             jmax = i
+          end if
+       end do
+       if (.not. (rem(jmax) >= thr)) then
+          do i = 1, kt
+             if (.not. done(i)) then
+                dep(i) = .true.
+                ndep = ndep + 1
+             end if
+          end do
+          return
+       end if
+       done(jmax) = .true.
+       piv = sqrt(rem(jmax))
+       l(jmax, step) = piv
+       do i = 1, kt
+          if (done(i)) cycle
+          l(i, step) = (gs(i, jmax) - dot_product(l(i, 1:step - 1), l(jmax, 1:step - 1))) / piv
+          rem(i) = rem(i) - l(i, step)**2
+       end do
+    end do
+  end subroutine dependent_columns
 
   !> yk (m x kt) <- yk * M with M = G^(-1/2)-like (Cholesky R^-1, or the eigen-decomposition route with an eigenvalue
   !> floor when the factor is ill-conditioned), G = yk^T yk: the columns of the result are Euclidean-orthonormal.

@@ -28,7 +28,7 @@ module davidson_hip_c
   end type dav_stats
   !> DAV_HIP_ABI_VERSION of include/davidson_hip.h these interfaces were written against: engine_create checks that the
   !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101, 102 and 104)
-  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 105
+  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 106
 
   interface
      function dav_last_error() bind(C, name="dav_last_error") result(p)
@@ -153,6 +153,16 @@ module davidson_hip_c
        import :: c_ptr, c_int
        type(c_ptr), value :: h
        integer(c_int), value :: which
+       integer(c_int) :: ierr
+     end function
+     !> the caller's own block apply on device memory (include/davidson_hip.h: dav_device_apply_fn); fn = c_funloc of a bind(C) function
+     function dav_set_operator_device(h, which, fn, ctx, diag) bind(C, name="dav_set_operator_device") result(ierr)
+       import :: c_ptr, c_int, c_funptr, c_double
+       type(c_ptr), value :: h
+       integer(c_int), value :: which
+       type(c_funptr), value :: fn
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: diag(*)
        integer(c_int) :: ierr
      end function
      function dav_set_operator_host(h, which, diag) bind(C, name="dav_set_operator_host") result(ierr)
@@ -389,6 +399,12 @@ module davidson_hip_c
        integer(c_int), value :: panel, c0, k
        real(c_double), intent(out) :: out(*)
        integer(c_int64_t), value :: ld
+       integer(c_int) :: ierr
+     end function
+     function dav_panel_unit_column(h, panel, col, k) bind(C, name="dav_panel_unit_column") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int), value :: panel, col, k
        integer(c_int) :: ierr
      end function
      function dav_panel_put(h, panel, c0, k, in, ld) bind(C, name="dav_panel_put") result(ierr)

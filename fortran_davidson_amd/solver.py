@@ -147,6 +147,10 @@ class DavidsonEngine:
     def set_identity(self, which):
         self._set_op(which, 3, 0, 0.0, None)
 
+    def set_device_operator(self, which, fn, ctx, diag):
+        """The caller's own operator as a block apply on device memory (engine_set_device_operator; which = 1 / 2)."""
+        self.c.set_operator_device(which - 1, fn, ctx, diag)
+
     def solve(self, method="DPR", max_iterations=1000, tolerance=1e-8, want_vectors=True):
         evals = np.zeros(self.lowest)
         evecs = np.zeros((self.n, self.lowest) if want_vectors else (1, 1), order="F")

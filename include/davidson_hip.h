@@ -83,9 +83,9 @@ typedef struct dav_stats {
 } dav_stats;
 
 /* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */
-/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next, 105 dav_free_buffers) must not    */
+/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next, 105 dav_free_buffers, 106 dav_set_operator_device) must not    */
 /* use the unsized call - the sized one, which copies at most `bytes` bytes, is safe across versions.   */
-#define DAV_HIP_ABI_VERSION 105
+#define DAV_HIP_ABI_VERSION 106
 const char* dav_last_error(void);
 int dav_version(void);
 
@@ -174,6 +174,16 @@ int dav_set_operator_identity(dav_handle_t h, int which);
  * src/davidson.f90:378-379): the driver moves blocks with dav_panel_get/put.  diag[n] is the
  * operator's diagonal (what extract_diagonal_free, src/davidson.f90:490-523, computes). */
 int dav_set_operator_host(dav_handle_t h, int which, const double* diag);
+/* The caller's OWN operator as a block apply on device memory - the device counterpart of the reference's matrix-free interface
+ * (src/davidson.f90:277-337: a procedure X(N,k) -> (N,k) on host arrays): for a caller who has the operator as a HIP kernel (a stencil,
+ * a sparse or structured product, ...) and wants the blocks to stay in HBM.  `fn` must ENQUEUE on `hip_stream` (a hipStream_t) the work
+ * that leaves  Y[0:nloc, 0:k] = Op[row0 : row0 + nloc, 0:n] * X[0:n, 0:k]  in y_dev (column-major, leading dimension ldy) - x_dev
+ * holds ALL n rows of the block (column-major, ldx; several ranks: the engine has all-gathered it), rows [row0, row0 + nloc) are this
+ * rank's slab (dav_local_rows) - and return 0; it must not synchronise the device.  diag: the operator's diagonal, n doubles on the
+ * host (the DPR preconditioner and the start vectors need it - src/davidson.f90:490-523 probes it with N unit vectors).  Since ABI 106. */
+typedef int (*dav_device_apply_fn)(void* ctx, void* hip_stream, int64_t n, int64_t row0, int64_t nloc, int k, const double* x_dev, int64_t ldx,
+                                   double* y_dev, int64_t ldy);
+int dav_set_operator_device(dav_handle_t h, int which, dav_device_apply_fn fn, void* ctx, const double* diag);
 int dav_get_diagonal(dav_handle_t h, int which, double* diag_out /* n, global */);
 
 /* ---- the per-iteration hot path ---------------------------------------------------------------- */
@@ -304,6 +314,11 @@ int dav_panel_transform(dav_handle_t h, int src_panel, int s0, int p, const doub
 int dav_panel_get(dav_handle_t h, int panel, int c0, int k, double* out, int64_t ld);
 /* panel[:, c0:c0+k] <- host(ld, k) holding all N rows (each rank keeps its slab) */
 int dav_panel_put(dav_handle_t h, int panel, int c0, int k, const double* in, int64_t ld);
+/* panel[:, col] <- the unit vector at the (k+1)-th smallest diagonal entry of operator A (the order dav_init_basis takes its start
+ * vectors from; k counts from 0).  What the driver completes a rank-deficient correction block with (the reference's Householder QR
+ * leaves unit vectors in such columns, src/davidson.f90:197-215).  Returns 1 - and leaves the column alone - when the engine keeps
+ * no (k+1)-th entry of that order.  Since ABI 106. */
+int dav_panel_unit_column(dav_handle_t h, int panel, int col, int k);
 int dav_set_width(dav_handle_t h, int m);
 
 #ifdef __cplusplus
