@@ -1200,7 +1200,9 @@ contains
     real(dp), allocatable :: c(:, :), g(:, :), mm(:, :), vec(:)
     logical, allocatable :: null_cols(:)
     integer, allocatable :: tries(:), queue(:)
-    integer :: pass, j, nnull, pass0, nqueue, qpos
+    integer :: pass, j, nnull, pass0, nqueue, qpos, rounds
+    integer, parameter :: max_rounds = 12
+    logical :: first_gram
     integer(c_int) :: ierr
     real(dp) :: wmax, wmin
     logical :: clean, stop_early
@@ -1213,17 +1215,28 @@ contains
     pass0 = 1
     if (present(first_pass)) pass0 = first_pass
     if (present(last_pass)) last_pass = pass0
-    do pass = pass0, max(max_pass, pass0 + 2)
-       if (pass == pass0 .and. present(c_first)) then
+    pass = pass0
+    rounds = 0
+    first_gram = .true.
+    do
+       if (first_gram .and. present(c_first)) then
           if (m > 0) c(1:m, :) = c_first
           g = g_first
        else
           call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
                int(kt, c_int64_t)), "dav_ortho_gram")
        end if
+       first_gram = .false.
        call ortho_pass_transform(pass, m, kt, c, g, mm, wmin, wmax, null_cols, nnull)
        if (nnull > 0) then
-          ! replace numerically null columns and repeat the pass
+          ! replace numerically null columns and repeat the pass (a replacement round is not a pass: however many rounds a block
+          ! needs, its passes are still to come; from the seventh round on every replacement is pseudo-random - generic vectors
+          ! cannot come back null as long as the basis is narrower than the space)
+          rounds = rounds + 1
+          if (rounds > max_rounds) then
+             print *, "generalized_eigensolver: no independent directions found for a correction block after ", max_rounds, " rounds"
+             error stop
+          end if
           ! first the unit vector at the next entry of the start order (the (m + j)-th smallest diagonal entry: the direction the
           ! initial guess would have taken next, and what the reference's Householder QR leaves in such a column when the diagonal
           ! ascends with the index); a column that comes back null gets a pseudo-random vector
@@ -1248,16 +1261,18 @@ contains
              if (null_cols(j)) then
                 tries(j) = tries(j) + 1
                 ierr = 1_c_int
-                if (tries(j) == 1) then
+                if (rounds == 1) then
                    ierr = dav_panel_unit_column(h, DAV_PANEL_V, int(m + j - 1, c_int), int(m + j - 1, c_int))
-                else if (tries(j) <= 3 .and. qpos < nqueue) then
+                else if (rounds <= 6 .and. qpos < nqueue) then
                    qpos = qpos + 1
                    ierr = dav_panel_unit_column(h, DAV_PANEL_V, int(m + j - 1, c_int), int(queue(qpos), c_int))
                 end if
                 if (ierr /= 0_c_int .and. ierr /= 1_c_int) call check_dav(ierr, "dav_panel_unit_column")
+                if (trace_iterations()) print "(a, i0, a, i0, a, i0, a, i0, a, l1)", "davidson trace: block at m=", m, " pass ", pass, " round ", rounds, &
+                     ": column ", j, " is numerically dependent; replaced by a unit vector: ", ierr == 0_c_int
                 if (ierr /= 0_c_int) then
                    allocate(vec(n))
-                   call pseudo_random_vector(vec, m + j + 7919 * pass)
+                   call pseudo_random_vector(vec, m + j + 7919 * (pass + 31 * rounds))
                    call check_dav(dav_panel_put(h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(n, c_int64_t)), &
                         "dav_panel_put")
                    deallocate(vec)
@@ -1276,6 +1291,8 @@ contains
           clean = .true.
           exit
        end if
+       if (pass >= max(max_pass, pass0 + 2)) exit
+       pass = pass + 1
     end do
     if (.not. clean) then
        print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
@@ -1397,7 +1414,7 @@ contains
        else
           if (pass >= 2) then
              ! ... and the same for columns that depend on EACH OTHER after a pass has already orthonormalised the block: those the
-             ! pivoted factorisation cannot reach (remaining pivot below again_rel) are replaced, not rescaled
+             ! left-to-right factorisation cannot reach (remaining pivot below again_rel) are replaced, not rescaled
              call dependent_columns(gp, kt, again_rel, null_cols, nnull)
              if (nnull > 0) return
           end if
@@ -1416,50 +1433,35 @@ contains
     end if
   end subroutine ortho_pass_transform
 
-  !> Greedy pivoted Cholesky of a Gram block with unit diagonal: the columns whose remaining pivot falls below thr once the larger
-  !> ones are eliminated depend on those to working precision (dep, ndep).
+  !> Left-to-right Cholesky of a Gram block with unit diagonal: a column whose remaining pivot - once the accepted columns to its
+  !> left are eliminated - falls below thr depends on them to working precision and is skipped (dep, ndep).  Left to right, not
+  !> pivoted, because that is the order in which the reference's Householder QR finds its dependent columns: the completion
+  !> vectors then land in the same slots.
   subroutine dependent_columns(gs, kt, thr, dep, ndep)
     integer, intent(in) :: kt
     real(dp), intent(in) :: gs(kt, kt), thr
     logical, intent(out) :: dep(kt)
     integer, intent(out) :: ndep
-    real(dp) :: l(kt, kt), rem(kt), piv
-    logical :: done(kt)
-    integer :: step, i, jmax
+    real(dp) :: l(kt, kt), rem
+    integer :: i, j, nacc, acc(kt)
     l = 0.0_dp
-    done = .false.
     dep = .false.
     ndep = 0
-    do i = 1, kt
-       rem(i) = gs(i, i)
-    end do
-    do step = 1, kt
-       jmax = 0
-       do i = 1, kt
-          if (done(i)) cycle
-          if (jmax == 0) then
-             jmax = i
-          else if (rem(i) > rem(jmax)) then
-             jmax = i
-          end if
+    nacc = 0
+    do j = 1, kt
+       ! row j of the factor against the accepted columns
+       do i = 1, nacc
+          l(j, i) = (gs(j, acc(i)) - dot_product(l(j, 1:i - 1), l(acc(i), 1:i - 1))) / l(acc(i), i)
        end do
-       if (.not. (rem(jmax) >= thr)) then
-          do i = 1, kt
-             if (.not. done(i)) then
-                dep(i) = .true.
-                ndep = ndep + 1
-             end if
-          end do
-          return
+       rem = gs(j, j) - dot_product(l(j, 1:nacc), l(j, 1:nacc))
+       if (rem >= thr) then
+          nacc = nacc + 1
+          acc(nacc) = j
+          l(j, nacc) = sqrt(rem)
+       else
+          dep(j) = .true.
+          ndep = ndep + 1
        end if
-       done(jmax) = .true.
-       piv = sqrt(rem(jmax))
-       l(jmax, step) = piv
-       do i = 1, kt
-          if (done(i)) cycle
-          l(i, step) = (gs(i, jmax) - dot_product(l(i, 1:step - 1), l(jmax, 1:step - 1))) / piv
-          rem(i) = rem(i) - l(i, step)**2
-       end do
     end do
   end subroutine dependent_columns
 

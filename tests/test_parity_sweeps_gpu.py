@@ -29,6 +29,22 @@ def test_dpr_solves_against_the_oracle_on_a_fixed_seed_slice():
     assert len([ln for ln in out.splitlines() if "oracle iters" in ln]) >= 15
 
 
+def test_structured_matrices_against_the_oracle_on_a_fixed_seed_slice():
+    """40 STRUCTURED problems (tests/structured_parity_sweep.py: banded, block diagonal, sparse, permuted / repeated diagonals,
+    negative and scaled spectra, strong coupling; DPR and GJD, standard and generalized, both storages) - the classes whose
+    correction blocks are rank deficient by structure: wherever the oracle's statement of the reference converges so does the
+    engine, to the same eigenvalues; DPR iteration counts equal, GJD never more."""
+    out = run_tool("structured_parity_sweep.py", 40, 9)
+    assert re.search(r"mismatches: 0, iteration counts differ", out), out[-3000:]
+    rows = [ln for ln in out.splitlines() if "oracle iters" in ln]
+    assert len(rows) == 40
+    for ln in rows:
+        m = re.search(r"oracle iters\s+(\d+), engine\s+(\d+)", ln)
+        ref_it, eng_it = int(m.group(1)), int(m.group(2))
+        if ref_it <= 200:
+            assert (eng_it <= ref_it) if " GJD " in ln else (abs(eng_it - ref_it) <= 2), ln
+
+
 def test_locking_policy_against_its_oracle_statement_on_a_fixed_seed_slice():
     """16 random standard problems (DPR and GJD, clustered and plain diagonals, restart widths, both storages) under the opt-in
     "locking" policy: iteration counts equal to the oracle's statement of the policy, eigenvalues to 1e-8, residuals below the
