@@ -367,6 +367,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # the pool's driver only supports dmabuf IPC (RCCL's peer-to-peer buffers): in place before the HIP runtime loads, whoever launched us
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
