@@ -1327,7 +1327,7 @@ contains
     real(dp), intent(out) :: mm(kt, kt), wmin, wmax
     logical, intent(out) :: null_cols(kt)
     integer, intent(out) :: nnull
-    real(dp), parameter :: floor_rel = 1.0e-14_dp, again_rel = 1.0e-10_dp
+    real(dp), parameter :: floor_rel = 1.0e-14_dp, again_rel = 1.0e-10_dp, first_rel = 1.0e-13_dp
     real(dp), allocatable :: gp(:, :), d(:), w(:), u(:, :)
     integer :: j, l, info
     logical :: chol_ok
@@ -1417,6 +1417,12 @@ contains
              ! left-to-right factorisation cannot reach (remaining pivot below again_rel) are replaced, not rescaled
              call dependent_columns(gp, kt, again_rel, null_cols, nnull)
              if (nnull > 0) return
+          else if (ortho_early()) then
+             ! the FIRST pass already sees dependence that is exact up to rounding (remaining pivot at the noise level of the Gram
+             ! product: the corrections of a banded matrix, section 0 of DESIGN.md): replaced before the block is swept, instead of a
+             ! sweep of noise columns, a second pass that finds them, and a second sweep
+             call dependent_columns(gp, kt, first_rel, null_cols, nnull)
+             if (nnull > 0) return
           end if
           call lapack_rayleigh_ritz(gp, w, u, kt)
           wmax = maxval(w)
@@ -1432,6 +1438,22 @@ contains
        end if
     end if
   end subroutine ortho_pass_transform
+
+  !> DAV_ORTHO_EARLY=0: structural rank deficiency of a correction block is only looked for from the second pass on (A/B knob)
+  function ortho_early() result(on)
+    logical :: on
+    integer :: stat, length
+    character(len=8) :: buf
+    integer, save :: cached = -1
+    if (cached < 0) then
+       cached = 1
+       call get_environment_variable("DAV_ORTHO_EARLY", buf, length, stat)
+       if (stat == 0 .and. length > 0) then
+          if (buf(1:1) == "0") cached = 0
+       end if
+    end if
+    on = cached == 1
+  end function ortho_early
 
   !> Left-to-right Cholesky of a Gram block with unit diagonal: a column whose remaining pivot - once the accepted columns to its
   !> left are eliminated - falls below thr depends on them to working precision and is skipped (dep, ndep).  Left to right, not
