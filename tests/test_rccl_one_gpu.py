@@ -132,3 +132,30 @@ def test_configs2_at_full_order_over_a_real_four_rank_communicator():
                        "value": line["value"], "iters_per_solve": line["config"]["iters_per_solve"], "eigenvalues": line["eigenvalues"], "comm": c}, f, indent=1)
     except OSError:
         pass
+
+
+@pytest.mark.parametrize("gev", [False, True])
+def test_callers_own_kernel_as_operator_over_a_real_communicator(gev):
+    """dav_set_operator_device on two ranks of a real RCCL communicator (tests/rccl_device_operator.py: the banded stencil of
+    tests/helpers/user_operator.hip, n = 2999 - it reads across the slab boundary, so the block the callback is handed must be the
+    gathered one): the eigenvalues and the iteration count of the dense solve of the same matrix by numpy / the oracle."""
+    from oracle import davidson_oracle as O
+    n, lowest = 2999, 4
+    a = np.diag(1.0 + np.arange(n, dtype=np.float64))
+    b = np.eye(n)
+    for off, w in ((1, 0.3), (2, 0.15)):
+        a += w * (np.eye(n, k=off) + np.eye(n, k=-off))
+    for off, w in ((1, 0.05), (2, 0.025)):
+        b += w * (np.eye(n, k=off) + np.eye(n, k=-off))
+    with np.errstate(invalid="ignore"):
+        lam_o, _, it_o = O.generalized_eigensolver_dense(a, lowest, "DPR", 200, 1e-8, None, b if gev else None)
+    env = dict(os.environ, DAVIDSON_COLLECTIVE_TIMEOUT="120")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (the helper library travels in lib/test/; the engine is whichever library this process's environment points at)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "rccl_device_operator.py"), str(n), str(lowest), "1" if gev else "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["ranks"] == 2 and line["iters"] == it_o and line["collectives"] > 0
+    assert np.abs(np.array(line["eigenvalues"]) - lam_o).max() < 1e-9
