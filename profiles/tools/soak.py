@@ -9,6 +9,7 @@ import fortran_davidson_amd as fd
 
 
 def free_mb():
+    fd.free_buffers()          # what the buffer cache keeps of destroyed engines is not a leak (dav_free_buffers)
     torch.cuda.synchronize()
     return torch.cuda.mem_get_info()[0] / 2**20
 
