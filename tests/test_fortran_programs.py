@@ -54,6 +54,19 @@ def build_options_program(tmp_path):
     return compile_link([os.path.join(SRC, "prog_options.f90")], os.path.join(bindir, "prog_options"), tmp_path)
 
 
+def build_device_operator_program(tmp_path):
+    """links the caller's own library too (lib/test/libuser_operator.so: tests/helpers/user_operator.hip)"""
+    bindir = os.path.join(SRC, "_bin")
+    os.makedirs(bindir, exist_ok=True)
+    tdir = os.path.join(LIBDIR, "test")
+    cmd = [FC, "-O1", "-fopenmp=libiomp5", f"-I{MODDIR}", "-module-dir", str(tmp_path), os.path.join(SRC, "prog_device_operator.f90"),
+           f"-L{tdir}", "-luser_operator", f"-L{LIBDIR}", "-lfortran_davidson_amd", "-ldavidson_hip", f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{tdir}",
+           "-L/opt/conda/lib", "-Wl,-rpath,/opt/conda/lib", "-o", os.path.join(bindir, "prog_device_operator")]
+    res = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp_path)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return os.path.join(bindir, "prog_device_operator")
+
+
 def build_ingest_program(tmp_path):
     bindir = os.path.join(SRC, "_bin")
     os.makedirs(bindir, exist_ok=True)
@@ -69,6 +82,7 @@ def test_user_programs_compile_and_link(tmp_path):
     assert os.path.exists(build_ingest_program(tmp_path))
     assert os.path.exists(build_ranks_program(tmp_path))
     assert os.path.exists(build_options_program(tmp_path))
+    assert os.path.exists(build_device_operator_program(tmp_path))
 
 
 @needs_flang
@@ -171,3 +185,15 @@ def test_options_program_runs_on_gpu(tmp_path):
     assert rc == 0, out
     checks = re.findall(r"CHECK (\S+) ([TF])", out)
     assert len(checks) == 14 and all(v == "T" for _, v in checks), out
+
+
+@needs_flang
+@pytest.mark.gpu
+def test_device_operator_program_runs_on_gpu(tmp_path):
+    """engine_set_device_operator (c_funloc of the caller's bind(C) launcher) + the generic on the engine, from a Fortran program,
+    against the drop-in dense call on the same banded matrix: DPR and GJD."""
+    exe = build_device_operator_program(tmp_path)
+    rc, out = _run(exe)
+    assert rc == 0, out
+    checks = re.findall(r"CHECK (\S+) ([TF])", out)
+    assert len(checks) == 12 and all(v == "T" for _, v in checks), out
