@@ -1199,7 +1199,7 @@ contains
     integer, parameter :: max_pass = 8
     real(dp), allocatable :: c(:, :), g(:, :), mm(:, :), vec(:)
     logical, allocatable :: null_cols(:)
-    integer, allocatable :: tries(:), queue(:)
+    integer, allocatable :: queue(:)
     integer :: pass, j, nnull, pass0, nqueue, qpos, rounds
     integer, parameter :: max_rounds = 12
     logical :: first_gram
@@ -1207,8 +1207,7 @@ contains
     real(dp) :: wmax, wmin
     logical :: clean, stop_early
 
-    allocate(c(max(m, 1), kt), g(kt, kt), mm(kt, kt), null_cols(kt), tries(kt))
-    tries = 0
+    allocate(c(max(m, 1), kt), g(kt, kt), mm(kt, kt), null_cols(kt))
     clean = .false.
     stop_early = .false.
     if (present(only_first)) stop_early = only_first
@@ -1237,11 +1236,10 @@ contains
              print *, "generalized_eigensolver: no independent directions found for a correction block after ", max_rounds, " rounds"
              error stop
           end if
-          ! first the unit vector at the next entry of the start order (the (m + j)-th smallest diagonal entry: the direction the
-          ! initial guess would have taken next, and what the reference's Householder QR leaves in such a column when the diagonal
-          ! ascends with the index); a column that comes back null gets a pseudo-random vector
-          ! (a column whose own entry comes back null - it lay in the span of the healthy columns - takes the entries of THEIR
-          ! slots next, then the entries behind the block)
+          ! Round 1: the unit vector at the column's own entry of the start order (the (m + j)-th smallest diagonal entry: the
+          ! direction the initial guess would have taken next, and what the reference's Householder QR leaves in such a column when
+          ! the diagonal ascends with the index).  Rounds 2-6, for a column whose unit vector came back null (it lay in the span
+          ! of the healthy columns): the entries of THEIR slots, then the entries behind the block.  After that pseudo-random vectors.
           if (.not. allocated(queue)) then
              allocate(queue(2 * kt))
              nqueue = 0
@@ -1259,7 +1257,6 @@ contains
           end if
           do j = 1, kt
              if (null_cols(j)) then
-                tries(j) = tries(j) + 1
                 ierr = 1_c_int
                 if (rounds == 1) then
                    ierr = dav_panel_unit_column(h, DAV_PANEL_V, int(m + j - 1, c_int), int(m + j - 1, c_int))
