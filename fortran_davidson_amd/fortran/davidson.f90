@@ -1436,17 +1436,22 @@ contains
     end if
   end subroutine ortho_pass_transform
 
-  !> DAV_ORTHO_EARLY=0: structural rank deficiency of a correction block is only looked for from the second pass on (A/B knob)
+  !> DAV_ORTHO_EARLY=1 (opt-in): structural rank deficiency of a correction block is looked for at the FIRST pass already - it
+  !> saves a banded matrix the sweep of its noise columns.  Off by default: before the first pass the columns are not orthogonal
+  !> to the basis, the projected Gram block G - C^T C carries the rounding of G at the scale of the UNPROJECTED columns, and a
+  !> threshold at 1e-13 of the projected norms sits below that noise for corrections that lie mostly in the span of the basis
+  !> (generalized problems with a second operator far from the identity: a left-to-right factorisation then accepts noise
+  !> pivots and rejects every column behind them - measured: an endless replacement of healthy columns).
   function ortho_early() result(on)
     logical :: on
     integer :: stat, length
     character(len=8) :: buf
     integer, save :: cached = -1
     if (cached < 0) then
-       cached = 1
+       cached = 0
        call get_environment_variable("DAV_ORTHO_EARLY", buf, length, stat)
        if (stat == 0 .and. length > 0) then
-          if (buf(1:1) == "0") cached = 0
+          if (buf(1:1) == "1") cached = 1
        end if
     end if
     on = cached == 1
