@@ -31,7 +31,8 @@ def test_dpr_solves_against_the_oracle_on_a_fixed_seed_slice():
 
 def test_structured_matrices_against_the_oracle_on_a_fixed_seed_slice():
     """40 STRUCTURED problems (tests/structured_parity_sweep.py: banded, block diagonal, sparse, permuted / repeated diagonals,
-    negative and scaled spectra, strong coupling; DPR and GJD, standard and generalized, both storages) - the classes whose
+    negative and scaled spectra, strong coupling; DPR and GJD, standard and generalized - second operators near the identity and far from
+    it -, both storages) - the classes whose
     correction blocks are rank deficient by structure: wherever the oracle's statement of the reference converges so does the
     engine, to the same eigenvalues; DPR iteration counts equal, GJD never more."""
     out = run_tool("structured_parity_sweep.py", 40, 9)
@@ -42,7 +43,7 @@ def test_structured_matrices_against_the_oracle_on_a_fixed_seed_slice():
         m = re.search(r"oracle iters\s+(\d+), engine\s+(\d+)", ln)
         ref_it, eng_it = int(m.group(1)), int(m.group(2))
         if ref_it <= 200:
-            assert (eng_it <= ref_it) if " GJD " in ln else (abs(eng_it - ref_it) <= 2), ln
+            assert (eng_it <= ref_it) if " GJD " in ln else (eng_it <= ref_it + 2), ln
 
 
 def test_locking_policy_against_its_oracle_statement_on_a_fixed_seed_slice():
