@@ -50,3 +50,46 @@ def test_block_diagonal_matrix_with_identical_blocks():
     lam, vec, it = fd.generalized_eigensolver(a, 6, "DPR", 300, 1e-8)
     assert it <= 300 and np.abs(lam - lam_np).max() < 1e-8
     assert np.linalg.norm(a @ vec - vec * lam[None, :], axis=0).max() < 1e-7
+
+
+@pytest.mark.parametrize("storage,gev", [("symmetric", False), ("full", True)])
+def test_banded_matrix_on_three_ranks(storage, gev):
+    """The completion of a rank-deficient block is a decision every rank must take alike (all-reduced Gram blocks, the same start
+    order on every rank): three ranks over the loopback transport against one rank - same iteration count, same eigenvalues."""
+    import ctypes as C
+    import threading
+    n, lowest, nranks = 1111, 4, 3
+    a = band(n, 1.0, 1.0, 0.3)
+    b = band(n, 1.0, 0.0, 0.05) if gev else None
+
+    def load(eng):
+        eng.set_dense(1, a)
+        if gev:
+            eng.set_dense(2, b)
+
+    with fd.DavidsonEngine(n, lowest, None, gev=gev, storage=storage) as one:
+        load(one)
+        lam1, _, it1 = one.solve("DPR", 200, 1e-8, want_vectors=False)
+    assert it1 == 2
+    engs = [fd.DavidsonEngine(n, lowest, None, gev=gev, rank=r, nranks=nranks, storage=storage) for r in range(nranks)]
+    handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+    assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            load(engs[r])
+            out[r] = engs[r].solve("DPR", 200, 1e-8, want_vectors=False)
+        except Exception as exc:      # noqa: BLE001
+            err[r] = exc
+        finally:
+            fd.hip_lib().dav_local_group_yield(engs[r].c.h)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for e in engs:
+        e.close()
+    assert all(x is None for x in err), err
+    for lam, _, it in out:
+        assert it == it1 and np.abs(lam - lam1).max() < 1e-10
