@@ -1423,8 +1423,11 @@ contains
           else if (relative_tests .and. ortho_early()) then
              ! the FIRST pass already sees dependence that is exact up to rounding (remaining pivot at the noise level of the Gram
              ! product: the corrections of a banded matrix, section 0 of DESIGN.md): replaced before the block is swept, instead of a
-             ! sweep of noise columns, a second pass that finds them, and a second sweep
-             call dependent_columns(gp, kt, first_rel, null_cols, nnull)
+             ! sweep of noise columns, a second pass that finds them, and a second sweep.  Conservative (dependent_columns: noise)
+             do j = 1, kt
+                w(j) = 64.0_dp * epsilon(1.0_dp) * g(j, j) * d(j) * d(j)          ! d(j)**2 = 1 / gp(j, j) before the scaling
+             end do
+             call dependent_columns(gp, kt, first_rel, null_cols, nnull, w)
              if (nnull > 0) return
           end if
           call lapack_rayleigh_ritz(gp, w, u, kt)
@@ -1442,22 +1445,23 @@ contains
     end if
   end subroutine ortho_pass_transform
 
-  !> DAV_ORTHO_EARLY=1 (opt-in): structural rank deficiency of a correction block is looked for at the FIRST pass already - it
-  !> saves a banded matrix the sweep of its noise columns.  Off by default: before the first pass the columns are not orthogonal
-  !> to the basis, the projected Gram block G - C^T C carries the rounding of G at the scale of the UNPROJECTED columns, and a
-  !> threshold at 1e-13 of the projected norms sits below that noise for corrections that lie mostly in the span of the basis
-  !> (generalized problems with a second operator far from the identity: a left-to-right factorisation then accepts noise
-  !> pivots and rejects every column behind them - measured: an endless replacement of healthy columns).
+  !> Structural rank deficiency of a correction block is looked for at the FIRST pass already (it saves a banded matrix the sweep
+  !> of its noise columns); DAV_ORTHO_EARLY=0 turns that off (A/B knob).  The first-pass test is conservative (dependent_columns:
+  !> noise): before the first pass the columns are not orthogonal to the basis, the projected Gram block G - C^T C carries the
+  !> rounding of G at the scale of the UNPROJECTED columns, and a threshold of 1e-13 of the projected norms sits below that noise
+  !> for corrections that lie mostly in the span of the basis (generalized problems with a second operator far from the identity:
+  !> an unconditional test accepted noise pivots and rejected every column behind them, round after round) - such columns, and
+  !> everything behind an ill-conditioned accepted column, are left to the second pass.
   function ortho_early() result(on)
     logical :: on
     integer :: stat, length
     character(len=8) :: buf
     integer, save :: cached = -1
     if (cached < 0) then
-       cached = 0
+       cached = 1
        call get_environment_variable("DAV_ORTHO_EARLY", buf, length, stat)
        if (stat == 0 .and. length > 0) then
-          if (buf(1:1) == "1") cached = 1
+          if (buf(1:1) == "0") cached = 0
        end if
     end if
     on = cached == 1
@@ -1467,17 +1471,24 @@ contains
   !> left are eliminated - falls below thr depends on them to working precision and is skipped (dep, ndep).  Left to right, not
   !> pivoted, because that is the order in which the reference's Householder QR finds its dependent columns: the completion
   !> vectors then land in the same slots.
-  subroutine dependent_columns(gs, kt, thr, dep, ndep)
+  subroutine dependent_columns(gs, kt, thr, dep, ndep, noise)
     integer, intent(in) :: kt
     real(dp), intent(in) :: gs(kt, kt), thr
     logical, intent(out) :: dep(kt)
     integer, intent(out) :: ndep
+    !> first pass only: noise(j) = rounding level of column j's entries of gs (the projected Gram block carries the rounding of the
+    !> unprojected one: eps g_jj / gp_jj).  With it the test is conservative: a column is only called dependent where the block
+    !> can tell - its own entries are accurate to thr, and every column accepted before it was accepted with a pivot far above
+    !> the noise (>= 1e-6) - everything else is left to the second pass
+    real(dp), intent(in), optional :: noise(kt)
     real(dp) :: l(kt, kt), rem
     integer :: i, j, nacc, acc(kt)
+    logical :: can_tell
     l = 0.0_dp
     dep = .false.
     ndep = 0
     nacc = 0
+    can_tell = .true.
     do j = 1, kt
        ! row j of the factor against the accepted columns
        do i = 1, nacc
@@ -1488,9 +1499,19 @@ contains
           nacc = nacc + 1
           acc(nacc) = j
           l(j, nacc) = sqrt(rem)
-       else
+          if (present(noise) .and. rem < 1.0e-6_dp) can_tell = .false.
+       else if (.not. present(noise)) then
           dep(j) = .true.
           ndep = ndep + 1
+       else if (can_tell .and. noise(j) < thr) then
+          dep(j) = .true.
+          ndep = ndep + 1
+       else
+          ! cannot tell: keep the column (with a pivot at the threshold, so that the factor stays finite) and stop judging
+          nacc = nacc + 1
+          acc(nacc) = j
+          l(j, nacc) = sqrt(thr)
+          can_tell = .false.
        end if
     end do
   end subroutine dependent_columns
