@@ -126,7 +126,8 @@ int dav_device_memory(dav_handle_t h, int64_t* free_bytes, int64_t* total_bytes)
  * same sizes - the reference's interface (src/davidson.f90:51-52) is one call per eigenproblem, so a caller in a loop creates and
  * destroys an engine per call; blocks idle through a whole create-destroy cycle are freed, a failing allocation frees them all and
  * tries again, dav_device_memory counts them as free.  dav_free_buffers() returns every idle block to the device now
- * (what mkl_free_buffers is to MKL); DAVIDSON_BUFFER_CACHE=0 in the environment turns the cache off. */
+ * (what mkl_free_buffers is to MKL); DAVIDSON_BUFFER_CACHE=0 in the environment turns the cache off; it never holds more than
+ * DAVIDSON_BUFFER_CACHE_MB megabytes (default 4096: the call it exists for is the small and frequent one). */
 int dav_free_buffers(void);
 /* Dense matrix from host memory, full storage a(lda, n), the caller's array as passed to
  * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and

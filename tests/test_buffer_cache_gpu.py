@@ -46,3 +46,29 @@ def test_engine_reports_idle_blocks_as_free_memory():
         free_seen, total = eng.c.device_memory()
     fd.free_buffers()
     assert free_seen > idle and free_seen <= total
+
+
+def test_the_cache_never_holds_more_than_its_cap():
+    """DAVIDSON_BUFFER_CACHE_MB (default 4096; read once per process, hence a child): with a cap of 16 MB the 150 MB of tiles of an
+    order-6000 call go straight back to the device when the call returns - a drop-in call on a large matrix must not leave the
+    device full behind it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import fortran_davidson_amd as fd\n"
+        "from oracle import davidson_oracle as O\n"
+        "a = O.generate_diagonal_dominant(6000, 1e-3, seed=7)\n"
+        "fd.generalized_eigensolver(a[:400, :400].copy(), 4, 'DPR', 100, 1e-8)\n"
+        "fd.free_buffers(); before = torch.cuda.mem_get_info(0)[0]\n"
+        "fd.generalized_eigensolver(a, 4, 'DPR', 100, 1e-8)\n"
+        "print('HELD', before - torch.cuda.mem_get_info(0)[0])\n" % root)
+    held = {}
+    for cap in ("16", "4096"):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, DAVIDSON_BUFFER_CACHE_MB=cap))
+        assert res.returncode == 0, (res.stdout + res.stderr)[-2000:]
+        held[cap] = int([ln for ln in res.stdout.splitlines() if ln.startswith("HELD")][0].split()[1])
+    assert held["16"] < (64 << 20) and held["4096"] > 8 * 6000 * 6000 // 2
