@@ -91,14 +91,17 @@ for case in range(ncases):
         hb = rng.random((n, n)) * 1e-3 * db.min()
         b = np.diag(db) + sym(hb) - np.diag(np.diag(sym(hb)))
         what += f" B{bkind}"
+    # restart width: the default (10 * lowest) or a narrow one (restarts between the completions of rank-deficient blocks)
+    md = None if rng.random() < 0.6 else int(rng.integers(2 * lowest, 5 * lowest + 1))
+    what += "" if md is None else f" md={md}"
     os.environ["DAVIDSON_STORAGE"] = storage
     try:
         with np.errstate(all="ignore"):
-            lam_o, _, it_o = O.generalized_eigensolver_dense(a, lowest, method, 200, tol, None, b)
+            lam_o, _, it_o = O.generalized_eigensolver_dense(a, lowest, method, 200, tol, md, b)
     except RuntimeError as exc:          # the reference's `error stop` after a failed LAPACK call (NaN in the projected matrix)
         lam_o, it_o = np.full(lowest, np.nan), 999
         what += " [oracle: " + str(exc)[-30:] + "]"
-    lam, vec, it = fd.generalized_eigensolver(a, lowest, method, 200, tol, None, b)
+    lam, vec, it = fd.generalized_eigensolver(a, lowest, method, 200, tol, md, b)
     bx = vec if b is None else b @ vec
     res = np.linalg.norm(a @ vec - bx * lam[None, :], axis=0).max()
     ok_o = it_o <= 200 and np.isfinite(lam_o).all()
