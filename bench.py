@@ -56,6 +56,10 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/
 # v_lshrrev_b64, 2 v_add3, 2 v_lshrrev_b32, 2 v_cvt_f64_u32, 1 each v_alignbit / v_add_f64 / v_fmac_f64 / v_mul_f64, ~1.3
 # 64-bit adds) PLUS the two 64-cycle MFMAs that consume it in a 16-column sweep (direct + transposed product).
 GEN_CYCLES_PER_WAVE_EVALUATION = 26 * 4 + 2 * 64
+# the reference's matrix-free test operator in its one-variable form (csrc/common.h: dav_harness_poly): 2 additions + 17 FMAs per entry
+HARNESS_CYCLES_PER_WAVE_EVALUATION = 19 * 4 + 2 * 64
+HARNESS_MODEL = ("1024 SIMDs x 2.4 GHz x 64 lanes / 204 cycles per wave-evaluation of 64 entries and 16 columns: 19 fp64 VALU instructions x 4 cycles "
+                 "(x = 1 - |l_i - l_j|, degree-17 Horner) + 2 fp64 MFMAs x 64 cycles (direct + transposed product) on one issue port")
 GEN_MODEL = ("1024 SIMDs x 2.4 GHz x 64 lanes / 232 cycles per wave-evaluation: 26 VALU instructions x 4 cycles (splitmix64 + key + "
              "conversion; no quarter-rate instruction among them, profiles/ubench/r03_valucost.log) + 2 fp64 MFMAs x 64 cycles (16 columns, "
              "direct + transposed product) - the two kinds of instruction do not overlap within a SIMD (same log: n VALU instructions "
@@ -81,7 +85,7 @@ def parse():
     ap.add_argument("--gjd-n", type=int, default=-1, help="order of the configs[3] leg (-1 = same as --order, 0 = skip)")
     ap.add_argument("--free-n", type=int, default=1000000, help="order of the configs[4] leg (0 = skip)")
     ap.add_argument("--harness-n", type=int, default=100000, help="order of the benchmark_free leg's large solve (0 = skip the leg)")
-    ap.add_argument("--harness-n2", type=int, default=1000000, help="order of that leg's single timed sweep (0 = skip)")
+    ap.add_argument("--harness-n2", type=int, default=1000000, help="order of that leg's full solve at configs[4]'s order, lowest = 8 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="only the timed workload and its roofline objects")
@@ -845,12 +849,13 @@ def main():
 
     if not args.headline_only and args.harness_n > 0 and world == 1:
         # ---- the reference's own benchmark program (src/benchmark_free.f90): its matrix-free test operator, B = I, DPR --------------
-        # A_ij = cos(log(sqrt(atan2(e_lo, e_hi)))) * 1e-4 (+ i on the diagonal), e = exp(real(i) / real(N)): four fp64 transcendental /
-        # root evaluations per entry - the sweep is bound by that arithmetic, not by memory.  Every symmetric pair is evaluated once.
+        # A_ij = cos(log(sqrt(atan2(e_lo, e_hi)))) * 1e-4 (+ i on the diagonal), e = exp(real(i) / real(N)).  Round 6: with 0 < e_lo <= e_hi
+        # the entry is a function of ONE variable, x = 1 - |2 log e_i - 2 log e_j|, evaluated as a degree-17 polynomial (csrc/common.h:
+        # dav_harness_poly; 19 fp64 VALU instructions per entry instead of four library calls, ~395).  Every symmetric pair is evaluated
+        # once.  Roofline: the issue-port model of the generated sweeps (configs4_free) - VALU work and the fp64 MFMAs it feeds share the
+        # SIMD's issue port: 19 x 4 + 2 x 64 = 204 cycles per 64 entries and 16 columns.
         try:
             hb = {}
-            with fd.CEngine(n=1024, max_cols=16, device=device) as e0:
-                rate = e0.bench_harness_rate(3000)
             h1 = make_engine(1000, 3, 20, "symmetric", gev=True)
             h1.set_harness_operator(1); h1.set_identity(2)
             for _ in range(3):
@@ -860,41 +865,51 @@ def main():
             hb["reference_configuration"] = {"workload": "benchmark_free.f90:80-111: N=1000, lowest=3, max_dim_sub=20, tol=1e-8, A = cos row generator, B = I, DPR",
                                              "ms_per_solve": round(dt_h / 20 * 1e3, 4), "iters_per_solve": it_h // 20,
                                              "iterations_per_s": round(it_h / dt_h, 1), "eigenvalues": [float(x) for x in lam_h]}
-            hn = args.harness_n
-            h2 = make_engine(hn, 3, 20, "symmetric", gev=True)
-            h2.set_harness_operator(1); h2.set_identity(2)
-            h2.solve("DPR", 1000, 1e-8, want_vectors=False)
-            h2.c.synchronize(); h2.c.reset_stats()
-            dt_2, it_2, lam_2 = timed_solves(h2, "DPR", 1, 1e-8)
-            s2 = h2.c.stats()
-            h2.close()
-            entries = 0.5 * float(hn) * (float(hn) + 1.0)
-            per_launch = s2.apply_kernel_ms / max(int(s2.apply_launches), 1)
-            hb["large"] = {"workload": f"N={hn}, lowest=3, max_dim_sub=20, tol=1e-8, same operator (entries generated in the sweep, each symmetric pair once), B = I, DPR",
-                           "iters": it_2, "seconds": round(dt_2, 4), "iterations_per_s": round(it_2 / dt_2, 3), "sweeps": int(s2.applies),
-                           "launches": int(s2.apply_launches), "ms_per_launch": round(per_launch, 3), "eigenvalues": [float(x) for x in lam_2],
-                           "entries_evaluated_per_s": round(entries / (per_launch * 1e-3), 0) if per_launch > 0 else None}
-            hb["roofline"] = {"bound": "fp64 transcendental arithmetic (atan2 + sqrt + log + cos per entry)", "unit": "entries/s",
-                              "achieved": hb["large"]["entries_evaluated_per_s"], "peak": round(rate, 0),
-                              "frac": round(entries / (per_launch * 1e-3) / rate, 4) if per_launch > 0 and rate > 0 else None,
-                              "N": hn, "entries_per_launch": entries,
-                              "peak_source": "dav_bench_harness_rate, this run: the same four library calls per entry on register operands, two waves per SIMD, no memory traffic"}
-            if args.harness_n2 > 0:
-                h3 = fd.CEngine(n=args.harness_n2, max_cols=16, device=device)
+            rate = 1024 * 2.4e9 * 64 / HARNESS_CYCLES_PER_WAVE_EVALUATION          # entries / s of the model, 16 columns per launch
+
+            def harness_solve(n_h, lowest_h, max_dim_h):
+                h = make_engine(n_h, lowest_h, max_dim_h, "symmetric", gev=True)
+                h.set_harness_operator(1); h.set_identity(2)
+                if n_h <= 200000:
+                    h.solve("DPR", 1000, 1e-8, want_vectors=False)             # warm-up (lazy workspace)
+                else:
+                    h.c.bench_apply2(16, 1)
+                h.c.synchronize(); h.c.reset_stats()
+                dt, it, lam = timed_solves(h, "DPR", 1, 1e-8)
+                st = h.c.stats()
+                h.close()
+                entries = 0.5 * float(n_h) * (float(n_h) + 1.0)
+                launches = max(int(st.apply_launches), 1)
+                per_launch = st.apply_kernel_ms / launches
+                return {"workload": f"N={n_h}, lowest={lowest_h}, max_dim_sub={max_dim_h}, tol=1e-8, the reference's test operator (entries generated in the sweep, each symmetric pair once), B = I, DPR",
+                        "iters": it, "seconds": round(dt, 4), "iterations_per_s": round(it / dt, 3), "sweeps": int(st.applies), "launches_of_16_columns": launches,
+                        "ms_per_launch": round(per_launch, 3), "ms_in_sweep_kernels": round(st.apply_kernel_ms, 2), "eigenvalues": [float(x) for x in lam[:3]],
+                        "entries_evaluated_per_s": round(entries / (per_launch * 1e-3), 0) if per_launch > 0 else None,
+                        "roofline": {"bound": "valu-fp64 + mfma on one issue port", "unit": "entries/s",
+                                     "achieved": round(entries / (per_launch * 1e-3), 0) if per_launch > 0 else None, "peak": round(rate, 0),
+                                     "frac": round(entries / (per_launch * 1e-3) / rate, 4) if per_launch > 0 else None,
+                                     "entries_per_launch": entries, "model": HARNESS_MODEL}}
+            hb["large"] = harness_solve(args.harness_n, 3, 20)
+            hb["roofline"] = dict(hb["large"]["roofline"], N=args.harness_n)
+            # A/B: the same sweep with the formula as written (four library calls per entry: DAV_HARNESS_LIBM=1 at dav_create) - round 5's path
+            try:
+                os.environ["DAV_HARNESS_LIBM"] = "1"
+                hl = fd.CEngine(n=args.harness_n, max_cols=16, device=device)
                 try:
-                    h3.set_storage(1)
-                    i3 = np.arange(1, args.harness_n2 + 1, dtype=np.float32)
-                    h3.set_operator_harness(0, np.exp(i3 / np.float32(args.harness_n2), dtype=np.float32).astype(np.float64))
-                    h3.reset_stats()
-                    h3.apply(0, 0, 0, 16, 1, 0)
-                    h3.synchronize()
-                    s3 = h3.stats()
-                    e3 = 0.5 * float(args.harness_n2) * (float(args.harness_n2) + 1.0)
-                    hb["sweep_at_configs4_order"] = {"N": args.harness_n2, "columns": 16, "ms": round(s3.apply_kernel_ms, 1),
-                                                     "entries_evaluated_per_s": round(e3 / (s3.apply_kernel_ms * 1e-3), 0),
-                                                     "frac_of_measured_arithmetic_rate": round(e3 / (s3.apply_kernel_ms * 1e-3) / rate, 4)}
+                    hl.set_storage(1)
+                    il = np.arange(1, args.harness_n + 1, dtype=np.float32)
+                    hl.set_operator_harness(0, np.exp(il / np.float32(args.harness_n), dtype=np.float32).astype(np.float64))
+                    hl.apply(0, 0, 0, 16, 1, 0); hl.synchronize(); hl.reset_stats()
+                    hl.apply(0, 0, 0, 16, 1, 0); hl.synchronize()
+                    hb["library_call_chain_sweep_ms"] = round(hl.stats().apply_kernel_ms, 3)
+                    hb["library_call_chain_rate_entries_per_s"] = round(hl.bench_harness_rate(3000), 0)
                 finally:
-                    h3.close()
+                    hl.close()
+            finally:
+                os.environ.pop("DAV_HARNESS_LIBM", None)
+            if args.harness_n2 > 0:
+                # configs[4]'s order on the reference's own operator: a FULL solve (lowest = 8, the doubling policy's 16 / 32 / 64-column blocks)
+                hb["solve_at_configs4_order"] = harness_solve(args.harness_n2, 8, 80)
             extras["configs4_free_harness"] = hb
         except Exception as exc:       # noqa: BLE001
             extras["configs4_free_harness"] = {"error": repr(exc)[:300]}

@@ -54,10 +54,11 @@ __host__ __device__ __forceinline__ double dav_hashed_entry(uint64_t seed, doubl
   return dav_uniform01(seed, lo, hi) * sparsity;
 }
 
-// Harness operator entry (tests/test_utils.f90:38-116): trig(log(sqrt(atan2(e_min, e_max)))) * 1e-4f,
+// Harness operator entry (src/tests/test_utils.f90:38-116): trig(log(sqrt(atan2(e_min, e_max)))) * 1e-4f,
 // e_min/e_max = table entries at min(i,j)/max(i,j); A (trig=0, cos): + real(i) on the diagonal;
 // B (trig=1, sin): exactly 1 on the diagonal.
-__device__ __forceinline__ double dav_harness_entry(const double* __restrict__ e, int trig, int64_t gi, int64_t gj) {
+// dav_harness_entry_libm: the formula as written - four library calls per entry (DAV_HARNESS_LIBM=1; the A/B path of round 5).
+__device__ __forceinline__ double dav_harness_entry_libm(const double* __restrict__ e, int trig, int64_t gi, int64_t gj) {
   const double scale = (double)1e-4f;
   int64_t lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
   double t = log(sqrt(atan2(e[lo], e[hi])));
@@ -66,6 +67,38 @@ __device__ __forceinline__ double dav_harness_entry(const double* __restrict__ e
     return gi == gj ? v + (double)(float)(gi + 1) : v;
   }
   return gi == gj ? 1.0 : sin(t) * scale;
+}
+// The same entries as a function of ONE variable (round 6).  0 < e_lo <= e_hi, so atan2(e_lo, e_hi) = atan(exp(log e_lo - log e_hi)):
+// with the table l2_i = 2 log e_i (made once, on the host, from the e_i the caller hands over) the off-diagonal entry is
+//   scale * trig(0.5 log atan exp((x - 1) / 2)),   x = 1 - |l2_i - l2_j|  in [-1, 1]
+// - a function analytic far beyond the interval, evaluated as a polynomial in x by Horner's rule: one subtraction, one addition and
+// 17 (cos) / 19 (sin) FMAs instead of atan2 + sqrt + log + cos.  Coefficients: harness_poly.h, generated (and checked against 60-digit
+// arithmetic: 0.6 / 1.2 ulp) by tools/gen_harness_poly.py; the literal 1e-4f is folded into them.
+#include "harness_poly.h"
+template <bool SIN>
+__device__ __forceinline__ double dav_harness_poly(double li, double lj) {
+  const double x = 1.0 - __builtin_fabs(li - lj);
+  if constexpr (!SIN) {
+    constexpr double cf[DAV_HARNESS_COS_DEGREE + 1] = {DAV_HARNESS_COS_COEFFS};
+    double acc = cf[DAV_HARNESS_COS_DEGREE];
+#pragma unroll
+    for (int k = DAV_HARNESS_COS_DEGREE - 1; k >= 0; --k) acc = __builtin_fma(acc, x, cf[k]);
+    return acc;
+  } else {
+    constexpr double cf[DAV_HARNESS_SIN_DEGREE + 1] = {DAV_HARNESS_SIN_COEFFS};
+    double acc = cf[DAV_HARNESS_SIN_DEGREE];
+#pragma unroll
+    for (int k = DAV_HARNESS_SIN_DEGREE - 1; k >= 0; --k) acc = __builtin_fma(acc, x, cf[k]);
+    return acc;
+  }
+}
+// full entry (diagonal included) from the table of 2 log e_i
+__device__ __forceinline__ double dav_harness_entry_poly(const double* __restrict__ l2, int trig, int64_t gi, int64_t gj) {
+  if (trig == 0) {
+    const double v = dav_harness_poly<false>(l2[gi], l2[gj]);
+    return gi == gj ? v + (double)(float)(gi + 1) : v;
+  }
+  return gi == gj ? 1.0 : dav_harness_poly<true>(l2[gi], l2[gj]);
 }
 
 enum { DAV_KIND_NONE = 0, DAV_KIND_DENSE = 1, DAV_KIND_HASHED = 2, DAV_KIND_HARNESS = 3,
@@ -78,5 +111,11 @@ struct OpParams {          // passed by value to the matrix-free kernels
   int use_diag;
   double diag_val;
   int trig;
-  const double* e_table;   // device, n entries
+  const double* e_table;   // device, n entries: exp(real(i) / real(n)) as the caller evaluated it (single precision)
+  const double* l2_table;  // device, roundup(n, 256) + 256 entries: 2 log e_i, zero behind n (harness operator, polynomial form)
+  int libm;                // harness operator: 1 = the four library calls per entry (DAV_HARNESS_LIBM=1), 0 = the polynomial form
 };
+// entry of the harness operator in whichever form the engine was created with
+__device__ __forceinline__ double dav_harness_entry(const OpParams& op, int64_t gi, int64_t gj) {
+  return op.libm ? dav_harness_entry_libm(op.e_table, op.trig, gi, gj) : dav_harness_entry_poly(op.l2_table, op.trig, gi, gj);
+}

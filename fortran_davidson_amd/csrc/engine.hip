@@ -216,6 +216,7 @@ Tune tune_from_env() {
   t.gram_wgs = geti("DAV_GRAM_WGS", t.gram_wgs);
   gram_set_fuse_chunks(geti("DAV_GRAM_FUSE", 0));
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
+  t.harness_libm = geti("DAV_HARNESS_LIBM", 0);
   return t;
 }
 
@@ -538,6 +539,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
     pool_free(e->op[w].a);
     pool_free(e->op[w].a32);
     pool_free(e->op[w].e_table);
+    pool_free(e->op[w].l2_table);
   }
   lt.lap("operators");
   if (e->stream) { (void)hipStreamSynchronize(e->stream); pool_stream_put(e->stream, e->device); }
@@ -631,7 +633,7 @@ extern "C" int dav_panel_unit_column(dav_handle_t e, int panel, int col, int k) 
   CHK(bind(e));
   CHK(check_panel(e, panel, col, 1));
   if (k < 0) return fail("dav_panel_unit_column: bad index");
-  if ((size_t)k >= e->basis_order.size()) return 1;                       // not an error: the caller falls back to another direction
+  if ((size_t)k >= e->basis_order.size()) return DAV_NO_SUCH_ENTRY;       // not an error: the caller falls back to another direction
   const int64_t idx = e->basis_order[(size_t)k];
   int64_t* slot = e->idx_dev + (e->cols_alloc - 1);                        // (dav_init_basis uses the front of idx_dev; stream order keeps them apart)
   HIPCHK(hipMemcpyAsync(slot, &idx, sizeof(int64_t), hipMemcpyHostToDevice, e->stream));

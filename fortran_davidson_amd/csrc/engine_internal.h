@@ -124,7 +124,9 @@ struct OpDesc {
   int use_diag = 0;
   double diag_val = 0;
   int trig = 0;
-  double* e_table = nullptr; // device
+  bool harness_libm = false; // harness operator: entries by the four library calls (Tune::harness_libm when the operator was set)
+  double* e_table = nullptr; // device: the caller's exp(real(i) / real(n)) table (harness operator)
+  double* l2_table = nullptr; // device: 2 log e_i, roundup(n, 256) + 256 entries, zero behind n (polynomial form of the harness operator)
   double* diag = nullptr;    // device, nloc_pad (local rows)
   int storage = 0;           // dense: 0 = full, 1 = symmetric-tiled (lower block triangle)
   float* a32 = nullptr;      // fp32 copy of the symmetric tiles: operand of the mixed-precision inner sweeps (lazy)
@@ -174,6 +176,7 @@ struct Tune {
   int coll_direct = 0;    // DAV_COLL_DIRECT=1: all-gather / reduce-scatter as direct exchanges (grouped send / receive to every peer) instead of RCCL's collectives (opt-in)
   int b_resident = 1;     // DAV_B_RESIDENT: keep what fits of a generated second operator resident as stored tiles (dav_set_operator_hashed, storage 1)
   bool gjd_trace = false; // DAV_GJD_TRACE
+  int harness_libm = 0;   // DAV_HARNESS_LIBM=1: the harness operator's entries by four library calls each (A/B; default: the one-variable polynomial)
 };
 Tune tune_from_env();
 

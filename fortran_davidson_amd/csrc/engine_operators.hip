@@ -483,9 +483,9 @@ extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed,
 }
 
 OpParams op_params(const OpDesc& o) {
-  OpParams p;
+  OpParams p{};
   p.kind = o.kind; p.seed = o.seed; p.sparsity = o.sparsity; p.use_diag = o.use_diag; p.diag_val = o.diag_val;
-  p.trig = o.trig; p.e_table = o.e_table;
+  p.trig = o.trig; p.e_table = o.e_table; p.l2_table = o.l2_table; p.libm = o.harness_libm;
   return p;
 }
 
@@ -519,6 +519,22 @@ extern "C" int dav_set_operator_harness(dav_handle_t e, int which, const double*
   if (o.storage == 1) CHK(sym_setup(e));
   if (!o.e_table) HIPCHK(pool_malloc(&o.e_table, sizeof(double) * e->n));
   HIPCHK(hipMemcpyAsync(o.e_table, e_table, sizeof(double) * e->n, hipMemcpyHostToDevice, e->stream));
+  // the one-variable form of the entries (common.h: dav_harness_poly) reads 2 log e_i; made here, once, from the table the caller
+  // evaluated (host log: correctly rounded to within an ulp); padded with zeros so that the sweeps read whole tiles' worth of it
+  o.harness_libm = e->tune.harness_libm != 0;
+  const size_t l2n = (size_t)roundup(e->n, SYM_TB) + SYM_TB;
+  std::vector<double> l2(l2n, 0.0);
+  for (int64_t i = 0; i < e->n; ++i) {
+    if (!(e_table[i] > 0.0)) return fail("dav_set_operator_harness: the table must hold positive numbers (exp(real(i) / real(n)))");
+    l2[(size_t)i] = 2.0 * std::log(e_table[i]);
+    // the one-variable form needs what exp(real(i) / real(n)) guarantees: a table that does not descend (then e_min / e_max are
+    // the entries at the lower / higher index, atan2's quotient is at most 1) and spans at most a factor e; any other table is
+    // served by the formula as written
+    if (i > 0 && l2[(size_t)i] < l2[(size_t)i - 1]) o.harness_libm = true;
+  }
+  if (e->n > 0 && l2[(size_t)e->n - 1] - l2[0] > 2.0 * (1.0 + 1e-6)) o.harness_libm = true;
+  if (!o.l2_table) HIPCHK(pool_malloc(&o.l2_table, sizeof(double) * l2n));
+  HIPCHK(hipMemcpyAsync(o.l2_table, l2.data(), sizeof(double) * l2n, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
   CHK(refresh_diag_host(e, which));

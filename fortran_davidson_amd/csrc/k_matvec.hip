@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void matvec_free_kernel(OpParams op, int64_t r
         } else if (li[rt] < nloc && gj < n) {
           int64_t gi = row0 + li[rt];
           if (KIND == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
-          else v = dav_harness_entry(op.e_table, op.trig, gi, gj);
+          else v = dav_harness_entry(op, gi, gj);
         }
         a[rt] = v;
       }

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(512, 1) void matvec_sym8_kernel(const double* __res
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int64_t cj = gj + 4 * u;
-          a[u].x = (gi < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi, cj) : 0.0;
-          a[u].y = (gi + 1 < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi + 1, cj) : 0.0;
+          a[u].x = (gi < n && cj < n) ? dav_harness_entry(op, gi, cj) : 0.0;
+          a[u].y = (gi + 1 < n && cj < n) ? dav_harness_entry(op, gi + 1, cj) : 0.0;
         }
       } else if (J < I && rows_inside) {
         // strictly below the diagonal and inside the matrix: lo = column, hi = row, no tests per entry

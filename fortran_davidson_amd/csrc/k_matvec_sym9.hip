@@ -53,8 +53,13 @@ __device__ __forceinline__ double mfma4_f64(double a, double b, double c) { retu
 
 // HARN (with GEN): the generated operator is the reference's matrix-free test operator (src/tests/test_utils.f90:72-116,
 // src/benchmark_free.f90:38-63: cos / sin (log (sqrt (atan2 (e_lo, e_hi)))) * 1e-4 from a table of exp(real(i) / real(n))), every
-// symmetric pair evaluated ONCE and used for both products - bound by fp64 transcendental throughput, not by memory.
-template <int R, bool GEN, bool F32, bool M4, bool HARN = false>
+// symmetric pair evaluated ONCE and used for both products.  HARN = 1 / 2: the cos / sin operator.  Round 6: the entries are a function
+// of ONE variable (common.h: dav_harness_poly - a table of 2 log e_i, one subtraction, one addition and 17 / 19 FMAs per entry instead of
+// atan2 + sqrt + log + cos: ~20 VALU instructions against ~395); the wave keeps the table values of its 128 rows in registers for the
+// whole work item and fetches the 16 column values of a unit one unit ahead.  Tiles strictly below the diagonal inside the matrix take
+// that path, the diagonal tile and the ragged last block row the same polynomial behind bounds and diagonal tests.  HARN = 3: the formula
+// as written, four library calls per entry (an engine created with DAV_HARNESS_LIBM=1, or a table that is not exp(real(i) / real(n))).
+template <int R, bool GEN, bool F32, bool M4, int HARN = 0>
 __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restrict__ tiles_v, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items,
                                                              const int* __restrict__ zslot_begin, const double* __restrict__ xt,
@@ -157,12 +162,17 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     if constexpr (GEN) {
       const int64_t gi = (int64_t)Ie * SYM_TB + 128 * rhalf + 32 * hs + 2 * c;
       const int64_t gj = (int64_t)J * SYM_TB + col + g;
-      if constexpr (HARN) {
+      if constexpr (HARN != 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int64_t cj = gj + 4 * u;
-          a[u].x = (gi < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi, cj) : 0.0;
-          a[u].y = (gi + 1 < n && cj < n) ? dav_harness_entry(op.e_table, op.trig, gi + 1, cj) : 0.0;
+          if constexpr (HARN == 3) {
+            a[u].x = (gi < n && cj < n) ? dav_harness_entry_libm(op.e_table, op.trig, gi, cj) : 0.0;
+            a[u].y = (gi + 1 < n && cj < n) ? dav_harness_entry_libm(op.e_table, op.trig, gi + 1, cj) : 0.0;
+          } else {
+            a[u].x = (gi < n && cj < n) ? dav_harness_entry_poly(op.l2_table, HARN - 1, gi, cj) : 0.0;
+            a[u].y = (gi + 1 < n && cj < n) ? dav_harness_entry_poly(op.l2_table, HARN - 1, gi + 1, cj) : 0.0;
+          }
         }
       } else if (J < Ie && ((int64_t)Ie + 1) * SYM_TB <= n) {
         const uint64_t k0 = (uint64_t)gi + seedmix;
@@ -217,17 +227,56 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     }
   };
 
+  // harness operator, polynomial form: 2 log e of this wave's rows (rows 2c, 2c + 1 of the four half-steps; a wave without a block row
+  // generates - and masks - the tile of block row Imax, as the stored kernels read it) and of a unit's tile columns g + 4u
+  const int Irow = I <= Imax ? I : Imax;
+  f64x2 lrow[4];
+  double lcol[4], lcoln[4];
+  auto load_lcol = [&](int q, double (&lc)[4]) {
+    if constexpr (HARN == 1 || HARN == 2) {
+      q = q < nunits ? q : nunits - 1;
+      const int J = J0 + q / UPJ, col = (q % UPJ) * BW + w * 16;
+      const double* lp = op.l2_table + (int64_t)J * SYM_TB + col + g;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lc[u] = lp[4 * u];
+    }
+  };
+  if constexpr (HARN == 1 || HARN == 2) {
+#pragma unroll
+    for (int hs = 0; hs < 4; ++hs) lrow[hs] = *reinterpret_cast<const f64x2*>(op.l2_table + (int64_t)Irow * SYM_TB + 128 * rhalf + 32 * hs + 2 * c);
+    load_lcol(0, lcol);
+  }
+  // half-step hs of unit q of the harness operator -> rows 2c, 2c + 1 of tile columns 4u + g
+  auto harness_hs = [&](int q, int hs, f64x2 (&a)[4]) {
+    if constexpr (HARN != 0) {
+      const int J = J0 + q / UPJ;
+      if (HARN != 3 && J < Irow && ((int64_t)Irow + 1) * SYM_TB <= n) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u].x = dav_harness_poly<HARN == 2>(lrow[hs].x, lcol[u]);
+          a[u].y = dav_harness_poly<HARN == 2>(lrow[hs].y, lcol[u]);
+        }
+      } else {
+        RingT now[4];
+        load_hs(q * 4 + hs, now);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)now[u].x, (double)now[u].y};
+      }
+    }
+  };
+
   double b[4][2], bn[4][2];
   load_b(0, b);
   // (the transcendental test operator is evaluated where it is consumed: there is no load latency to run ahead of, and the ring's
   // 64 registers are what its four library calls per entry need - with the ring the kernel spilled 150-230 bytes per lane)
-  if constexpr (!HARN) {
+  if constexpr (HARN == 0) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) load_hs(d, ra[d]);
   }
 
   for (int q = 0; q < nunits; ++q) {
     load_b(q + 1, bn);
+    load_lcol(q + 1, lcoln);
     const int J = J0 + q / UPJ;
     const double zm = (I <= Imax && J < I) ? 1.0 : 0.0;
     int xoff = (M4 ? (c & 3) : (c < XROWS ? c : XROWS)) * XT + 128 * hh + 4 * g;   // opaque: keeps the X_I reads inside the loop
@@ -240,11 +289,8 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
 #pragma unroll
     for (int hs = 0; hs < 4; ++hs) {
       f64x2 a[4];
-      if constexpr (HARN) {
-        RingT now[4];
-        load_hs(q * 4 + hs, now);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)now[u].x, (double)now[u].y};
+      if constexpr (HARN != 0) {
+        harness_hs(q, hs, a);
       } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] = f64x2{(double)ra[hs][u].x, (double)ra[hs][u].y};
@@ -337,6 +383,10 @@ __global__ __launch_bounds__(512, 1) void matvec_sym9_kernel(const void* __restr
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { b[u][0] = bn[u][0]; b[u][1] = bn[u][1]; }
+    if constexpr (HARN == 1 || HARN == 2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lcol[u] = lcoln[u];
+    }
   }
   __syncthreads();
   flush_strip(nunits / UPS - 1);
@@ -379,14 +429,20 @@ void launch_matvec_sym9(hipStream_t st, int R, bool gen, const void* tiles, bool
                      kcols, npair, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
   // m4 = false (Tune::sym_mfma4 = 0): the k <= 8 sweep of a stored fp64 matrix on the 16-wide MFMA (A/B runs)
   const bool harness = gen && op.kind == DAV_KIND_HARNESS;
+  const bool hsin = harness && op.trig != 0;
+  const bool hlibm = harness && op.libm != 0;
   if (R == 4) {
-    if (harness) DAV_SYM9_LAUNCH(4, true, false, true, true);
+    if (hlibm) DAV_SYM9_LAUNCH(4, true, false, true, 3);
+    else if (hsin) DAV_SYM9_LAUNCH(4, true, false, true, 2);
+    else if (harness) DAV_SYM9_LAUNCH(4, true, false, true, 1);
     else if (gen) DAV_SYM9_LAUNCH(4, true, false, true);
     else if (tiles_f32) DAV_SYM9_LAUNCH(4, false, true, true);
     else if (m4) DAV_SYM9_LAUNCH(4, false, false, true);
     else DAV_SYM9_LAUNCH(4, false, false, false);
   } else {
-    if (harness) DAV_SYM9_LAUNCH(2, true, false, false, true);
+    if (hlibm) DAV_SYM9_LAUNCH(2, true, false, false, 3);
+    else if (hsin) DAV_SYM9_LAUNCH(2, true, false, false, 2);
+    else if (harness) DAV_SYM9_LAUNCH(2, true, false, false, 1);
     else if (gen) DAV_SYM9_LAUNCH(2, true, false, false);
     else if (tiles_f32) DAV_SYM9_LAUNCH(2, false, true, false);
     else DAV_SYM9_LAUNCH(2, false, false, false);

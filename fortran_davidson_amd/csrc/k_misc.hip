@@ -45,7 +45,7 @@ __global__ void diag_free_kernel(OpParams op, int64_t row0, int64_t nloc, double
   int64_t gi = row0 + i;
   double v;
   if (op.kind == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gi);
-  else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op.e_table, op.trig, gi, gi);
+  else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op, gi, gi);
   else v = 1.0;
   diag[i] = v;
 }
@@ -76,7 +76,7 @@ __global__ void gather_columns_free_kernel(OpParams op, int64_t row0, int64_t nl
   if (i < nloc) {
     const int64_t gi = row0 + i, gj = idx[c];
     if (op.kind == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
-    else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op.e_table, op.trig, gi, gj);
+    else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op, gi, gj);
     else v = gi == gj ? 1.0 : 0.0;
   }
   dst[(int64_t)c * ldd + i] = v;
@@ -95,7 +95,7 @@ __global__ void entries_free_kernel(OpParams op, const int64_t* __restrict__ idx
   const int64_t gi = idx[t % k], gj = idx[t / k];
   double v;
   if (op.kind == DAV_KIND_HASHED) v = dav_hashed_entry(op.seed, op.sparsity, op.use_diag, op.diag_val, gi, gj);
-  else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op.e_table, op.trig, gi, gj);
+  else if (op.kind == DAV_KIND_HARNESS) v = dav_harness_entry(op, gi, gj);
   else v = gi == gj ? 1.0 : 0.0;
   h0[t] = v;
 }

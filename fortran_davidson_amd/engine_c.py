@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("b_stored_launches", C.c_int64), ("b_generated_launches", C.c_int64)]
 
 
-ABI_VERSION = 106      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
+ABI_VERSION = 107      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
 
 
 def _dp(a):

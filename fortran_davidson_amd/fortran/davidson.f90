@@ -17,7 +17,9 @@ module davidson_device
   use, intrinsic :: iso_c_binding
   use numeric_kinds, only: dp
   use davidson_hip_c
-  use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_cholesky_inverse, lapack_matmul
+  use lapack_wrapper, only: lapack_rayleigh_ritz, lapack_matmul
+  use davidson_knobs
+  use davidson_ortho
   implicit none
   private
   public :: davidson_engine, engine_create, engine_destroy, engine_set_dense, engine_set_storage, env_device, env_storage_symmetric, env_storage, symmetry_probe, fits_as_full_rows, engine_set_device_rr, engine_set_inner_precision, &
@@ -48,6 +50,18 @@ module davidson_device
      real(dp) :: phase_seconds(8) = 0.0_dp
   end type davidson_engine
 
+  !> The N-long side of the block orthonormalisation (davidson_ortho: ortho_backend) on the engine's panels: K2 Gram launches, K3
+  !> block updates, replacement columns written into the basis panel
+  type, extends(ortho_backend) :: device_ortho
+     type(c_ptr) :: h = c_null_ptr
+     integer :: n = 0
+   contains
+     procedure :: gram => device_ortho_gram
+     procedure :: apply => device_ortho_apply
+     procedure :: unit_column => device_ortho_unit_column
+     procedure :: put_column => device_ortho_put_column
+  end type device_ortho
+
   !> Correction policies of the outer loop (see davidson_device_loop)
   integer, parameter, public :: POLICY_ALL = 0, POLICY_UNCONVERGED = 1, POLICY_LOCKING = 2
 
@@ -69,17 +83,6 @@ contains
     ierr = dav_free_buffers()
   end subroutine davidson_free_buffers
 
-  !> Device index from the environment (DAVIDSON_DEVICE, default 0): an engine knob that does not
-  !> touch the reference's argument lists (dense and matrix-free front ends alike).
-  function env_device() result(dev)
-    integer :: dev, stat, length
-    character(len=16) :: buf
-    dev = 0
-    call get_environment_variable("DAVIDSON_DEVICE", buf, length, stat)
-    if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) dev
-    if (stat /= 0) dev = 0
-  end function env_device
-
   !> Do `nmat` dense operators of order n fit the engine's device as full rows (8 n^2 bytes each), with a tenth of the memory left
   !> for the panels and the partial-sum slabs?  (dav_device_memory: what is free now.)
   function fits_as_full_rows(eng, n, nmat) result(fits)
@@ -90,70 +93,6 @@ contains
     call check_dav(dav_device_memory(eng%h, free_bytes, total_bytes), "dav_device_memory")
     fits = 8.0_dp * real(n, dp) * real(n, dp) * real(nmat, dp) <= 0.9_dp * real(free_bytes, dp)
   end function fits_as_full_rows
-
-  !> DAVIDSON_STORAGE for the dense front end: 1 = "symmetric", 0 = "full", -1 = not set (the front end decides by symmetry_probe)
-  function env_storage() result(mode)
-    integer :: mode, stat, length
-    character(len=16) :: buf
-    mode = -1
-    call get_environment_variable("DAVIDSON_STORAGE", buf, length, stat)
-    if (stat == 0 .and. length >= 3) then
-       if (buf(1:3) == "sym") mode = 1
-       if (buf(1:3) == "ful") mode = 0
-    end if
-  end function env_storage
-
-  !> Is the matrix symmetric where it is looked at?  Exact comparison of 8 sampled rows (the first, the last, six spread over the
-  !> order) with their columns at up to 512 positions each (the row's neighbourhood of the diagonal excluded: stride over the whole
-  !> order) - ~4000 pairs, a fraction of a millisecond whatever the order (a walk along a ROW of a column-major matrix is one cache
-  !> miss per entry: whole rows cost 3.5 ms at N=20000, a tenth of the upload they are meant to halve).  A matrix with a single
-  !> asymmetric entry outside the sample passes - as it passes the reference, which never looks; what the probe guards against is an
-  !> input that is not meant to be symmetric at all.
-  function symmetry_probe(matrix) result(symmetric)
-    real(dp), dimension(:, :), intent(in) :: matrix
-    logical :: symmetric
-    integer :: n, k, i, j, nsample, step
-    n = size(matrix, 1)
-    symmetric = size(matrix, 2) == n
-    if (.not. symmetric) return
-    nsample = min(n, 8)
-    step = max(1, n / 512)
-    do k = 0, nsample - 1
-       i = 1 + int(int(k, c_int64_t) * int(n - 1, c_int64_t) / int(max(nsample - 1, 1), c_int64_t))
-       do j = 1 + mod(k, step), n, step
-          if (matrix(i, j) /= matrix(j, i)) then
-             symmetric = .false.
-             return
-          end if
-       end do
-       ! the two corners of the row: the entries a one-sided (triangular) input would leave different
-       if (matrix(i, 1) /= matrix(1, i) .or. matrix(i, n) /= matrix(n, i)) then
-          symmetric = .false.
-          return
-       end if
-    end do
-  end function symmetry_probe
-
-  !> DAVIDSON_STORAGE=symmetric selects symmetric-tiled storage for the dense front end (engines: engine_set_storage)
-  function env_storage_symmetric() result(sym)
-    logical :: sym
-    integer :: stat, length
-    character(len=16) :: buf
-    call get_environment_variable("DAVIDSON_STORAGE", buf, length, stat)
-    sym = (stat == 0 .and. length >= 3)
-    if (sym) sym = buf(1:3) == "sym"
-  end function env_storage_symmetric
-
-  !> Widest basis the reference's policy can reach: m starts at 2*lowest and doubles while
-  !> m <= max_dim (src/davidson.f90:195-213), so it may overshoot max_dim once.
-  pure function basis_capacity(lowest, max_dim) result(cap)
-    integer, intent(in) :: lowest, max_dim
-    integer :: cap
-    cap = 2 * lowest
-    do while (cap <= max_dim)
-       cap = 2 * cap
-    end do
-  end function basis_capacity
 
   subroutine engine_create(eng, n, lowest, max_dim_sub, gev, device, rank, nranks)
     type(davidson_engine), intent(out) :: eng
@@ -490,8 +429,11 @@ contains
     logical, allocatable :: has_converged(:)
     logical :: host_ops, done, lazy_x, have_all_pairs
     real(dp) :: t0, t1, phase_s(8), tol_unwanted, adaptive_c
+    type(device_ortho) :: dev
 
     phase_s = 0.0_dp
+    dev%h = h
+    dev%n = n
     host_ops = present(fun_a)
     if (host_ops) then
        meth = DAV_METHOD_DPR       ! the matrix-free driver never looks at `method`: always DPR (src/davidson.f90:428)
@@ -731,9 +673,9 @@ contains
           if (drr) then
              ! device-resident projected matrices: all passes first, then the sweep and the projection on the device
              if (have_pre) then
-                call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt))
+                call block_orthonormalise(dev, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt))
              else
-                call block_orthonormalise(h, n, m, kt)
+                call block_orthonormalise(dev, n, m, kt)
              end if
              call lap(4)
              call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
@@ -743,9 +685,9 @@ contains
           else
              ! first Gram-Schmidt pass only (the block is then orthonormal to ~1e-8) ...
              if (have_pre) then
-                call block_orthonormalise(h, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt), only_first=.true., last_pass=opass)
+                call block_orthonormalise(dev, n, m, kt, c_pre(:, 1:kt), g_pre(1:kt, 1:kt), only_first=.true., last_pass=opass)
              else
-                call block_orthonormalise(h, n, m, kt, only_first=.true., last_pass=opass)
+                call block_orthonormalise(dev, n, m, kt, only_first=.true., last_pass=opass)
              end if
              call lap(4)
              ! 6. ... one block sweep of A over the new columns as that pass left them ...
@@ -840,7 +782,7 @@ contains
          if (nnull > 0) then
             ! numerically null columns (rank-deficient corrections: rare): they are replaced by fresh directions, which have no
             ! images yet - separate passes, a second sweep of the block and dav_project
-            call block_orthonormalise(h, n, m, kt, first_pass=pass)
+            call block_orthonormalise(dev, n, m, kt, first_pass=pass)
             call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
             if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
             call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
@@ -1007,7 +949,7 @@ contains
             call lap(7)
          end if
          if (grow) then
-            call block_orthonormalise(h, n, m, kt, only_first=.true., last_pass=opass)
+            call block_orthonormalise(dev, n, m, kt, only_first=.true., last_pass=opass)
             call lap(4)
             call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
             call lap(5)
@@ -1050,116 +992,39 @@ contains
 
   end subroutine davidson_device_loop
 
-  !> Inner tolerance of the GJD solves for the Ritz pairs beyond `lowest`: 1e-2 relative (DAV_GJD_TOL_UNWANTED
-  !> overrides; 1e-4 until round 4).  Their corrections only enrich the search space; with 1e-6, 1e-4, 1e-2 and 1e-1
-  !> every golden GJD case keeps the reference's outer iteration count while the block sweeps of A drop by a third
-  !> to a half (N=40000 generalized: 62 -> 45 / 39 / 33 sweeps), and over a grid of 108 problems against the oracle's
-  !> exact solves (tests/gjd_policy_sweep.py: orders 150-500, lowest 2-8, sparsity 1e-3 - 5e-2, standard
-  !> and generalized) 1e-2 gives the iteration counts of 1e-4 in every case.  These pairs sit in the interior of the
-  !> projected spectrum, where MINRES on A - theta B converges slowest: at configs[3] they kept the inner solve
-  !> going for 13 of 18 steps after the wanted pairs had finished.  Hence the sign: a NEGATIVE tolerance (the default,
-  !> -1e-2) makes these pairs followers (dav_gjd_correction_n) - they stop at |t| or when every wanted pair has
-  !> stopped, whichever comes first: they get the inner steps the wanted pairs need, not a solve of their own
-  !> (144-problem sweep against the oracle: never more outer iterations than the reference's exact solves).
-  function gjd_tol_unwanted() result(t)
-    real(dp) :: t
-    integer :: stat, length
-    character(len=32) :: buf
-    t = -1.0e-2_dp
-    call get_environment_variable("DAV_GJD_TOL_UNWANTED", buf, length, stat)
-    if (stat == 0 .and. length > 0) read (buf(1:length), *, iostat=stat) t
-    if (stat /= 0 .or. t == 0.0_dp) t = -1.0e-2_dp
-  end function gjd_tol_unwanted
+  subroutine device_ortho_gram(be, m, kt, c, g)
+    class(device_ortho), intent(inout) :: be
+    integer, intent(in) :: m, kt
+    real(dp), intent(out) :: c(:, :), g(:, :)
+    call check_dav(dav_ortho_gram(be%h, int(m, c_int), int(kt, c_int), c, int(size(c, 1), c_int64_t), g, int(size(g, 1), c_int64_t)), &
+         "dav_ortho_gram")
+  end subroutine device_ortho_gram
 
-  !> Inner tolerance of the GJD solve for a WANTED pair whose residual norm is `err`: the correction equation is solved
-  !> only as far as the outer iteration can use it.  An exact solve (the reference's DSYSV) takes the residual from
-  !> err to ~err**2; an inexact one with relative tolerance tau to ~max(err**2, tau*err).  tau = c * tolerance / err
-  !> therefore leaves c * tolerance on top of what the exact solve reaches: where the reference converges (err**2 below
-  !> the tolerance) so does this, where it does not, the next residual is the reference's to within c * tolerance.
-  !> c = 0.01 (gjd_adaptive_factor), tau clipped to [1e-10, 1e-2].
-  function gjd_tol_wanted(err, tolerance, c) result(t)
-    real(dp), intent(in) :: err, tolerance, c
-    real(dp) :: t
-    t = 1.0e-10_dp
-    if (c > 0.0_dp .and. err > 0.0_dp) t = min(1.0e-2_dp, max(1.0e-10_dp, c * tolerance / err))
-    ! (A forcing term on top - no more accurate than c2 * err, because an exact solve "only" leaves ~err**2 - was measured and
-    ! dropped: these matrices converge faster than that estimate, and with c2 = 1e-3 already 11 of 144 problems need an outer
-    ! iteration more than the reference; profiles/experiments/r04_gjd_policy_sweep3.log.)
-  end function gjd_tol_wanted
+  subroutine device_ortho_apply(be, m, kt, c, mm)
+    class(device_ortho), intent(inout) :: be
+    integer, intent(in) :: m, kt
+    real(dp), intent(in) :: c(:, :), mm(:, :)
+    call check_dav(dav_ortho_apply(be%h, int(m, c_int), int(kt, c_int), c, int(size(c, 1), c_int64_t), mm, int(size(mm, 1), c_int64_t)), &
+         "dav_ortho_apply")
+  end subroutine device_ortho_apply
 
-  !> c of gjd_tol_wanted: 0.01; DAV_GJD_ADAPTIVE overrides (0 = the fixed 1e-10 of round 3).  Read once per solve, before the loop.
-  function gjd_adaptive_factor() result(c)
-    real(dp) :: c
-    integer :: stat, length
-    character(len=32) :: buf
-    c = 0.01_dp
-    call get_environment_variable("DAV_GJD_ADAPTIVE", buf, length, stat)
-    if (stat == 0 .and. length > 0) then
-       read (buf(1:length), *, iostat=stat) c
-       if (stat /= 0) c = 0.01_dp
-    end if
-  end function gjd_adaptive_factor
+  function device_ortho_unit_column(be, m, j, entry) result(ok)
+    class(device_ortho), intent(inout) :: be
+    integer, intent(in) :: m, j, entry
+    logical :: ok
+    integer(c_int) :: ierr
+    ierr = dav_panel_unit_column(be%h, DAV_PANEL_V, int(m + j - 1, c_int), int(entry, c_int))
+    ! DAV_NO_SUCH_ENTRY: the engine keeps no such entry of the start order - the caller takes another direction; anything else is an error
+    if (ierr /= 0_c_int .and. ierr /= DAV_NO_SUCH_ENTRY) call check_dav(ierr, "dav_panel_unit_column")
+    ok = ierr == 0_c_int
+  end function device_ortho_unit_column
 
-  !> order(k) = index of the k-th smallest entry (stable insertion sort: a handful of eigenvalues)
-  subroutine ascending_order(x, order)
-    real(dp), intent(in) :: x(:)
-    integer, intent(out) :: order(size(x))
-    integer :: a, b, t
-    do a = 1, size(x)
-       order(a) = a
-    end do
-    do a = 2, size(x)
-       t = order(a)
-       b = a - 1
-       do while (b >= 1)
-          if (x(order(b)) <= x(t)) exit
-          order(b + 1) = order(b)
-          b = b - 1
-       end do
-       order(b + 1) = t
-    end do
-  end subroutine ascending_order
-
-  function tick() result(t)
-    real(dp) :: t
-    integer(c_int64_t) :: count, rate
-    call system_clock(count, rate)
-    t = real(count, dp) / real(rate, dp)
-  end function tick
-
-  !> DAVIDSON_VERBOSE=2 (or more): one line per outer iteration (basis width, residual norms of the wanted pairs)
-  function trace_iterations() result(on)
-    logical :: on
-    integer :: stat, length, level
-    character(len=8) :: buf
-    on = .false.
-    call get_environment_variable("DAVIDSON_VERBOSE", buf, length, stat)
-    if (stat == 0 .and. length > 0) then
-       read (buf(1:length), *, iostat=stat) level
-       on = (stat == 0 .and. level >= 2)
-    end if
-  end function trace_iterations
-
-  !> After how many collapse restarts W = A*V (and B*V) of the kept block are recomputed instead of contracted (see the restart
-  !> branch of the loop): 8; DAV_REFRESH_EVERY overrides (1 = after every restart, as the reference does).
-  function restart_refresh_interval() result(k)
-    integer :: k, stat, length
-    character(len=16) :: buf
-    k = 8
-    call get_environment_variable("DAV_REFRESH_EVERY", buf, length, stat)
-    if (stat == 0 .and. length > 0) then
-       read (buf(1:length), *, iostat=stat) k
-       if (stat /= 0 .or. k < 1) k = 8
-    end if
-  end function restart_refresh_interval
-
-  function verbose() result(on)
-    logical :: on
-    integer :: stat, length
-    character(len=8) :: buf
-    call get_environment_variable("DAVIDSON_VERBOSE", buf, length, stat)
-    on = (stat == 0 .and. length > 0)
-  end function verbose
+  subroutine device_ortho_put_column(be, m, j, vec)
+    class(device_ortho), intent(inout) :: be
+    integer, intent(in) :: m, j
+    real(dp), intent(in) :: vec(:)
+    call check_dav(dav_panel_put(be%h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(size(vec), c_int64_t)), "dav_panel_put")
+  end subroutine device_ortho_put_column
 
   !> Apply host callbacks to basis columns c0+1..c0+k: download the block, call, upload A*V and B*V.
   subroutine apply_host_block(h, n, c0, k, fun_a, fun_b)
@@ -1177,409 +1042,6 @@ contains
     call check_dav(dav_panel_put(h, DAV_PANEL_BV, int(c0, c_int), int(k, c_int), img, int(n, c_int64_t)), &
          "dav_panel_put")
   end subroutine apply_host_block
-
-  !> Orthonormalise the kt columns T = V(:, m+1:m+kt) against V(:, 1:m) and among themselves
-  !> (replaces concatenate + lapack_qr of the whole basis, src/davidson.f90:210-213).
-  !> Each pass: one device Gram [V T]^T T, a kt x kt factorisation on the host (ortho_pass_transform:
-  !> T <- (T - V C) M), one device block update.  Two passes give orthonormality to
-  !> rounding; a direction that is numerically dependent (e.g. the correction of an already converged
-  !> pair) is replaced by a deterministic pseudo-random vector, as Householder QR would complete the
-  !> basis with an arbitrary direction.
-  !> only_first = .true.: return after the first pass that applied a transform (its number in last_pass) - the driver then
-  !> sweeps the block and runs the last pass together with the projection (project_with_last_pass); first_pass: number of
-  !> the first pass made here (a continuation).
-  subroutine block_orthonormalise(h, n, m, kt, c_first, g_first, only_first, last_pass, first_pass)
-    type(c_ptr), intent(in) :: h
-    integer, intent(in) :: n, m, kt
-    !> Gram blocks V^T T and T^T T of the block as it stands (first pass), when the caller already has them
-    real(dp), intent(in), optional :: c_first(:, :), g_first(:, :)
-    logical, intent(in), optional :: only_first
-    integer, intent(out), optional :: last_pass
-    integer, intent(in), optional :: first_pass
-    integer, parameter :: max_pass = 8
-    real(dp), allocatable :: c(:, :), g(:, :), mm(:, :), vec(:)
-    logical, allocatable :: null_cols(:)
-    integer, allocatable :: queue(:)
-    integer :: pass, j, nnull, pass0, nqueue, qpos, rounds
-    integer, parameter :: max_rounds = 12
-    logical :: first_gram
-    integer(c_int) :: ierr
-    real(dp) :: wmax, wmin
-    logical :: clean, stop_early
-
-    allocate(c(max(m, 1), kt), g(kt, kt), mm(kt, kt), null_cols(kt))
-    clean = .false.
-    stop_early = .false.
-    if (present(only_first)) stop_early = only_first
-    pass0 = 1
-    if (present(first_pass)) pass0 = first_pass
-    if (present(last_pass)) last_pass = pass0
-    pass = pass0
-    rounds = 0
-    first_gram = .true.
-    do
-       if (first_gram .and. present(c_first)) then
-          if (m > 0) c(1:m, :) = c_first
-          g = g_first
-       else
-          call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), g, &
-               int(kt, c_int64_t)), "dav_ortho_gram")
-       end if
-       first_gram = .false.
-       call ortho_pass_transform(pass, m, kt, c, g, mm, wmin, wmax, null_cols, nnull, detect=rounds < max_rounds)
-       if (nnull > 0) then
-          ! replace numerically null columns and repeat the pass (a replacement round is not a pass: however many rounds a block
-          ! needs, its passes are still to come; from the seventh round on every replacement is pseudo-random - generic vectors
-          ! cannot come back null as long as the basis is narrower than the space).  A block that twelve rounds have not settled
-          ! is a block the relative tests misjudge: they are switched off for it (detect) and the passes go on as they did
-          ! before those tests existed - rescaling, with the eigenvalue floor
-          rounds = rounds + 1
-          if (rounds > max_rounds + 4) then
-             print *, "generalized_eigensolver: a correction block keeps columns that are exactly zero"
-             error stop
-          end if
-          ! Round 1: the unit vector at the column's own entry of the start order (the (m + j)-th smallest diagonal entry: the
-          ! direction the initial guess would have taken next, and what the reference's Householder QR leaves in such a column when
-          ! the diagonal ascends with the index).  Rounds 2-6, for a column whose unit vector came back null (it lay in the span
-          ! of the healthy columns): the entries of THEIR slots, then the entries behind the block.  After that pseudo-random vectors.
-          if (.not. allocated(queue)) then
-             allocate(queue(2 * kt))
-             nqueue = 0
-             do j = 1, kt
-                if (.not. null_cols(j)) then
-                   nqueue = nqueue + 1
-                   queue(nqueue) = m + j - 1
-                end if
-             end do
-             do j = 1, kt
-                nqueue = nqueue + 1
-                queue(nqueue) = m + kt + j - 1
-             end do
-             qpos = 0
-          end if
-          do j = 1, kt
-             if (null_cols(j)) then
-                ierr = 1_c_int
-                if (rounds == 1) then
-                   ierr = dav_panel_unit_column(h, DAV_PANEL_V, int(m + j - 1, c_int), int(m + j - 1, c_int))
-                else if (rounds <= 6 .and. qpos < nqueue) then
-                   qpos = qpos + 1
-                   ierr = dav_panel_unit_column(h, DAV_PANEL_V, int(m + j - 1, c_int), int(queue(qpos), c_int))
-                end if
-                if (ierr /= 0_c_int .and. ierr /= 1_c_int) call check_dav(ierr, "dav_panel_unit_column")
-                if (trace_iterations()) print "(a, i0, a, i0, a, i0, a, i0, a, l1)", "davidson trace: block at m=", m, " pass ", pass, " round ", rounds, &
-                     ": column ", j, " is numerically dependent; replaced by a unit vector: ", ierr == 0_c_int
-                if (ierr /= 0_c_int) then
-                   allocate(vec(n))
-                   call pseudo_random_vector(vec, m + j + 7919 * (pass + 31 * rounds))
-                   call check_dav(dav_panel_put(h, DAV_PANEL_V, int(m + j - 1, c_int), 1_c_int, vec, int(n, c_int64_t)), &
-                        "dav_panel_put")
-                   deallocate(vec)
-                end if
-             end if
-          end do
-          cycle
-       end if
-       call check_dav(dav_ortho_apply(h, int(m, c_int), int(kt, c_int), c, int(max(m, 1), c_int64_t), mm, &
-            int(kt, c_int64_t)), "dav_ortho_apply")
-       if (present(last_pass)) last_pass = pass
-       if (stop_early) return
-       ! a pass that started from a nearly orthonormal block (all scaled Gram eigenvalues close to 1
-       ! and negligible overlap with V) leaves it orthonormal to rounding
-       if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) then
-          clean = .true.
-          exit
-       end if
-       if (pass >= max(max_pass, pass0 + 2)) exit
-       pass = pass + 1
-    end do
-    if (.not. clean) then
-       print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
-    end if
-  end subroutine block_orthonormalise
-
-  !> raw = [V T']^T (Op T') ((m + kt) x kt) -> the same blocks for T'' = (T' - V C) M, whose image Op T'' = (Op T' - (Op V) C) M
-  !> follows it: rows 1:m  V^T Op T'' = (raw_V - P C) M,  rows m+1:  T''^T Op T'' = M^T (raw_T - C^T raw_V - raw_V^T C + C^T P C) M,
-  !> with P = pm(1:m, 1:m) the projected matrix of the basis so far (Op symmetric, as everywhere).
-  subroutine transform_projected(pm, raw, c2, mm, m, kt)
-    real(dp), intent(in) :: pm(:, :), c2(:, :), mm(:, :)
-    real(dp), intent(inout) :: raw(:, :)
-    integer, intent(in) :: m, kt
-    real(dp), allocatable :: pc(:, :), newv(:, :), tt(:, :)
-    integer :: p
-    p = m + kt
-    pc = lapack_matmul("N", "N", pm(1:m, 1:m), c2(1:m, 1:kt))
-    newv = lapack_matmul("N", "N", raw(1:m, 1:kt) - pc, mm(1:kt, 1:kt))
-    tt = raw(m + 1:p, 1:kt) - lapack_matmul("T", "N", c2(1:m, 1:kt), raw(1:m, 1:kt)) &
-         - lapack_matmul("T", "N", raw(1:m, 1:kt), c2(1:m, 1:kt)) + lapack_matmul("T", "N", c2(1:m, 1:kt), pc)
-    raw(1:m, 1:kt) = newv
-    raw(m + 1:p, 1:kt) = lapack_matmul("T", "N", mm(1:kt, 1:kt), lapack_matmul("N", "N", tt, mm(1:kt, 1:kt)))
-  end subroutine transform_projected
-
-  !> The transform of ONE block Gram-Schmidt pass from its Gram blocks C = V^T T (m x kt) and G = T^T T (kt x kt):
-  !> T <- (T - V C) M.  wmin / wmax: conditioning of the scaled Gram block G' = D (G - C^T C) D the pass started from (a pass
-  !> numbered >= 2 with wmin > 0.5 and wmax < 2 leaves the block orthonormal to rounding).  nnull > 0: the columns flagged in
-  !> null_cols are numerically null - no transform is made, the caller replaces them and repeats the pass.
-  subroutine ortho_pass_transform(pass, m, kt, c, g, mm, wmin, wmax, null_cols, nnull, detect)
-    integer, intent(in) :: pass, m, kt
-    !> .false.: only the absolute test for null columns (a zero correction) - the relative tests of dependence are skipped
-    logical, intent(in), optional :: detect
-    real(dp), intent(in) :: c(:, :), g(:, :)
-    real(dp), intent(out) :: mm(kt, kt), wmin, wmax
-    logical, intent(out) :: null_cols(kt)
-    integer, intent(out) :: nnull
-    real(dp), parameter :: floor_rel = 1.0e-14_dp, again_rel = 1.0e-10_dp, first_rel = 1.0e-13_dp
-    real(dp), allocatable :: gp(:, :), d(:), w(:), u(:, :)
-    integer :: j, l, info
-    logical :: chol_ok, relative_tests
-    real(dp) :: dev
-
-    relative_tests = .true.
-    if (present(detect)) relative_tests = detect
-    allocate(gp(kt, kt), d(kt), w(kt), u(kt, kt))
-    wmin = 0.0_dp
-    wmax = huge(1.0_dp)
-    gp = g(1:kt, 1:kt)
-    if (m > 0) then
-       if (m * kt >= 4096) then
-          gp = gp - lapack_matmul("T", "N", c(1:m, 1:kt), c(1:m, 1:kt))      ! DGEMM: the intrinsic is O(100 ms) at m = kt = 400
-       else
-          gp = gp - matmul(transpose(c(1:m, 1:kt)), c(1:m, 1:kt))
-       end if
-    end if
-    nnull = 0
-    do j = 1, kt
-       null_cols(j) = .not. (gp(j, j) > tiny(1.0_dp) * 1.0e16_dp)
-       ! "twice is enough": a column that a pass has already orthogonalised and normalised, and that loses five digits of its norm
-       ! to V AGAIN, lies in span(V) to working precision - what is left of it is rounding noise.  (Corrections confined to the span
-       ! of the basis and a few more rows - banded or block-structured operators: t = r / (theta - d) has the support of r - never
-       ! leave it however often they are projected and rescaled; the reference's Householder QR completes the basis with arbitrary
-       ! orthonormal columns there, src/davidson.f90:197-215, this driver with pseudo-random ones.)
-       if (relative_tests .and. pass >= 2 .and. .not. null_cols(j)) null_cols(j) = gp(j, j) < again_rel * g(j, j)
-       if (null_cols(j)) nnull = nnull + 1
-    end do
-    if (nnull > 0) return
-    do j = 1, kt
-       d(j) = 1.0_dp / sqrt(gp(j, j))
-    end do
-    do j = 1, kt
-       do l = 1, kt
-          gp(l, j) = gp(l, j) * d(l) * d(j)
-       end do
-    end do
-    ! deviation of the scaled Gram block from the identity
-    dev = 0.0_dp
-    do j = 1, kt
-       do l = 1, kt
-          if (l == j) then
-             dev = max(dev, abs(gp(l, j) - 1.0_dp))
-          else
-             dev = max(dev, abs(gp(l, j)))
-          end if
-       end do
-    end do
-    if (pass >= 2 .and. dev * real(kt, dp) < 1.0e-7_dp) then
-       ! already orthonormal to ~1e-7: G^(-1/2) = I - E/2 + O(E^2) is exact to rounding, no
-       ! eigen-decomposition needed (the usual state of the second pass)
-       do j = 1, kt
-          do l = 1, kt
-             mm(l, j) = -0.5_dp * gp(l, j) * d(l)
-          end do
-          mm(j, j) = (1.5_dp - 0.5_dp * gp(j, j)) * d(j)
-       end do
-       wmin = 1.0_dp - dev * real(kt, dp)
-       wmax = 1.0_dp + dev * real(kt, dp)
-    else
-       ! Cholesky route first (CholQR: M = D R^-1 with D G' D = R^T R): a k x k DPOTRF + DTRTRI costs a
-       ! fraction of a symmetric eigen-decomposition.  It is accepted only when the factor is well
-       ! conditioned (diagonal ratio); otherwise - rank deficiency, clustered corrections - the
-       ! eigen-decomposition route (SVQB) with its eigenvalue floor takes over.
-       call lapack_cholesky_inverse(gp, u, info)
-       chol_ok = .false.
-       if (info == 0) then
-          wmin = huge(1.0_dp)
-          wmax = 0.0_dp
-          do j = 1, kt
-             wmin = min(wmin, abs(u(j, j)))
-             wmax = max(wmax, abs(u(j, j)))
-          end do
-          chol_ok = wmax < 1.0e4_dp * wmin          ! cond(R) estimate below 1e4 => cond(G') below 1e8
-       end if
-       if (chol_ok) then
-          do j = 1, kt
-             do l = 1, kt
-                mm(l, j) = d(l) * u(l, j)
-             end do
-          end do
-          ! report the conditioning in the same terms as the eigenvalue route (1/r_jj^2 ~ eigenvalues)
-          wmin = 1.0_dp / (wmax * wmax)
-          wmax = wmin * 1.0e8_dp
-       else
-          if (relative_tests .and. pass >= 2) then
-             ! ... and the same for columns that depend on EACH OTHER after a pass has already orthonormalised the block: those the
-             ! left-to-right factorisation cannot reach (remaining pivot below again_rel) are replaced, not rescaled
-             call dependent_columns(gp, kt, again_rel, null_cols, nnull)
-             if (nnull > 0) return
-          else if (relative_tests .and. ortho_early()) then
-             ! the FIRST pass already sees dependence that is exact up to rounding (remaining pivot at the noise level of the Gram
-             ! product: the corrections of a banded matrix, section 0 of DESIGN.md): replaced before the block is swept, instead of a
-             ! sweep of noise columns, a second pass that finds them, and a second sweep.  Conservative (dependent_columns: noise)
-             do j = 1, kt
-                w(j) = 64.0_dp * epsilon(1.0_dp) * g(j, j) * d(j) * d(j)          ! d(j)**2 = 1 / gp(j, j) before the scaling
-             end do
-             call dependent_columns(gp, kt, first_rel, null_cols, nnull, w)
-             if (nnull > 0) return
-          end if
-          call lapack_rayleigh_ritz(gp, w, u, kt)
-          wmax = maxval(w)
-          wmin = minval(w)
-          do j = 1, kt
-             w(j) = max(w(j), floor_rel * wmax)
-          end do
-          do j = 1, kt
-             do l = 1, kt
-                mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
-             end do
-          end do
-       end if
-    end if
-  end subroutine ortho_pass_transform
-
-  !> Structural rank deficiency of a correction block is looked for at the FIRST pass already (it saves a banded matrix the sweep
-  !> of its noise columns); DAV_ORTHO_EARLY=0 turns that off (A/B knob).  The first-pass test is conservative (dependent_columns:
-  !> noise): before the first pass the columns are not orthogonal to the basis, the projected Gram block G - C^T C carries the
-  !> rounding of G at the scale of the UNPROJECTED columns, and a threshold of 1e-13 of the projected norms sits below that noise
-  !> for corrections that lie mostly in the span of the basis (generalized problems with a second operator far from the identity:
-  !> an unconditional test accepted noise pivots and rejected every column behind them, round after round) - such columns, and
-  !> everything behind an ill-conditioned accepted column, are left to the second pass.
-  function ortho_early() result(on)
-    logical :: on
-    integer :: stat, length
-    character(len=8) :: buf
-    integer, save :: cached = -1
-    if (cached < 0) then
-       cached = 1
-       call get_environment_variable("DAV_ORTHO_EARLY", buf, length, stat)
-       if (stat == 0 .and. length > 0) then
-          if (buf(1:1) == "0") cached = 0
-       end if
-    end if
-    on = cached == 1
-  end function ortho_early
-
-  !> Left-to-right Cholesky of a Gram block with unit diagonal: a column whose remaining pivot - once the accepted columns to its
-  !> left are eliminated - falls below thr depends on them to working precision and is skipped (dep, ndep).  Left to right, not
-  !> pivoted, because that is the order in which the reference's Householder QR finds its dependent columns: the completion
-  !> vectors then land in the same slots.
-  subroutine dependent_columns(gs, kt, thr, dep, ndep, noise)
-    integer, intent(in) :: kt
-    real(dp), intent(in) :: gs(kt, kt), thr
-    logical, intent(out) :: dep(kt)
-    integer, intent(out) :: ndep
-    !> first pass only: noise(j) = rounding level of column j's entries of gs (the projected Gram block carries the rounding of the
-    !> unprojected one: eps g_jj / gp_jj).  With it the test is conservative: a column is only called dependent where the block
-    !> can tell - its own entries are accurate to thr, and every column accepted before it was accepted with a pivot far above
-    !> the noise (>= 1e-6) - everything else is left to the second pass
-    real(dp), intent(in), optional :: noise(kt)
-    real(dp) :: l(kt, kt), rem
-    integer :: i, j, nacc, acc(kt)
-    logical :: can_tell
-    l = 0.0_dp
-    dep = .false.
-    ndep = 0
-    nacc = 0
-    can_tell = .true.
-    do j = 1, kt
-       ! row j of the factor against the accepted columns
-       do i = 1, nacc
-          l(j, i) = (gs(j, acc(i)) - dot_product(l(j, 1:i - 1), l(acc(i), 1:i - 1))) / l(acc(i), i)
-       end do
-       rem = gs(j, j) - dot_product(l(j, 1:nacc), l(j, 1:nacc))
-       if (rem >= thr) then
-          nacc = nacc + 1
-          acc(nacc) = j
-          l(j, nacc) = sqrt(rem)
-          if (present(noise) .and. rem < 1.0e-6_dp) can_tell = .false.
-       else if (.not. present(noise)) then
-          dep(j) = .true.
-          ndep = ndep + 1
-       else if (can_tell .and. noise(j) < thr) then
-          dep(j) = .true.
-          ndep = ndep + 1
-       else
-          ! cannot tell: keep the column (with a pivot at the threshold, so that the factor stays finite) and stop judging
-          nacc = nacc + 1
-          acc(nacc) = j
-          l(j, nacc) = sqrt(thr)
-          can_tell = .false.
-       end if
-    end do
-  end subroutine dependent_columns
-
-  !> yk (m x kt) <- yk * M with M = G^(-1/2)-like (Cholesky R^-1, or the eigen-decomposition route with an eigenvalue
-  !> floor when the factor is ill-conditioned), G = yk^T yk: the columns of the result are Euclidean-orthonormal.
-  subroutine restart_transform(yk, m, kt)
-    integer, intent(in) :: m, kt
-    real(dp), intent(inout) :: yk(m, kt)
-    real(dp), allocatable :: g(:, :), u(:, :), w(:), mm(:, :), d(:)
-    integer :: j, l, info, pass
-    real(dp) :: wmin, wmax
-    allocate(g(kt, kt), u(kt, kt), w(kt), mm(kt, kt), d(kt))
-    do pass = 1, 2                      ! the second pass sees G = I + O(eps cond): it removes what the first left
-       g = lapack_matmul("T", "N", yk, yk)
-       do j = 1, kt
-          d(j) = 1.0_dp / sqrt(g(j, j))
-       end do
-       do j = 1, kt
-          do l = 1, kt
-             g(l, j) = g(l, j) * d(l) * d(j)
-          end do
-       end do
-       call lapack_cholesky_inverse(g, u, info)
-       wmin = huge(1.0_dp)
-       wmax = 0.0_dp
-       if (info == 0) then
-          do j = 1, kt
-             wmin = min(wmin, abs(u(j, j)))
-             wmax = max(wmax, abs(u(j, j)))
-          end do
-       end if
-       if (info == 0 .and. wmax < 1.0e4_dp * wmin) then
-          do j = 1, kt
-             do l = 1, kt
-                mm(l, j) = d(l) * u(l, j)
-             end do
-          end do
-       else
-          call lapack_rayleigh_ritz(g, w, u, kt)
-          wmax = maxval(w)
-          do j = 1, kt
-             w(j) = max(w(j), 1.0e-14_dp * wmax)
-          end do
-          do j = 1, kt
-             do l = 1, kt
-                mm(l, j) = d(l) * u(l, j) / sqrt(w(j))
-             end do
-          end do
-       end if
-       yk = lapack_matmul("N", "N", yk, mm)
-    end do
-  end subroutine restart_transform
-
-  !> Deterministic filler direction (xorshift), entries in (-0.5, 0.5).
-  subroutine pseudo_random_vector(vec, salt)
-    real(dp), intent(out) :: vec(:)
-    integer, intent(in) :: salt
-    integer(c_int64_t) :: s
-    integer :: i
-    s = 88172645463325252_c_int64_t + int(salt, c_int64_t) * 2654435761_c_int64_t
-    do i = 1, size(vec)
-       s = ieor(s, shiftl(s, 13))
-       s = ieor(s, shiftr(s, 7))
-       s = ieor(s, shiftl(s, 17))
-       vec(i) = real(shiftr(s, 11), dp) / 9007199254740992.0_dp - 0.5_dp
-    end do
-  end subroutine pseudo_random_vector
 
 end module davidson_device
 

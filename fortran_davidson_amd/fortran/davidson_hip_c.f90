@@ -9,6 +9,8 @@ module davidson_hip_c
   integer(c_int), parameter :: DAV_PANEL_V = 0, DAV_PANEL_W = 1, DAV_PANEL_BV = 2, DAV_PANEL_X = 3, &
        DAV_PANEL_R = 4, DAV_PANEL_S = 5
   integer(c_int), parameter :: DAV_METHOD_DPR = 0, DAV_METHOD_GJD = 1, DAV_METHOD_NONE = 2
+  !> dav_panel_unit_column: "the engine keeps no such entry of the start order" (not an error)
+  integer(c_int), parameter :: DAV_NO_SUCH_ENTRY = 2
 
   type, bind(C) :: dav_stats
      integer(c_int64_t) :: n, nloc
@@ -28,7 +30,7 @@ module davidson_hip_c
   end type dav_stats
   !> DAV_HIP_ABI_VERSION of include/davidson_hip.h these interfaces were written against: engine_create checks that the
   !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101, 102 and 104)
-  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 106
+  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 107
 
   interface
      function dav_last_error() bind(C, name="dav_last_error") result(p)

@@ -83,9 +83,9 @@ typedef struct dav_stats {
 } dav_stats;
 
 /* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */
-/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next, 105 dav_free_buffers, 106 dav_set_operator_device) must not    */
+/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next, 105 dav_free_buffers, 106 dav_set_operator_device, 107 DAV_NO_SUCH_ENTRY) must not    */
 /* use the unsized call - the sized one, which copies at most `bytes` bytes, is safe across versions.   */
-#define DAV_HIP_ABI_VERSION 106
+#define DAV_HIP_ABI_VERSION 107
 const char* dav_last_error(void);
 int dav_version(void);
 
@@ -317,8 +317,10 @@ int dav_panel_get(dav_handle_t h, int panel, int c0, int k, double* out, int64_t
 int dav_panel_put(dav_handle_t h, int panel, int c0, int k, const double* in, int64_t ld);
 /* panel[:, col] <- the unit vector at the (k+1)-th smallest diagonal entry of operator A (the order dav_init_basis takes its start
  * vectors from; k counts from 0).  What the driver completes a rank-deficient correction block with (the reference's Householder QR
- * leaves unit vectors in such columns, src/davidson.f90:197-215).  Returns 1 - and leaves the column alone - when the engine keeps
- * no (k+1)-th entry of that order.  Since ABI 106. */
+ * leaves unit vectors in such columns, src/davidson.f90:197-215).  Returns DAV_NO_SUCH_ENTRY (2; until ABI 106: 1, the code of every
+ * failure) - and leaves the column alone - when the engine keeps no (k+1)-th entry of that order: not an error, the caller takes
+ * another direction; 1 is a failure like everywhere else (dav_last_error).  Since ABI 106. */
+#define DAV_NO_SUCH_ENTRY 2
 int dav_panel_unit_column(dav_handle_t h, int panel, int col, int k);
 int dav_set_width(dav_handle_t h, int m);
 
