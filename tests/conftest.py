@@ -21,6 +21,13 @@ if os.path.exists(os.path.join(_TEST_LIB_DIR, "libdavidson_hip.so")):
     os.environ["LD_LIBRARY_PATH"] = _TEST_LIB_DIR + (":" + os.environ["LD_LIBRARY_PATH"] if os.environ.get("LD_LIBRARY_PATH") else "")
 
 
+# device code of the tests themselves (tests/helpers/Makefile: the caller's own operator kernel) - __graft_entry__.build() makes it; a
+# tree built with `make -C fortran_davidson_amd` alone gets it here (hipcc cross-compiles without a GPU)
+if not os.path.exists(os.path.join(_TEST_LIB_DIR, "libuser_operator.so")) and os.path.exists("/opt/rocm/bin/hipcc"):
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "helpers")], capture_output=True)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -3,7 +3,9 @@ classes the generator-based sweeps never produce: banded, block diagonal, sparse
 repeated diagonal entries, negative and scaled spectra, strong coupling.  Prints one line per case; a case counts as a mismatch
 when the engine does not converge where the oracle does, its eigenvalues differ by more than 1e-7 or its residuals exceed the
 tolerance; differing iteration counts are reported separately (completion directions of rank-deficient blocks are arbitrary in the
-reference too).      python tests/structured_parity_sweep.py [ncases] [seed]"""
+reference too).      python tests/structured_parity_sweep.py [ncases] [seed] [only]
+`only` = comma-separated case numbers (0-based): every case is still DRAWN - the random stream is the sweep's - but only those are
+solved: how tests/golden/structured_iteration_differences.json re-runs single cases of a logged sweep."""
 import os
 import sys
 import time
@@ -16,6 +18,7 @@ from oracle import davidson_oracle as O    # noqa: E402
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = {int(x) for x in sys.argv[3].split(",")} if len(sys.argv) > 3 else None
 
 
 def sym(a):
@@ -94,6 +97,8 @@ for case in range(ncases):
     # restart width: the default (10 * lowest) or a narrow one (restarts between the completions of rank-deficient blocks)
     md = None if rng.random() < 0.6 else int(rng.integers(2 * lowest, 5 * lowest + 1))
     what += "" if md is None else f" md={md}"
+    if only is not None and case not in only:
+        continue
     os.environ["DAVIDSON_STORAGE"] = storage
     try:
         with np.errstate(all="ignore"):
@@ -126,6 +131,6 @@ for case in range(ncases):
         differ += 1
     elif not ok_o and ok_e:
         flag = "   (engine converged, oracle did not)"
-    print(f"{kind:9s} {what:18s} n={n:4d} lowest={lowest} {method} gev={int(gev)} {storage:9s}: oracle iters {it_o:3d}, engine {it:3d}, "
+    print(f"#{case:<4d}" * (only is not None) + f"{kind:9s} {what:18s} n={n:4d} lowest={lowest} {method} gev={int(gev)} {storage:9s}: oracle iters {it_o:3d}, engine {it:3d}, "
           f"|dlam|/scale {dl:.1e}, residual {res:.1e}{flag}", flush=True)
 print(f"{ncases} cases in {time.time() - t0:.0f} s, mismatches: {bad}, iteration counts differ: {differ}")

@@ -4,7 +4,10 @@ this pool, and none of what runs here touches the HIP runtime.
   * fortran_davidson_amd/csrc/ingest.hip - text parser (dav_parse_text_f64's engine) and the two file readers: plain C++,
     compiled with g++ -fsanitize=address,undefined and driven by tests/host_sanitizer/ingest_driver.cpp;
   * the Fortran host units numeric_kinds / lapack_wrapper / array_utils: flang -fsanitize=address,
-    tests/host_sanitizer/fortran_units.f90."""
+    tests/host_sanitizer/fortran_units.f90;
+  * the rank decisions of the block orthonormalisation (fortran/davidson_ortho.f90: what replaced the reference's Householder QR of
+    the whole basis, src/lapack_wrapper.f90:176-236) on host arrays, against the column choices of DGEQRF with the column order
+    preserved, for DAV_ORTHO_EARLY = 0 and 1: tests/host_sanitizer/ortho_driver.f90."""
 import os
 import shutil
 import subprocess
@@ -49,3 +52,38 @@ def test_fortran_host_units_under_asan(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(ENV, ASAN_OPTIONS="detect_leaks=0"))
     assert run.returncode == 0 and "fortran units under the sanitizer: ok" in run.stdout, (run.stdout + run.stderr)[-4000:]
     assert "ERROR: AddressSanitizer" not in run.stderr, run.stderr[-4000:]
+
+
+MKL = ["-L/opt/conda/lib", "-Wl,--no-as-needed", "-lmkl_intel_lp64", "-lmkl_sequential", "-lmkl_core", "-Wl,-rpath,/opt/conda/lib"]
+
+
+@pytest.fixture(scope="module")
+def ortho_driver(tmp_path_factory):
+    if not os.path.exists(FC):
+        pytest.skip("flang not available")
+    tmp = tmp_path_factory.mktemp("ortho")
+    objs = []
+    for unit in ("numeric_kinds", "lapack_wrapper", "davidson_knobs", "davidson_ortho"):
+        obj = str(tmp / (unit + ".o"))
+        res = subprocess.run([FC, "-g", "-O1", "-fsanitize=address", "-module-dir", str(tmp), "-c", os.path.join(FSRC, unit + ".f90"), "-o", obj],
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        objs.append(obj)
+    exe = str(tmp / "ortho_driver")
+    res = subprocess.run([FC, "-g", "-O1", "-fsanitize=address", "-module-dir", str(tmp), os.path.join(HERE, "ortho_driver.f90"), *objs, *MKL, "-o", exe],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return exe
+
+
+@pytest.mark.parametrize("early", ["0", "1"])
+def test_rank_decisions_of_the_block_orthonormalisation_against_householder_qr(ortho_driver, early):
+    """Banded, block-diagonal, duplicated-column, zero-column, near-dependent (1e-3 .. 1e-14) and inside-the-basis correction blocks
+    through the PRODUCT's passes (block_orthonormalise over a host backend): the result is orthonormal, spans every column
+    Householder QR keeps, and the columns declared dependent are the ones QR declares (see the driver's header for the sense in
+    which DAV_ORTHO_EARLY = 0 matches); restart_transform and dependent_columns on inputs with known answers."""
+    run = subprocess.run([ortho_driver], capture_output=True, text=True, timeout=600, env=dict(ENV, ASAN_OPTIONS="detect_leaks=0", DAV_ORTHO_EARLY=early))
+    assert run.returncode == 0 and "ortho driver: ok" in run.stdout, (run.stdout + run.stderr)[-4000:]
+    assert f"DAV_ORTHO_EARLY on: {'T' if early == '1' else 'F'}" in run.stdout
+    assert "ERROR: AddressSanitizer" not in run.stderr, run.stderr[-4000:]
+    assert run.stdout.count("ok=T") >= 22 and "ok=F" not in run.stdout
