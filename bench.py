@@ -608,11 +608,16 @@ def main():
             dist.all_reduce(t, op=op)
             return float(t.item())
         local_ms = sc.apply_ms - sc.apply_comm_ms
+        # which way the collectives of wide blocks go: decided by the engine at its first wide block (dav_comm_path; the warm-up solves)
+        cpath = eng.c.comm_path() if transport.startswith("rccl") else {"selected": "program order", "trial_ran": False, "columns": 0,
+                                                                        "trial_ms_max_over_ranks": {}, "validated": {}}
         sweep_min, sweep_max = over_ranks(sc.apply_kernel_ms, dist.ReduceOp.MIN), over_ranks(sc.apply_kernel_ms, dist.ReduceOp.MAX)
         local_min, local_max = over_ranks(local_ms, dist.ReduceOp.MIN), over_ranks(local_ms, dist.ReduceOp.MAX)
         extras["comm"] = {
             "transport": transport, "ranks_reported_by_rccl": int(sc.comm_ranks), "world_size": world, "storage": storage,
             "collectives_overlapped_with_sweeps": bool(sc.comm_overlap),
+            "path_selected": cpath["selected"], "path_trial_ran": cpath["trial_ran"], "path_trial_columns": cpath["columns"],
+            "path_trial_ms_max_over_ranks": cpath["trial_ms_max_over_ranks"], "path_validated": cpath["validated"],
             "collectives_per_solve": int(sc.collectives),
             "allgather_ms_per_solve": round(sc.allgather_ms, 3), "allgather_MB_per_solve": round(sc.allgather_bytes / 1e6, 2),
             "reduce_scatter_ms_per_solve": round(sc.reduce_scatter_ms, 3), "reduce_scatter_MB_per_solve": round(sc.reduce_scatter_bytes / 1e6, 2),
@@ -628,6 +633,7 @@ def main():
                     "overlapped collectives their time runs under the sweeps and is not additive to apply_ms"}
         # the scalars also inside `roofline` (the driver's record keeps the scalars of that object)
         roofline.update({"comm_" + k_: v_ for k_, v_ in extras["comm"].items() if isinstance(v_, (int, float, bool, str)) and k_ != "note"})
+        roofline.update({"comm_path_trial_ms_" + k_.replace(" ", "_"): v_ for k_, v_ in cpath["trial_ms_max_over_ranks"].items()})
         roofline.update({"comm_model_" + k_: v_ for k_, v_ in extras["comm"]["model_ms_per_solve"].items() if isinstance(v_, (int, float))})
     if not args.headline_only:
         # opt-in correction policies (not the reference's, so never part of `value`): the same problem, same engine

@@ -217,6 +217,10 @@ Tune tune_from_env() {
   gram_set_fuse_chunks(geti("DAV_GRAM_FUSE", 0));
   t.gjd_trace = getenv("DAV_GJD_TRACE") != nullptr;
   t.harness_libm = geti("DAV_HARNESS_LIBM", 0);
+  t.no_h0 = geti("DAV_NO_H0", 0);
+  t.coll_select = geti("DAV_COLL_SELECT", 1);
+  t.coll_trial_corrupt = geti("DAV_COLL_TRIAL_CORRUPT", 0);
+  t.coll_forced = getenv("DAV_SYM_OVERLAP") != nullptr || getenv("DAV_COLL_DIRECT") != nullptr;
   return t;
 }
 
@@ -229,7 +233,9 @@ struct Pool {
   std::vector<std::pair<int, hipStream_t>> streams;      // idle engine streams (device, stream), synchronised before they came here
   uint64_t gen = 0;
   int enabled = -1;
-  size_t cap_bytes = 0;
+  size_t cap_bytes = 0;          // device blocks
+  size_t cap_pinned_bytes = 0;   // pinned host blocks: their own, much smaller cap (page-locked memory is the scarcer resource)
+  int destroying = 0;            // inside dav_destroy: the blocks that come back are an engine's whole set, kept for the next dav_create
 };
 Pool& pool() { static Pool* p = new Pool; return *p; }                               // never destroyed: outlives every engine
 constexpr size_t POOL_MIN_BYTES = 64 << 10;
@@ -243,6 +249,8 @@ bool pool_enabled(Pool& P) {
     // device full behind a single drop-in call
     const char* mb = getenv("DAVIDSON_BUFFER_CACHE_MB");
     P.cap_bytes = (size_t)(mb && atol(mb) >= 0 ? atol(mb) : 4096) << 20;
+    const char* pmb = getenv("DAVIDSON_BUFFER_CACHE_PINNED_MB");
+    P.cap_pinned_bytes = (size_t)(pmb && atol(pmb) >= 0 ? atol(pmb) : 256) << 20;
   }
   return P.enabled == 1;
 }
@@ -298,9 +306,13 @@ hipError_t pool_put(void* p, int kind) {
         P.live[i] = P.live.back();
         P.live.pop_back();
         if (!pool_enabled(P)) break;
+        // a block freed in the MIDDLE of an engine's life (a regrown slab, the staging panels of an upload) is not what the next
+        // dav_create will ask for: above 512 MiB it goes straight back instead of sitting idle through the solve (round-5 advisor; the
+        // staging panels of a small drop-in upload - 2 x 165 MB at N=20000 - stay: the next call's upload takes them)
+        if (P.destroying == 0 && b.bytes > ((size_t)512 << 20)) break;
         size_t held = 0;
-        for (const PoolBlock& q : P.idle) held += q.bytes;
-        if (held + b.bytes > P.cap_bytes) break;                 // over the cap: this block goes back to the device
+        for (const PoolBlock& q : P.idle) if ((q.kind == 0) == (b.kind == 0)) held += q.bytes;
+        if (held + b.bytes > (b.kind == 0 ? P.cap_bytes : P.cap_pinned_bytes)) break;   // over its cap (device and pinned blocks have their own): back it goes
         b.gen = P.gen;
         P.idle.push_back(b);
         return hipSuccess;
@@ -349,10 +361,15 @@ size_t pool_idle_device_bytes(int device) {
   return sum;
 }
 // end of a dav_destroy: what this engine returned stays; what was idle before the engine before it was destroyed goes
+void pool_begin_of_destroy() {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  ++P.destroying;
+}
 void pool_end_of_destroy() {
   Pool& P = pool();
   std::vector<PoolBlock> drop;
-  { std::lock_guard<std::mutex> lk(P.mu); ++P.gen; if (P.gen >= 2) drop = pool_take_idle(P, P.gen - 1); }
+  { std::lock_guard<std::mutex> lk(P.mu); if (P.destroying > 0) --P.destroying; ++P.gen; if (P.gen >= 2) drop = pool_take_idle(P, P.gen - 1); }
   for (const PoolBlock& b : drop) pool_release_block(b);
 }
 extern "C" int dav_free_buffers(void) {
@@ -493,6 +510,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
   lt.lap("sync");
   if (e->comm && g_rccl.lib) g_rccl.CommDestroy(e->comm);
   lt.lap("comm");
+  pool_begin_of_destroy();
   if (e->arena) pool_free(e->arena);
   if (e->arena_host) pool_host_free(e->arena_host);
   lt.lap("arenas");

@@ -179,6 +179,135 @@ int apply_sym_overlapped(E* e, int which, OpDesc& o, const double* src, int k, d
   return 0;
 }
 
+static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool partial, bool accumulate, const double* src, int k, double* dst,
+                         bool timed, bool inner);
+
+// ---- which way do the collectives of a wide block go?  (round 6) ---------------------------------------------------------------
+// Three ways exist (all three give the sweep's kernels the same operands and sum their partial products in a fixed order):
+//   program order   one all-gather, one 64-column launch, one reduce-scatter, RCCL's collectives on the engine's stream
+//   direct          the same program order with the all-gather / reduce-scatter as grouped ncclSend / ncclRecv to every peer and a
+//                   rank-order sum: the P - 1 point-to-point links of the xGMI mesh at once, whatever schedule RCCL would pick
+//   second stream   32-column chunks, the all-gather of chunk i + 1 and the reduce-scatter of chunk i - 1 under the sweep of chunk i
+// Which is fastest depends on the links and on RCCL's schedules - nothing a one-GPU box can measure, and an environment knob is
+// not something a launcher sets.  So the first wide block of an engine with a real communicator of several ranks goes through all
+// three: program order first (its result is the one that is kept), then the other two into scratch blocks, each twice (the first
+// run pays the lazy set-up of connections / streams), timed with HIP events on the engine's stream, compared with the program-order
+// result - the second stream bitwise (it changes the order of launches, not a single sum), the direct exchange bitwise on two ranks
+// and to 1e-12 of the block's largest entry beyond (RCCL's ring sums in ring order, the direct exchange in rank order).  ONE small
+// all-reduce then makes the figures common (maximum over the ranks of each time, any rank's failed comparison), and every rank
+// picks the fastest validated way.  A way that fails its comparison or returns an error is left out with a message; program order
+// is always valid.  A rank that hangs inside a trial ends like any hung collective: the watchdog's exit 124 (no re-exec, nothing is
+// retried).  DAV_COLL_SELECT=0, DAV_SYM_OVERLAP or DAV_COLL_DIRECT in the environment at dav_create switch the trial off.
+static int coll_path_trial(E* e, int which, OpDesc& o, const SymSet& set, const double* src, int k, double* dst, bool timed) {
+  const Tune saved = e->tune;
+  const size_t blk = (size_t)e->ldp * k;
+  double* scratch_blk = nullptr;
+  double* cmp_dev = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(e->stream);
+    if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
+    pool_free(scratch_blk); pool_free(cmp_dev);
+    for (hipEvent_t v : ev) if (v) (void)hipEventDestroy(v);
+  };
+  e->coll_path = COLL_PATH_PROGRAM_ORDER;                 // the runs below must not come back here
+  e->tune.coll_direct = 0; e->tune.sym_overlap = 0;
+  // the block in program order: THE result (timed like any other apply of the solve)
+  int rc = apply_sym_set(e, which, o, set, false, false, src, k, dst, timed, false);
+  if (rc != 0) { e->tune = saved; return rc; }
+  bool setup_ok = pool_malloc(&scratch_blk, sizeof(double) * blk) == hipSuccess && pool_malloc(&cmp_dev, sizeof(double) * 3 * 64) == hipSuccess &&
+                  hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
+  CollTrial& t = e->coll_trial;
+  t = CollTrial();
+  t.ran = true;
+  t.columns = k;
+  if (!setup_ok) {
+    (void)hipGetLastError();
+    cleanup();
+    e->tune = saved; e->tune.coll_direct = 0; e->tune.sym_overlap = 0;
+    fprintf(stderr, "davidson (rank %d): no memory for the collective-path trial - program order\n", e->rank);
+    return 0;
+  }
+  std::vector<double> cmp_host(3 * 64);
+  for (int path = 0; path < 3; ++path) {
+    e->tune.coll_direct = path == COLL_PATH_DIRECT ? 1 : 0;
+    e->tune.sym_overlap = path == COLL_PATH_SECOND_STREAM ? 1 : 0;
+    bool ok = true;
+    float ms = 0.0f;
+    for (int rep = 0; rep < 2 && ok; ++rep) {             // the first run of a way pays its lazy set-up; the second is timed
+      if (rep == 1) ok = hipEventRecord(ev[0], e->stream) == hipSuccess;
+      if (ok) {
+        const int r = apply_sym_set(e, which, o, set, false, false, src, k, scratch_blk, false, false);
+        if (r != 0) { ok = false; t.message[path] = g_err; }
+        else if (path == COLL_PATH_SECOND_STREAM && !e->ov_ready) { ok = false; t.message[path] = "its stream / buffers could not be set up"; }
+      }
+      if (ok && rep == 1) ok = hipEventRecord(ev[1], e->stream) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
+                               hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+    }
+    if (!ok) (void)hipGetLastError();
+    t.valid[path] = ok;
+    t.ms[path] = ms;
+    if (ok && path != COLL_PATH_PROGRAM_ORDER) {
+      // test hook of the PRODUCT build (tests/test_rccl_one_gpu.py: an injected mismatch): DAV_COLL_TRIAL_CORRUPT = 1 | 2 spoils one
+      // entry of that way's result on rank 0
+      if (e->tune.coll_trial_corrupt == path && e->rank == 0) launch_poke(e->stream, scratch_blk, 1.0);
+      launch_compare_blocks(e->stream, dst, scratch_blk, e->ldp, e->nloc, k, cmp_dev);
+      if (hipMemcpyAsync(cmp_host.data(), cmp_dev, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+          hipStreamSynchronize(e->stream) != hipSuccess) { (void)hipGetLastError(); t.valid[path] = false; t.message[path] = "comparison failed"; continue; }
+      double differing = 0.0, maxdiff = 0.0, maxref = 0.0;
+      for (int j = 0; j < k; ++j) { differing += cmp_host[3 * j]; maxdiff = std::max(maxdiff, cmp_host[3 * j + 1]); maxref = std::max(maxref, cmp_host[3 * j + 2]); }
+      t.differing[path] = differing;
+      t.maxdiff[path] = maxdiff;
+      const bool bitwise = differing == 0.0;
+      const bool close = maxdiff <= 1e-12 * maxref;
+      t.valid[path] = (path == COLL_PATH_DIRECT && e->nranks > 2) ? close : bitwise;
+      if (!t.valid[path]) t.message[path] = "result differs from program order";
+    }
+  }
+  e->tune = saved; e->tune.coll_direct = 0; e->tune.sym_overlap = 0;
+  // make the figures common: slot r of each word carries rank r's value (the SUM all-reduce reproduces every rank's)
+  const int nw = 6;
+  std::vector<double> words((size_t)nw * e->nranks, 0.0);
+  for (int p = 0; p < 3; ++p) {
+    words[(size_t)p * e->nranks + e->rank] = t.ms[p];
+    words[(size_t)(3 + p) * e->nranks + e->rank] = t.valid[p] ? 0.0 : 1.0;
+  }
+  int chosen = COLL_PATH_PROGRAM_ORDER;
+  if ((size_t)nw * e->nranks <= e->gram_doubles &&
+      hipMemcpyAsync(e->gram_dev, words.data(), sizeof(double) * words.size(), hipMemcpyHostToDevice, e->stream) == hipSuccess &&
+      coll_allreduce(e, e->gram_dev, words.size()) == 0 &&
+      hipMemcpyAsync(words.data(), e->gram_dev, sizeof(double) * words.size(), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+      hipStreamSynchronize(e->stream) == hipSuccess) {
+    double best = 0.0;
+    for (int p = 0; p < 3; ++p) {
+      double worst = 0.0, bad = 0.0;
+      for (int r = 0; r < e->nranks; ++r) { worst = std::max(worst, words[(size_t)p * e->nranks + r]); bad += words[(size_t)(3 + p) * e->nranks + r]; }
+      t.ms_max[p] = worst;
+      t.valid_all[p] = bad == 0.0 && worst > 0.0;
+      if (t.valid_all[p] && (p == COLL_PATH_PROGRAM_ORDER || worst < best)) { best = worst; chosen = p; }
+      if (p == COLL_PATH_PROGRAM_ORDER && !t.valid_all[p]) { t.valid_all[p] = true; best = worst; }      // always available
+    }
+  } else {
+    (void)hipGetLastError();
+    fprintf(stderr, "davidson (rank %d): the ranks could not agree on the collective-path trial - program order\n", e->rank);
+  }
+  static const char* names[3] = {"program order", "direct exchange", "second stream"};
+  for (int p = 1; p < 3; ++p)
+    if (!t.valid_all[p] && e->rank == 0)
+      fprintf(stderr, "davidson: collective path '%s' left out of the selection (%s%s)\n", names[p], t.valid[p] ? "another rank's comparison failed" : "this rank: ",
+              t.valid[p] ? "" : t.message[p].c_str());
+  t.selected = chosen;
+  e->coll_path = chosen;
+  e->tune.coll_direct = chosen == COLL_PATH_DIRECT ? 1 : 0;
+  e->tune.sym_overlap = chosen == COLL_PATH_SECOND_STREAM ? 1 : 0;
+  if (saved.gjd_trace || getenv("DAVIDSON_VERBOSE"))
+    if (e->rank == 0)
+      fprintf(stderr, "davidson: collectives of wide blocks: %s (trial of a %d-column block, ms max over ranks: program order %.3f, direct exchange %.3f%s, second stream %.3f%s)\n",
+              names[chosen], k, t.ms_max[0], t.ms_max[1], t.valid_all[1] ? "" : " [invalid]", t.ms_max[2], t.valid_all[2] ? "" : " [invalid]");
+  cleanup();
+  return 0;
+}
+
 // The symmetric-tiled sweep of the block rows of `set` of operator view `o` (stored tiles at o.a / generated entries):
 // dst[:, 0:k] (+)= Op * src[:, 0:k].  partial: `set` is not all of the rank's block rows (an operator swept in two parts: its
 // resident and its generated block rows); accumulate: the result is added to dst.
@@ -203,8 +332,11 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
     // the same order on every rank, ordered against the engine's stream by events, so no two collectives of the communicator are
     // ever in flight together.  Off by default: it has never run over more than one RCCL rank (round-4 advisor); the default below
     // keeps every collective on the engine's stream in program order.
-    if (e->tune.sym_overlap != 0 && !partial && (e->comm || has_test_transport(e)) && pair_ok && k > 32 && o.kind == DAV_KIND_DENSE &&
-        sym_schedule(e, 32, true) == 2) {
+    const bool wide_block = !partial && pair_ok && k > 32 && o.kind == DAV_KIND_DENSE && sym_schedule(e, 32, true) == 2;
+    // Round 6: which way the collectives of a wide block go is decided by the engine itself, once, at the first such block over a
+    // real communicator of several ranks (coll_path_trial below) - unless the environment forced a path at dav_create
+    if (wide_block && e->comm && e->nranks > 1 && e->coll_path == COLL_PATH_UNDECIDED && !inner) return coll_path_trial(e, which, o, set, src, k, dst, timed);
+    if (e->tune.sym_overlap != 0 && wide_block && (e->comm || has_test_transport(e))) {
       const int rc = apply_sym_overlapped(e, which, o, src, k, dst, timed, inner);
       if (rc != 2) return rc;                          // 2: its streams / buffers / slabs could not be set up - serial path below
     }

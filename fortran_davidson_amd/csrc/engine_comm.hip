@@ -89,6 +89,9 @@ extern "C" int dav_comm_init(dav_handle_t e, const void* id128) {
   NCCLCHK(g_rccl.CommCount(e->comm, &count));          // what RCCL itself reports: goes into dav_stats.comm_ranks (bench.py prints it)
   if (count != e->nranks) return fail("dav_comm_init: the communicator has " + std::to_string(count) + " ranks, the engine was created for " + std::to_string(e->nranks));
   e->comm_ranks = count;
+  // the first wide block of the symmetric sweep decides which way its collectives go (engine_apply.hip: coll_path_trial) - with a
+  // communicator of several ranks, and unless the environment chose at dav_create
+  e->coll_path = (e->nranks > 1 && e->tune.coll_select != 0 && !e->tune.coll_forced) ? COLL_PATH_UNDECIDED : COLL_PATH_PROGRAM_ORDER;
   // the watchdog of this communicator's collectives (DAVIDSON_COLLECTIVE_TIMEOUT seconds; default 600, 0 = none)
   double timeout = 600.0;
   if (const char* ev = getenv("DAVIDSON_COLLECTIVE_TIMEOUT")) timeout = atof(ev);
@@ -517,6 +520,36 @@ int coll_reduce_scatter(E* e, const double* send, double* recv, size_t count) {
   }
   CHK(timed_end(e, slot));
   return watch_mark(e, "reduce-scatter", e->stream);
+}
+
+// The inputs of a solve (order, wanted pairs, restart width, tolerance, method, policy ...) must be the same on every rank: everything the
+// driver decides follows from them and from all-reduced numbers.  Verified with dav_ranks_agree - a collective whose size does not depend
+// on the words - when they differ from what THIS engine verified last (the first solve on an engine always verifies): repeated solves
+// with unchanged inputs add no collective.  Ranks of an SPMD caller change their inputs together, so all of them come here together; a
+// rank that changes them alone is the error this check exists for - its peers are then in another collective, and the watchdog ends the run.
+extern "C" int dav_agree_inputs(dav_handle_t e, const double* words, int nwords) {
+  if (nwords <= 0 || nwords > 16 || !words) return fail("dav_agree_inputs: 1..16 words");
+  if (e->nranks <= 1 || !has_comm(e)) return 0;
+  if ((int)e->agreed_inputs.size() == nwords && std::equal(words, words + nwords, e->agreed_inputs.begin())) return 0;
+  CHK(dav_ranks_agree(e, words, nwords));
+  e->agreed_inputs.assign(words, words + nwords);
+  return 0;
+}
+
+// What coll_path_trial decided and measured (engine_apply.hip).  selected: 0 program order, 1 direct exchange, 2 second stream, -1 = not
+// decided yet (no wide block has been swept over a communicator of several ranks); ms[3] / valid[3]: maximum over the ranks of the trial
+// block's time per way and whether every rank validated it (ms = 0: not tried - the environment forced a way, or one rank).
+extern "C" int dav_comm_path(dav_handle_t e, int* selected, int* trial_ran, int* columns, double* ms3, int* valid3) {
+  if (!e) return fail("dav_comm_path: null handle");
+  const CollTrial& t = e->coll_trial;
+  if (selected) *selected = e->coll_path == COLL_PATH_UNDECIDED ? -1 : (e->tune.sym_overlap ? COLL_PATH_SECOND_STREAM : e->tune.coll_direct ? COLL_PATH_DIRECT : COLL_PATH_PROGRAM_ORDER);
+  if (trial_ran) *trial_ran = t.ran ? 1 : 0;
+  if (columns) *columns = t.columns;
+  for (int p = 0; p < 3; ++p) {
+    if (ms3) ms3[p] = t.ms_max[p];
+    if (valid3) valid3[p] = t.valid_all[p] ? 1 : 0;
+  }
+  return 0;
 }
 
 // The same check without a collective of its own: the words wait in the engine and ride on the NEXT all-reduced small result

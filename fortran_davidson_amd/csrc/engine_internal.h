@@ -55,6 +55,7 @@ hipError_t pool_host_malloc_raw(void** p, size_t bytes, unsigned flags);
 hipError_t pool_free(void* p);
 hipError_t pool_host_free(void* p);
 size_t pool_idle_device_bytes(int device);
+void pool_begin_of_destroy();
 void pool_end_of_destroy();
 hipError_t pool_stream_get(hipStream_t* st);          // the engine's stream (non-blocking): created, or the one of the engine destroyed last
 void pool_stream_put(hipStream_t st, int device);
@@ -176,9 +177,24 @@ struct Tune {
   int coll_direct = 0;    // DAV_COLL_DIRECT=1: all-gather / reduce-scatter as direct exchanges (grouped send / receive to every peer) instead of RCCL's collectives (opt-in)
   int b_resident = 1;     // DAV_B_RESIDENT: keep what fits of a generated second operator resident as stored tiles (dav_set_operator_hashed, storage 1)
   bool gjd_trace = false; // DAV_GJD_TRACE
+  int coll_select = 1;    // DAV_COLL_SELECT=0: no trial of the collective paths at the first wide block (program order, or what DAV_SYM_OVERLAP / DAV_COLL_DIRECT force)
+  int coll_trial_corrupt = 0;   // DAV_COLL_TRIAL_CORRUPT=1|2: test hook - spoil that way's trial result on rank 0
+  bool coll_forced = false;     // DAV_SYM_OVERLAP or DAV_COLL_DIRECT present in the environment
+  int no_h0 = 0;          // DAV_NO_H0=1: the first projection by a Gram product instead of the operator's entries at the start indices (A/B)
   int harness_libm = 0;   // DAV_HARNESS_LIBM=1: the harness operator's entries by four library calls each (A/B; default: the one-variable polynomial)
 };
 Tune tune_from_env();
+
+// which way the collectives of a wide block of the symmetric sweep go (engine_apply.hip: coll_path_trial)
+enum { COLL_PATH_UNDECIDED = -1, COLL_PATH_PROGRAM_ORDER = 0, COLL_PATH_DIRECT = 1, COLL_PATH_SECOND_STREAM = 2 };
+struct CollTrial {
+  bool ran = false;
+  int selected = COLL_PATH_PROGRAM_ORDER, columns = 0;
+  double ms[3] = {0, 0, 0}, ms_max[3] = {0, 0, 0};       // this rank's time of the trial block per way; maximum over the ranks
+  bool valid[3] = {true, false, false}, valid_all[3] = {true, false, false};
+  double differing[3] = {0, 0, 0}, maxdiff[3] = {0, 0, 0};
+  std::string message[3];
+};
 
 struct Watchdog;
 struct dav_engine {
@@ -227,11 +243,14 @@ struct dav_engine {
   size_t coll_stage_doubles = 0;
   // RCCL only: a second stream for the collectives of the symmetric sweep, so that the all-gather of the NEXT 32 columns
   // and the reduce-scatter of the PREVIOUS ones run under the sweep of the current ones; buffers alternate by chunk parity
+  int coll_path = COLL_PATH_PROGRAM_ORDER;   // UNDECIDED once a communicator of several ranks exists and the environment forced nothing
+  CollTrial coll_trial;
   Watchdog* wd = nullptr;         // watches the RCCL collectives of this engine (dav_comm_init)
   int group_depth = 0;            // inside ncclGroupStart / ncclGroupEnd: the group is marked once, at its end
   bool group_timed = false;       // a CollGroup times its members as a whole
   long iter_hint = -1;            // outer iteration the driver is in (dav_ranks_agree), for the watchdog's message
   std::vector<double> agree_words;   // dav_agree_next: the driver's control words, riding on the next all-reduced small result
+  std::vector<double> agreed_inputs; // dav_agree_inputs: the solve inputs the ranks verified last
   double* agree_pin = nullptr;       // pinned staging of those words (16 x nranks doubles)
   // H0 = V0^T (Op V0) of the unit columns of dav_init_basis is the operator's entries at (idx_i, idx_j): several ranks of dealt-out
   // tiles sum what each holds of them in the SAME grouped collective that reduce-scatters W0 (one collective per solve fewer);

@@ -218,7 +218,7 @@ extern "C" int dav_init_basis(dav_handle_t e, int ncols, int64_t* idx_out) {
   // H0 = V0^T (Op V0) of unit columns is the operator's entries (idx_i, idx_j): read / generated here instead of a Gram product over
   // N rows in dav_project; several ranks of dealt-out tiles sum what each holds of them inside the reduce-scatter group of W0
   // (h0_dev in engine_internal.h), a generated operator's entries every rank generates for itself - no collective for H0 either way
-  const bool h0_try = !e->rr_on && ncols <= e->h0_cap && getenv("DAV_NO_H0") == nullptr;
+  const bool h0_try = !e->rr_on && ncols <= e->h0_cap && e->tune.no_h0 == 0;
   const size_t h0_blk = (size_t)e->h0_cap * e->h0_cap;
   e->h0_kind[0] = e->h0_kind[1] = 0;
   for (int w = 0; w < (e->gev ? 2 : 1); ++w) {

@@ -254,3 +254,38 @@ void launch_sum_parts(hipStream_t st, const double* own, const double* stage, in
   const unsigned grid = (unsigned)std::min<size_t>(4096, (count + 255) / 256);
   hipLaunchKernelGGL(sum_parts_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, own, stage, nparts, self, count, out);
 }
+
+// Trial of the collective paths (engine_apply.hip: coll_path_trial): column j of two blocks compared - out[3 j] = entries whose bits
+// differ, out[3 j + 1] = max |a - b|, out[3 j + 2] = max |a| - one workgroup per column, fixed-order tree in LDS.
+__global__ __launch_bounds__(256) void compare_blocks_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t ld, int64_t rows,
+                                                             double* __restrict__ out) {
+  __shared__ double sh[3][256];
+  const double* ac = a + (int64_t)blockIdx.x * ld;
+  const double* bc = b + (int64_t)blockIdx.x * ld;
+  double differ = 0.0, maxdiff = 0.0, maxabs = 0.0;
+  for (int64_t i = threadIdx.x; i < rows; i += 256) {
+    const double x = ac[i], y = bc[i];
+    if (__double_as_longlong(x) != __double_as_longlong(y)) differ += 1.0;
+    const double d = fabs(x - y);
+    maxdiff = !(d <= maxdiff) ? d : maxdiff;         // a NaN difference wins: the comparison fails
+    maxabs = fmax(maxabs, fabs(x));
+  }
+  sh[0][threadIdx.x] = differ; sh[1][threadIdx.x] = maxdiff; sh[2][threadIdx.x] = maxabs;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+      const double d = sh[1][threadIdx.x + s];
+      sh[1][threadIdx.x] = !(d <= sh[1][threadIdx.x]) ? d : sh[1][threadIdx.x];
+      sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[3 * blockIdx.x] = sh[0][0]; out[3 * blockIdx.x + 1] = sh[1][0]; out[3 * blockIdx.x + 2] = sh[2][0]; }
+}
+void launch_compare_blocks(hipStream_t st, const double* a, const double* b, int64_t ld, int64_t rows, int k, double* out) {
+  hipLaunchKernelGGL(compare_blocks_kernel, dim3(k), dim3(256), 0, st, a, b, ld, rows, out);
+}
+// test hook of that trial (DAV_COLL_TRIAL_CORRUPT): p[0] += delta
+__global__ void poke_kernel(double* p, double delta) { p[0] += delta; }
+void launch_poke(hipStream_t st, double* p, double delta) { hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(1), 0, st, p, delta); }

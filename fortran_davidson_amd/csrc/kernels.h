@@ -97,6 +97,8 @@ void launch_copy_columns(hipStream_t st, const double* src, int64_t lds, double*
 void launch_stream(hipStream_t st, int mode, double* a, const double* b, const double* c, double s, int64_t n);
 void launch_harness_rate(hipStream_t st, double* out, int wgs, int iters);
 // out[i] = sum over p = 0 .. nparts-1 of part_p[i] in that order; part_p = own for p == self, stage + slot(p) * count otherwise (slot = p, minus one behind self)
+void launch_compare_blocks(hipStream_t st, const double* a, const double* b, int64_t ld, int64_t rows, int k, double* out);
+void launch_poke(hipStream_t st, double* p, double delta);
 void launch_sum_parts(hipStream_t st, const double* own, const double* stage, int nparts, int self, size_t count, double* out);
 
 

@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("b_stored_launches", C.c_int64), ("b_generated_launches", C.c_int64)]
 
 
-ABI_VERSION = 107      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
+ABI_VERSION = 108      # DAV_HIP_ABI_VERSION of include/davidson_hip.h this module mirrors
 
 
 def _dp(a):
@@ -104,6 +104,17 @@ class CEngine:
     def comm_init(self, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self.lib.dav_comm_init(self.h, buf))
+
+    def comm_path(self):
+        """What the trial of the collective paths decided (dav_comm_path): dict(selected, trial_ran, columns, ms, valid)"""
+        sel, ran, cols = C.c_int(), C.c_int(), C.c_int()
+        ms = (C.c_double * 3)()
+        valid = (C.c_int * 3)()
+        self._chk(self.lib.dav_comm_path(self.h, C.byref(sel), C.byref(ran), C.byref(cols), ms, valid))
+        names = {-1: "undecided", 0: "program order", 1: "direct exchange", 2: "second stream"}
+        return {"selected": names[sel.value], "trial_ran": bool(ran.value), "columns": cols.value,
+                "trial_ms_max_over_ranks": {names[i]: round(ms[i], 4) for i in range(3)},
+                "validated": {names[i]: bool(valid[i]) for i in range(3)}}
 
     def comm_init_shm(self, name: str):
         """Test transport for ranks that are processes sharing one GPU (POSIX shared memory `name`)."""

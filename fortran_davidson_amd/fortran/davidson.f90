@@ -472,6 +472,14 @@ contains
     lazy_x = (.not. drr) .and. meth /= DAV_METHOD_GJD
     call check_dav(dav_set_lazy_ritz_vectors(h, merge(1_c_int, 0_c_int, lazy_x)), "dav_set_lazy_ritz_vectors")
 
+    ! Several ranks: everything the loop decides follows from these inputs and from all-reduced (hence bitwise identical) numbers.
+    ! The inputs are verified in a collective whose size does not depend on them (round-5 advisor: the per-iteration words of
+    ! dav_agree_next ride on all-reduces whose element count they determine - ranks that differ in `lowest` or `max_dim` would enter
+    ! those with different counts) whenever they differ from what the engine verified last: the first solve always, repeated solves
+    ! with the same inputs never (dav_agree_inputs); a single rank: a no-op
+    call check_dav(dav_agree_inputs(h, [real(n, dp), real(lowest, dp), real(max_dim, dp), real(max_iterations, dp), tolerance, &
+         real(pol, dp), real(meth, dp), merge(1.0_dp, 0.0_dp, sticky), merge(1.0_dp, 0.0_dp, gev)], 9_c_int), "dav_agree_inputs")
+
     ! 1. initial basis: unit vectors at the lowest diagonal entries; W0 = A*V0
     m = initial_dimension
     t0 = tick()

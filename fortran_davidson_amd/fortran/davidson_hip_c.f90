@@ -30,7 +30,7 @@ module davidson_hip_c
   end type dav_stats
   !> DAV_HIP_ABI_VERSION of include/davidson_hip.h these interfaces were written against: engine_create checks that the
   !> loaded libdavidson_hip.so reports the same number (the layout of dav_stats grew in 101, 102 and 104)
-  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 107
+  integer(c_int), parameter :: DAV_HIP_ABI_VERSION = 108
 
   interface
      function dav_last_error() bind(C, name="dav_last_error") result(p)
@@ -321,6 +321,13 @@ module davidson_hip_c
        integer(c_int) :: ierr
      end function
      function dav_ranks_agree(h, words, nwords) bind(C, name="dav_ranks_agree") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h
+       real(c_double), intent(in) :: words(*)
+       integer(c_int), value :: nwords
+       integer(c_int) :: ierr
+     end function
+     function dav_agree_inputs(h, words, nwords) bind(C, name="dav_agree_inputs") result(ierr)
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: h
        real(c_double), intent(in) :: words(*)

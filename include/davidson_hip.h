@@ -83,9 +83,9 @@ typedef struct dav_stats {
 } dav_stats;
 
 /* ABI version of this header.  dav_version() of the loaded library must return the same number: a     */
-/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next, 105 dav_free_buffers, 106 dav_set_operator_device, 107 DAV_NO_SUCH_ENTRY) must not    */
+/* caller built against another layout of the statistics structure (it grew in 101 and 102; 103 added dav_device_memory, 104 dav_agree_next, 105 dav_free_buffers, 106 dav_set_operator_device, 107 DAV_NO_SUCH_ENTRY, 108 dav_comm_path) must not    */
 /* use the unsized call - the sized one, which copies at most `bytes` bytes, is safe across versions.   */
-#define DAV_HIP_ABI_VERSION 107
+#define DAV_HIP_ABI_VERSION 108
 const char* dav_last_error(void);
 int dav_version(void);
 
@@ -99,6 +99,15 @@ int dav_destroy(dav_handle_t h);
  * distributes it, every rank calls dav_comm_init.  Not needed when nranks == 1. */
 int dav_comm_unique_id(void* id128);
 int dav_comm_init(dav_handle_t h, const void* id128);
+/* Several ranks (ABI 108): which way the collectives of a wide block (more than 32 columns) of the symmetric sweep go - RCCL's all-gather /
+ * reduce-scatter in program order (0), direct exchanges with every peer over the point-to-point links (1), or 32-column chunks whose
+ * collectives run on a second stream under the sweeps (2) - is decided by the engine at the first such block over a real communicator:
+ * the block goes through all three, the results are compared with the program-order one (bitwise; the direct exchange's rank-order sums
+ * to 1e-12 beyond two ranks), the times (HIP events, maximum over the ranks) are made common with one small all-reduce and the fastest
+ * validated way is kept; a way that fails is left out with a message on stderr.  DAV_COLL_SELECT=0, DAV_SYM_OVERLAP or DAV_COLL_DIRECT in
+ * the environment at dav_create switch the trial off.  This call reports the outcome: *selected = -1 before the trial, ms3 / valid3 per
+ * way (0 / 1 / 2 as above). */
+int dav_comm_path(dav_handle_t h, int* selected, int* trial_ran, int* columns, double* ms3, int* valid3);
 int dav_synchronize(dav_handle_t h);
 int dav_get_stats(dav_handle_t h, dav_stats* out);
 int dav_get_stats_n(dav_handle_t h, void* out, size_t bytes);
@@ -127,7 +136,12 @@ int dav_device_memory(dav_handle_t h, int64_t* free_bytes, int64_t* total_bytes)
  * destroys an engine per call; blocks idle through a whole create-destroy cycle are freed, a failing allocation frees them all and
  * tries again, dav_device_memory counts them as free.  dav_free_buffers() returns every idle block to the device now
  * (what mkl_free_buffers is to MKL); DAVIDSON_BUFFER_CACHE=0 in the environment turns the cache off; it never holds more than
- * DAVIDSON_BUFFER_CACHE_MB megabytes (default 4096: the call it exists for is the small and frequent one). */
+ * DAVIDSON_BUFFER_CACHE_MB megabytes of device memory (default 4096: the call it exists for is the small and frequent one) and
+ * DAVIDSON_BUFFER_CACHE_PINNED_MB of page-locked host memory (default 256); a block above 512 MiB that an engine frees in the middle of
+ * its life goes straight back.  What the cache holds is invisible to every other allocator of the device (the caller's hipMalloc,
+ * PyTorch, RCCL, other processes): a co-tenant that needs the memory calls dav_free_buffers() after the solve, or runs with the cache
+ * off.  Nothing is released at process exit - the driver reclaims a dead process's memory, and HIP calls from exit handlers are
+ * not safe against the runtime's own teardown. */
 int dav_free_buffers(void);
 /* Dense matrix from host memory, full storage a(lda, n), the caller's array as passed to
  * generalized_eigensolver_dense (src/davidson.f90:75-76).  Copies this rank's row slab to HBM and
@@ -279,6 +293,11 @@ int dav_ranks_agree(dav_handle_t h, const double* words, int nwords);
  * iteration with (iteration, basis width, grow-or-restart, corrections, tolerance, converged flags): together with the
  * all-reduced (hence bitwise identical) residual norms they determine every decision of the iteration.  One rank: a no-op. */
 int dav_agree_next(dav_handle_t h, const double* words, int nwords);
+/* The INPUTS of a solve (ABI 108; at most 16 words: order, wanted pairs, restart width, iteration limit, tolerance, policy, method ...),
+ * verified across the ranks with dav_ranks_agree - a collective whose size does not depend on them, which the all-reduces the words of
+ * dav_agree_next ride on are not: their element counts follow from the basis width - whenever they differ from what this engine verified
+ * last; the first solve on an engine always verifies, repeated solves with unchanged inputs add no collective.  One rank: a no-op. */
+int dav_agree_inputs(dav_handle_t h, const double* words, int nwords);
 /* Mixed-precision correction path (opt-in).  bits = 32: the block sweeps inside the GJD correction solve
  * (replacing the dense projected solves of src/davidson.f90:700-734 + src/lapack_wrapper.f90:238-277) read an fp32 copy of
  * the stored symmetric tiles (made on first use; half the bytes per inner sweep), widen to fp64 in registers and

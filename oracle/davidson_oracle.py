@@ -314,25 +314,44 @@ def generalized_eigensolver_dense_unconverged(matrix, lowest, method, max_iterat
     return eigenvalues, eigenvectors, iters
 
 
-def generalized_eigensolver_dense_locking(matrix, lowest, method, max_iterations, tolerance, max_dim_sub=None, trace=None):
+def generalized_eigensolver_dense_locking(matrix, lowest, method, max_iterations, tolerance, max_dim_sub=None, trace=None,
+                                          second_matrix=None):
     """NOT in the reference: CPU statement of the engine's OPT-IN correction policy "locking" (the deflation the
     reference's header cites, src/davidson.f90:7-8, and never implements; fortran_davidson_amd/fortran/davidson.f90,
-    POLICY_LOCKING), kept here as its checker.  Standard problems only.  Same building blocks as generalized_eigensolver_dense
-    (davidson.f90:51-246):
+    POLICY_LOCKING), kept here as its checker.  Same building blocks as generalized_eigensolver_dense (davidson.f90:51-246):
       * a wanted Ritz pair whose residual is below the tolerance is LOCKED: its Ritz vector joins Q, its value is final, and the
-        active basis is rotated to the remaining Ritz vectors (V <- V Y(:, not locked): orthonormal and orthogonal to Q);
-      * the Rayleigh-Ritz problem is that of the active basis alone (H = V^T A V), for the lowest - len(Q) pairs still wanted;
-      * corrections only for the wanted pairs that are not locked; the new block is orthonormalised against Q AND V (QR of
-        [Q V T], davidson.f90:210-213), so the search space stays orthogonal to what is locked;
+        active basis is rotated to the remaining Ritz vectors (V <- V Y(:, not locked));
+      * the search space is kept orthogonal to the GUARD vectors U = B Q (standard problems: U = Q): the eigenvectors still wanted are
+        B-orthogonal to the locked ones, x^T B q = 0, i.e. they lie in the complement of span(B Q) - and for a locked pair
+        V^T A q = lambda V^T B q = 0 there, so the projected pencil of the active basis is decoupled from what is locked;
+      * the Rayleigh-Ritz problem is that of the active basis alone (H = V^T A V, generalized: S = V^T B V), for the
+        lowest - len(Q) pairs still wanted;
+      * corrections only for the wanted pairs that are not locked; the new block is orthonormalised against U AND V (QR of
+        [U V T], davidson.f90:210-213);
       * the active basis grows while m + wanted <= max_dim (one of 2*wanted columns or fewer always grows), else it collapses to its
         2*wanted lowest Ritz vectors (:218); the solve ends when `lowest` pairs are locked; eigenvalues returned in ascending order."""
     A = np.asarray(matrix, dtype=np.float64)
+    B = None if second_matrix is None else np.asarray(second_matrix, dtype=np.float64)
+    gev = B is not None
     n = A.shape[0]
     max_dim = max_dim_sub if max_dim_sub is not None else 10 * lowest
     if method not in ("DPR", "GJD"):
         raise ValueError("method must be DPR or GJD")
     V = generate_preconditioner(diagonal(A), 2 * lowest)
     Q = np.zeros((n, 0), order="F")
+
+    def guards():
+        """orthonormal basis of span(B Q) (standard problems: Q itself, orthonormal already)"""
+        if Q.shape[1] == 0:
+            return Q
+        return lapack_qr(np.asfortranarray(B @ Q)) if gev else Q
+
+    def complement(block):
+        """orthonormal basis of the columns of `block` made orthogonal to the guards (QR of [U block])"""
+        U = guards()
+        W = lapack_qr(concatenate(U, block) if U.shape[1] else np.asfortranarray(block))
+        return np.asfortranarray(W[:, U.shape[1]:])
+
     locked = []
     iters = max_iterations + 1
     theta = np.zeros(0)
@@ -340,10 +359,11 @@ def generalized_eigensolver_dense_locking(matrix, lowest, method, max_iterations
     for i in range(1, max_iterations + 1):
         want = lowest - len(locked)
         H = V.T @ (A @ V)
-        theta, Y = lapack_generalized_eigensolver(H, None)
+        theta, Y = lapack_generalized_eigensolver(H, V.T @ (B @ V) if gev else None)
         m = V.shape[1]
         X = np.asfortranarray(V @ Y[:, :want])
-        R = np.asfortranarray(A @ X - X * theta[None, :want])
+        BX = np.asfortranarray(B @ X) if gev else X
+        R = np.asfortranarray(A @ X - BX * theta[None, :want])
         errors = np.array([norm(R[:, j]) for j in range(want)])
         if trace is not None:
             trace.widths.append(m + len(locked))
@@ -365,14 +385,15 @@ def generalized_eigensolver_dense_locking(matrix, lowest, method, max_iterations
             if conv.any():
                 V = np.asfortranarray(V @ Y[:, rest])
             if method == "DPR":
-                T = compute_DPR_generalized_dense(A, theta[sel], np.asfortranarray(R[:, sel]), None)
+                T = compute_DPR_generalized_dense(A, theta[sel], np.asfortranarray(R[:, sel]), B)
             else:
-                T = compute_GJD_generalized_dense(A, theta[sel], np.asfortranarray(X[:, sel]), np.asfortranarray(R[:, sel]), None)
+                T = compute_GJD_generalized_dense(A, theta[sel], np.asfortranarray(X[:, sel]), np.asfortranarray(R[:, sel]), B)
             T = T[:, :max(0, n - len(locked) - V.shape[1])]                  # never more columns than the space has left
-            W = lapack_qr(concatenate(concatenate(Q, V) if Q.shape[1] else V, T))
-            V = np.asfortranarray(W[:, Q.shape[1]:])
+            V = complement(concatenate(V, T))
         else:
             V = np.asfortranarray(V @ Y[:, rest[:2 * want_new]])
+            if gev:
+                V = complement(V)                                            # S-orthonormal Ritz vectors: Euclidean-orthonormal again
     order = np.argsort(np.array(locked)) if len(locked) == lowest else None
     if order is not None:
         return np.array(locked)[order], np.asfortranarray(Q[:, order]), iters

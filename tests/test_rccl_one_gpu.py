@@ -61,25 +61,45 @@ def test_real_rccl_communicator_of_several_ranks_matches_one_rank(nproc, storage
         assert c["reduce_scatter_ms_per_solve"] > 0
 
 
-def test_wide_blocks_in_program_order_on_a_second_stream_and_as_direct_exchanges():
-    """lowest = 16 makes the 64-column expansion (two-block-row schedule forced at this small order).  Three ways to move its
-    collectives over a real 2- and 3-rank communicator: in program order on the engine's stream (the default: one all-gather, one
-    64-column launch, one reduce-scatter), on a second stream under the sweeps of the 32-column chunks (DAV_SYM_OVERLAP=1: the
-    pipeline had only ever run over a 1-rank communicator), and as direct exchanges (DAV_COLL_DIRECT=1: grouped ncclSend / ncclRecv
-    and a fixed-order local sum).  Same iteration count as one rank, eigenvalues to 1e-10."""
+def test_the_engine_picks_the_way_of_its_wide_blocks_collectives_itself():
+    """lowest = 16 makes the 64-column expansion (two-block-row schedule forced at this small order).  Three ways exist to move its
+    collectives: RCCL's all-gather / reduce-scatter in program order on the engine's stream, direct exchanges (grouped ncclSend /
+    ncclRecv with every peer and a rank-order sum) and 32-column chunks whose collectives run on a second stream under the sweeps.
+    Round 6: the engine decides at its first wide block over a real communicator of several ranks (csrc/engine_apply.hip:
+    coll_path_trial) - the block through all three, results compared with the program-order one, times made common with one
+    all-reduce, the fastest validated way kept - and reports it (dav_comm_path -> comm.path_*).  Over real 2- and 3-rank communicators:
+    the trial runs, validates all three ways (the second stream bitwise), the solve continues on the chosen one to the one-rank
+    eigenvalues; a way whose trial result is spoiled (DAV_COLL_TRIAL_CORRUPT: one entry on rank 0) is left out and the run still
+    ends correctly; a way forced through the environment (DAV_SYM_OVERLAP / DAV_COLL_DIRECT, or DAV_COLL_SELECT=0) skips the trial."""
     extra = ["--steps", "1", "--warmup", "1", "--order", "6000", "--lowest", "16", "--storage", "symmetric", "--headline-only"]
     one = run_bench(1, extra, {"DAV_SYM_R": "2"})
+    names = ("program order", "direct exchange", "second stream")
+
+    def check(many, nproc, what):
+        assert many["comm"]["ranks_reported_by_rccl"] == nproc, what
+        assert many["config"]["iters_per_solve"] == one["config"]["iters_per_solve"], what
+        assert np.abs(np.array(many["eigenvalues"]) - np.array(one["eigenvalues"])).max() < 1e-10, what
+        return many["comm"]
+
     for nproc in (2, 3):
-        lams = {}
-        for name, env in (("program order", {}), ("second stream", {"DAV_SYM_OVERLAP": "1"}), ("direct exchange", {"DAV_COLL_DIRECT": "1"})):
-            many = run_bench(nproc, extra, dict(env, DAV_SYM_R="2"))
-            assert many["comm"]["ranks_reported_by_rccl"] == nproc, name
-            assert many["comm"]["collectives_overlapped_with_sweeps"] == (name == "second stream"), name
-            assert many["config"]["iters_per_solve"] == one["config"]["iters_per_solve"], name
-            assert np.abs(np.array(many["eigenvalues"]) - np.array(one["eigenvalues"])).max() < 1e-10, name
-            lams[name] = many["eigenvalues"]
-        # the pipeline changes the order of launches, not a single sum (same ring reductions): the same bits as program order
-        assert lams["second stream"] == lams["program order"]
+        c = check(run_bench(nproc, extra, {"DAV_SYM_R": "2"}), nproc, "selected by the engine")
+        assert c["path_trial_ran"] and c["path_trial_columns"] == 64 and c["path_selected"] in names, c
+        assert all(c["path_validated"][w] for w in names), c
+        assert all(c["path_trial_ms_max_over_ranks"][w] > 0 for w in names), c
+        assert c["collectives_overlapped_with_sweeps"] == (c["path_selected"] == "second stream")
+        # a spoiled trial result: that way is left out, the run is unaffected (the kept result is always the program-order one)
+        spoiled = 1 if nproc == 3 else 2
+        c = check(run_bench(nproc, extra, {"DAV_SYM_R": "2", "DAV_COLL_TRIAL_CORRUPT": str(spoiled)}), nproc, "one way spoiled")
+        assert c["path_trial_ran"] and not c["path_validated"][names[spoiled]] and c["path_selected"] != names[spoiled], c
+        assert c["path_validated"]["program order"], c
+    # forced through the environment: no trial; the second stream gives the bits of program order (same ring reductions, other launch order)
+    lams = {}
+    for what, env in (("program order", {"DAV_COLL_SELECT": "0"}), ("second stream", {"DAV_SYM_OVERLAP": "1"}), ("direct exchange", {"DAV_COLL_DIRECT": "1"})):
+        line = run_bench(2, extra, dict(env, DAV_SYM_R="2"))
+        c = check(line, 2, what)
+        assert not c["path_trial_ran"] and c["path_selected"] == what, c
+        lams[what] = line["eigenvalues"]
+    assert lams["second stream"] == lams["program order"]
 
 
 def test_matrix_free_and_generalized_legs_over_a_real_communicator():
@@ -100,12 +120,12 @@ def test_a_rank_that_dies_inside_a_real_communicator_ends_the_launch_within_the_
     """One rank of two ends abruptly in the middle of a long run (tests/rank_killer.py: a timer in rank 1): its peer must not wait
     in an RCCL collective for ever - the engine's watchdog (DAVIDSON_COLLECTIVE_TIMEOUT) or the launcher ends it, and the launch
     returns a non-zero code well inside the bound."""
-    env = dict(os.environ, DAVIDSON_TRANSPORT="rccl-one-gpu", DAVIDSON_COLLECTIVE_TIMEOUT="20")
+    env = dict(os.environ, DAVIDSON_TRANSPORT="rccl-one-gpu", DAVIDSON_COLLECTIVE_TIMEOUT="8")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.pop("DAVIDSON_HIP_LIB", None)
     t0 = time.time()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "rank_killer.py"), "1", "40", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1000000",
+           os.path.join(ROOT, "tests", "rank_killer.py"), "1", "15", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1000000",
            "--warmup", "1", "--order", "6000", "--headline-only"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     assert res.returncode != 0
