@@ -117,17 +117,56 @@ def test_locking_policy_through_restarts_on_one_and_three_ranks(nranks, storage)
         assert (np.diff(lam) > 0).all()
 
 
-def test_locking_policy_refuses_generalized_problems():
-    import subprocess
-    import sys
-    code = ("import fortran_davidson_amd as fd\n"
-            "e = fd.DavidsonEngine(300, 3, gev=True)\n"
-            "e.generate_diagonal_dominant(1, 1e-3, seed=1); e.generate_diagonal_dominant(2, 1e-3, 1.0, seed=2)\n"
-            "e.set_correction_policy('locking'); e.solve('DPR', 50, 1e-8)\n")
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, PYTHONPATH=root))
-    assert res.returncode != 0 and "standard problems" in (res.stdout + res.stderr)
+GEV_LOCKING_CASES = [(300, 3, 1e-2, None, "DPR", "full", 1), (500, 5, 3e-2, 15, "DPR", "symmetric", 1), (200, 2, 1e-2, None, "GJD", "full", 1),
+                     (400, 8, 5e-2, 24, "DPR", "symmetric", 1), (700, 6, 3e-2, 20, "DPR", "full", 3), (700, 6, 3e-2, 20, "DPR", "symmetric", 3)]
+
+
+@pytest.mark.parametrize("n,L,sp,md,method,storage,nranks", GEV_LOCKING_CASES)
+def test_locking_policy_on_generalized_problems(n, L, sp, md, method, storage, nranks):
+    """"locking" for A x = lambda B x (round 6; the deflation of the paper the reference's header cites, src/davidson.f90:7-8, covers the
+    generalized problem): a converged pair's eigenvector leaves the basis, its GUARD vector B x takes its place - the pairs still wanted
+    are B-orthogonal to the locked ones, so the search space stays orthogonal to span(B X_locked) - and the Rayleigh-Ritz pencil is that
+    of the active basis.  Against the oracle's statement of the policy (generalized_eigensolver_dense_locking with a second matrix):
+    its iteration count, its eigenvalues; residuals below the tolerance, B-orthonormal eigenvectors, scipy's eigenvalues; one rank and
+    three (loopback transport), both storages, DPR and GJD."""
+    import scipy.linalg
+    A = O.generate_diagonal_dominant(n, sp, seed=3)
+    B = O.generate_diagonal_dominant(n, sp, 1.0, seed=4)
+    if L >= 5:
+        d = np.arange(1, n + 1, dtype=float) + 2.0
+        d[:L] = np.cumsum([1.0] + [0.08 if i % 2 else 1.7 for i in range(L - 1)])        # pairs that converge at different iterations
+        A[np.arange(n), np.arange(n)] = d
+    tol = 1e-8
+    lam_o, _, it_o = O.generalized_eigensolver_dense_locking(A, L, method, 200, tol, md, second_matrix=B)
+    assert it_o < 200
+    engs = [fd.DavidsonEngine(n, L, md, gev=True, rank=r, nranks=nranks, storage=storage) for r in range(nranks)]
+    if nranks > 1:
+        handles = (C.c_void_p * nranks)(*[e.c.h for e in engs])
+        assert fd.hip_lib().dav_local_group_join(handles, nranks) == 0
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            engs[r].set_correction_policy("locking")
+            engs[r].set_dense(1, A)
+            engs[r].set_dense(2, B)
+            out[r] = engs[r].solve(method, 200, tol)
+        except Exception as exc:      # noqa: BLE001
+            err[r] = exc
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in threads]
+    [t.join(timeout=300) for t in threads]
+    for e in engs:
+        e.close()
+    assert all(x is None for x in err), err
+    ref = scipy.linalg.eigh(A, B, eigvals_only=True, subset_by_index=[0, L - 1])
+    for lam, vec, iters in out:
+        assert iters == it_o, (iters, it_o)
+        assert np.abs(lam - lam_o).max() < EV_TOL and np.abs(lam - ref).max() < EV_TOL
+        assert (residuals(A, B, lam, vec) < tol).all()
+        assert np.abs(vec.T @ B @ vec - np.eye(L)).max() < 1e-7
+        assert (np.diff(lam) > 0).all()
 
 
 def test_policy_through_the_environment_reaches_the_dense_and_free_front_ends(monkeypatch):
