@@ -791,6 +791,21 @@ def main():
                     "device_floor_seconds": round((sg.apply_ms + dev_other) * 1e-3, 3),
                     "note": "fp64 MFMA and the generator's integer VALU work share the SIMD's issue port (DESIGN section 0, item 3): a fused A + B pass "
                             "could hide generation only under the HBM stalls of the 16-column A sweeps"}
+                # opt-in correction policies on the generalized problem ("locking" covers A x = lambda B x since round 6: the
+                # guard vectors B x of the locked pairs keep the search space B-orthogonal to them) - never part of the headline
+                pol3 = {"reference_policy_all": {"seconds": round(dt_g, 4), "iters": it_g, "sweeps_of_A": int(sg.applies)}}
+                for pol_ in ("unconverged", "locking"):
+                    try:
+                        g.set_correction_policy(pol_)
+                        g.c.synchronize(); g.c.reset_stats()
+                        dt_p3, it_p3, lam_p3 = timed_solves(g, "GJD", 1, args.tol)
+                        sp3 = g.c.stats()
+                        pol3[pol_] = {"seconds": round(dt_p3, 4), "iters": it_p3, "sweeps_of_A": int(sp3.applies), "columns_swept": int(sp3.apply_cols),
+                                      "max_abs_eigenvalue_diff_vs_reference_policy": float(np.abs(lam_p3 - lam_g).max())}
+                    except Exception as exc:   # noqa: BLE001
+                        pol3[pol_] = {"error": repr(exc)[:300]}
+                g.set_correction_policy("all")
+                extras["configs3_gjd"]["opt_in_policy"] = pol3
                 # opt-in mixed-precision correction path: the inner sweeps of A read an fp32 copy of its tiles
                 try:
                     g.set_inner_precision(32)

@@ -371,52 +371,58 @@ def test_dense_matrix_from_device_memory(storage):
                                  {"DAV_SYM_R": "2", "DAV_SYM_WIDE": "2", "DAV_SYM_RUN9": "1"}, {"DAV_SYM_R": "4"}, {"DAV_SYM_R": "4", "DAV_SYM_RUN9": "1"},
                                  {"DAV_SYM_R": "2", "DAV_SYM_RUN9": "3"}, {"DAV_SYM_R": "2", "DAV_SYM_PAIR": "0"},
                                  {"DAV_SYM_R": "2", "DAV_SYM_QUAD": "0"}, {"DAV_SYM_R": "4", "DAV_SYM_MFMA4": "0"}])
-def test_symmetric_sweep_alternative_kernels_and_schedules(env):
+def test_symmetric_sweep_alternative_kernels_and_schedules(env, monkeypatch):
     """The A/B knobs of the symmetric sweep (one-wave-per-SIMD kernel, unpaired 16-column launches, other run
     lengths, the super-row schedules with 2 / 4 block rows per workgroup that large matrices select by
     themselves - with 2 block rows: the wide one-wave-per-SIMD kernel of k_matvec_symw.hip for more than 8 columns
-    (DAV_SYM_WIDE = 2, default), for more than 16 only (1) or never (0: matvec_sym9_kernel<2>)) are read when an engine is
-    created; each set runs in a child process; same product, bit-reproducible.
+    (DAV_SYM_WIDE = 2, default), for more than 16 only (1) or never (0: matvec_sym9_kernel<2>)) are read ONCE per engine, when it
+    is created (csrc/engine.hip: tune_from_env) - so each set is put into the environment around the engines of this test (until
+    round 5 each ran in a child process: 13 interpreter starts); same product, bit-reproducible.
     Orders cover 1..10 block rows: ragged super rows, diagonal super blocks, a single block row."""
-    import os
-    import subprocess
-    import sys
-    code = r"""
-import numpy as np
-import fortran_davidson_amd as fd
-from fortran_davidson_amd.engine_c import OP_A, PANEL_V, PANEL_W, PANEL_S
-from oracle import davidson_oracle as O
-for n, k in [(300, 8), (1300, 40), (2500, 64), (200, 3), (1300, 5), (1800, 8), (2305, 7), (2500, 16), (1030, 24)]:
-    rng = np.random.default_rng(n + k)
-    A = rng.standard_normal((n, n)); A = A + A.T
-    X = rng.standard_normal((n, k))
-    with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
-        e.set_storage(1)
-        e.set_dense_host(OP_A, A)
-        e.panel_put(PANEL_V, 0, X)
-        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
-        W = e.panel_get(PANEL_W, 0, k)
-        ref = A @ X
-        assert np.abs(W - ref).max() <= 1e-12 * n * np.abs(ref).max(), (n, k)
-        e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
-        assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
-# the hashed operator generated in the sweep (every symmetric pair once) under the same schedule
-for n, k in [(700, 8), (1027, 17), (2500, 40), (1500, 4)]:
-    A = O.generate_diagonal_dominant(n, 1e-2, seed=13)
-    X = np.random.default_rng(n).standard_normal((n, k))
-    with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
-        e.set_storage(1)
-        e.set_operator_hashed(OP_A, 13, 1e-2)
-        e.panel_put(PANEL_V, 0, X)
-        e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
-        ref = A @ X
-        assert np.abs(e.panel_get(PANEL_W, 0, k) - ref).max() <= 1e-12 * np.abs(ref).max(), (n, k)
-print("OK")
-"""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root,
-                         env=dict(os.environ, PYTHONPATH=root, **env))
-    assert res.returncode == 0 and "OK" in res.stdout, (res.stdout + res.stderr)[-2000:]
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    for n, k in [(300, 8), (1300, 40), (2500, 64), (200, 3), (1300, 5), (1800, 8), (2305, 7), (2500, 16), (1030, 24)]:
+        A, X, ref = _alt_case(n, k)
+        with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
+            e.set_storage(1)
+            e.set_dense_host(OP_A, A)
+            e.panel_put(PANEL_V, 0, X)
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+            W = e.panel_get(PANEL_W, 0, k)
+            assert np.abs(W - ref).max() <= 1e-12 * n * np.abs(ref).max(), (n, k)
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_S, 0)
+            assert np.array_equal(W, e.panel_get(PANEL_S, 0, k))
+    # the hashed operator generated in the sweep (every symmetric pair once) under the same schedule
+    for n, k in [(700, 8), (1027, 17), (2500, 40), (1500, 4)]:
+        X, ref = _alt_hashed_case(n, k)
+        with fd.CEngine(n=n, max_cols=max(k, 16)) as e:
+            e.set_storage(1)
+            e.set_operator_hashed(OP_A, 13, 1e-2)
+            e.panel_put(PANEL_V, 0, X)
+            e.apply(OP_A, PANEL_V, 0, k, PANEL_W, 0)
+            assert np.abs(e.panel_get(PANEL_W, 0, k) - ref).max() <= 1e-12 * np.abs(ref).max(), (n, k)
+
+
+_ALT = {}
+
+
+def _alt_case(n, k):
+    """inputs and the numpy product of one (order, columns) case of the test above: made once, shared by its 13 knob sets"""
+    if (n, k) not in _ALT:
+        rng = np.random.default_rng(n + k)
+        A = rng.standard_normal((n, n))
+        A = A + A.T
+        X = rng.standard_normal((n, k))
+        _ALT[(n, k)] = (A, X, A @ X)
+    return _ALT[(n, k)]
+
+
+def _alt_hashed_case(n, k):
+    if ("hashed", n, k) not in _ALT:
+        A = O.generate_diagonal_dominant(n, 1e-2, seed=13)
+        X = np.random.default_rng(n).standard_normal((n, k))
+        _ALT[("hashed", n, k)] = (X, A @ X)
+    return _ALT[("hashed", n, k)]
 
 
 @pytest.mark.parametrize("n,k", [(50, 3), (256, 16), (700, 8), (1027, 17), (2500, 40)])
