@@ -58,8 +58,10 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/
 GEN_CYCLES_PER_WAVE_EVALUATION = 26 * 4 + 2 * 64
 # the reference's matrix-free test operator in its one-variable form (csrc/common.h: dav_harness_poly): 2 additions + 17 FMAs per entry
 HARNESS_CYCLES_PER_WAVE_EVALUATION = 19 * 4 + 2 * 64
+HARNESS_CYCLES_32 = (19 + 1.5) * 4 + 4 * 64       # the wide generating kernel: + 12 v_accvgpr_read per 8 entries, 4 MFMAs per 64 entries
 HARNESS_MODEL = ("1024 SIMDs x 2.4 GHz x 64 lanes / 204 cycles per wave-evaluation of 64 entries and 16 columns: 19 fp64 VALU instructions x 4 cycles "
-                 "(x = 1 - |l_i - l_j|, degree-17 Horner) + 2 fp64 MFMAs x 64 cycles (direct + transposed product) on one issue port")
+                 "(x = 1 - |l_i - l_j|, degree-17 Horner) + 2 fp64 MFMAs x 64 cycles (direct + transposed product) on one issue port; "
+                 "32 columns per launch (matvec_symw_kernel<2, ., ., 2>): 20.5 x 4 + 4 x 64 = 338")
 GEN_MODEL = ("1024 SIMDs x 2.4 GHz x 64 lanes / 232 cycles per wave-evaluation: 26 VALU instructions x 4 cycles (splitmix64 + key + "
              "conversion; no quarter-rate instruction among them, profiles/ubench/r03_valucost.log) + 2 fp64 MFMAs x 64 cycles (16 columns, "
              "direct + transposed product) - the two kinds of instruction do not overlap within a SIMD (same log: n VALU instructions "
@@ -789,7 +791,7 @@ def main():
                         "note": "per-kernel: stored_tiles = launches of the stored-tile kernels on B's resident block rows (bytes = 8 x stored entries + 16 N k), "
                                 "generated_block_rows = launches that evaluate the hash (entries once per 16 columns; once per 32 in the wide kernel's generating variant)"},
                     "device_floor_seconds": round((sg.apply_ms + dev_other) * 1e-3, 3),
-                    "note": "fp64 MFMA and the generator's integer VALU work share the SIMD's issue port (DESIGN section 0, item 3): a fused A + B pass "
+                    "note": "fp64 MFMA and the generator's integer VALU work share the SIMD's issue port (docs/history/DESIGN_rounds_1_to_5.md section 0, item 3; DESIGN section 10): a fused A + B pass "
                             "could hide generation only under the HBM stalls of the 16-column A sweeps"}
                 # opt-in correction policies on the generalized problem ("locking" covers A x = lambda B x since round 6: the
                 # guard vectors B x of the locked pairs keep the search space B-orthogonal to them) - never part of the headline
@@ -818,7 +820,7 @@ def main():
                         "ms_per_sweep_of_A_end_to_end": round(sm_.apply_ms / max(sm_.applies, 1), 3),
                         "max_abs_eigenvalue_diff_vs_fp64_inner": float(np.abs(lam_m - lam_g).max()),
                         "note": "engine_set_inner_precision(eng, 32): inner MINRES sweeps of A of up to 16 columns on fp32 tiles (fp64 accumulation); kept as an option for orders where "
-                                "the fp32 copy fits next to B's resident tiles - at N=200000 it competes with them for the same memory and buys nothing (DESIGN section 11); not the default"}
+                                "the fp32 copy fits next to B's resident tiles - at N=200000 it competes with them for the same memory and buys nothing (docs/history/DESIGN_rounds_1_to_5.md section 11); not the default"}
                 except Exception as exc:   # noqa: BLE001  (e.g. no room for the fp32 copy)
                     extras["configs3_gjd"]["inner_fp32"] = {"error": repr(exc)[:300]}
                 g.close()
@@ -894,7 +896,7 @@ def main():
                 if n_h <= 200000:
                     h.solve("DPR", 1000, 1e-8, want_vectors=False)             # warm-up (lazy workspace)
                 else:
-                    h.c.bench_apply2(16, 1)
+                    h.c.bench_apply2(32, 1)                                    # untimed: the partial-sum slabs of a 32-column launch allocated
                 h.c.synchronize(); h.c.reset_stats()
                 dt, it, lam = timed_solves(h, "DPR", 1, 1e-8)
                 st = h.c.stats()
@@ -902,13 +904,22 @@ def main():
                 entries = 0.5 * float(n_h) * (float(n_h) + 1.0)
                 launches = max(int(st.apply_launches), 1)
                 per_launch = st.apply_kernel_ms / launches
+                # a launch generates every entry once: for 16 columns (204 cycles per 64 entries) or - blocks wider than 16 columns, the
+                # generating variant of the wide kernel - for 32 (HARNESS_CYCLES_32)
+                n32 = min(max((int(st.apply_cols) - 16 * launches) // 16, 0), launches)
+                n16 = launches - n32
+                unit_rate = 1024 * 2.4e9 * 64
+                model_ms = entries * (n16 * HARNESS_CYCLES_PER_WAVE_EVALUATION + n32 * HARNESS_CYCLES_32) / unit_rate * 1e3
                 return {"workload": f"N={n_h}, lowest={lowest_h}, max_dim_sub={max_dim_h}, tol=1e-8, the reference's test operator (entries generated in the sweep, each symmetric pair once), B = I, DPR",
-                        "iters": it, "seconds": round(dt, 4), "iterations_per_s": round(it / dt, 3), "sweeps": int(st.applies), "launches_of_16_columns": launches,
+                        "iters": it, "seconds": round(dt, 4), "iterations_per_s": round(it / dt, 3), "sweeps": int(st.applies),
+                        "launches_of_16_columns": n16, "launches_of_32_columns": n32, "columns_swept": int(st.apply_cols),
                         "ms_per_launch": round(per_launch, 3), "ms_in_sweep_kernels": round(st.apply_kernel_ms, 2), "eigenvalues": [float(x) for x in lam[:3]],
-                        "entries_evaluated_per_s": round(entries / (per_launch * 1e-3), 0) if per_launch > 0 else None,
+                        "entries_evaluated_per_s": round(entries * launches / (st.apply_kernel_ms * 1e-3), 0) if st.apply_kernel_ms > 0 else None,
                         "roofline": {"bound": "valu-fp64 + mfma on one issue port", "unit": "entries/s",
-                                     "achieved": round(entries / (per_launch * 1e-3), 0) if per_launch > 0 else None, "peak": round(rate, 0),
-                                     "frac": round(entries / (per_launch * 1e-3) / rate, 4) if per_launch > 0 else None,
+                                     "achieved": round(entries * launches / (st.apply_kernel_ms * 1e-3), 0) if st.apply_kernel_ms > 0 else None,
+                                     "peak": round(entries * launches / (model_ms * 1e-3), 0) if model_ms > 0 else None,
+                                     "frac": round(model_ms / st.apply_kernel_ms, 4) if st.apply_kernel_ms > 0 else None,
+                                     "peak_16_columns": round(rate, 0), "peak_32_columns": round(unit_rate / HARNESS_CYCLES_32, 0),
                                      "entries_per_launch": entries, "model": HARNESS_MODEL}}
             hb["large"] = harness_solve(args.harness_n, 3, 20)
             hb["roofline"] = dict(hb["large"]["roofline"], N=args.harness_n)

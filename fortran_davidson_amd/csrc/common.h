@@ -113,6 +113,7 @@ struct OpParams {          // passed by value to the matrix-free kernels
   int trig;
   const double* e_table;   // device, n entries: exp(real(i) / real(n)) as the caller evaluated it (single precision)
   const double* l2_table;  // device, roundup(n, 256) + 256 entries: 2 log e_i, zero behind n (harness operator, polynomial form)
+  const double* dadd_table; // device, like l2_table: the diagonal ENTRIES of operator A: poly(1) + (double)(float)(i + 1) (src/tests/test_utils.f90:49)
   int libm;                // harness operator: 1 = the four library calls per entry (DAV_HARNESS_LIBM=1), 0 = the polynomial form
 };
 // entry of the harness operator in whichever form the engine was created with

@@ -558,6 +558,7 @@ extern "C" int dav_destroy(dav_handle_t e) {
     pool_free(e->op[w].a32);
     pool_free(e->op[w].e_table);
     pool_free(e->op[w].l2_table);
+    pool_free(e->op[w].dadd_table);
   }
   lt.lap("operators");
   if (e->stream) { (void)hipStreamSynchronize(e->stream); pool_stream_put(e->stream, e->device); }

@@ -39,7 +39,8 @@ void sym9_sweep(E* e, int R, const OpDesc& o, bool use32, const SymSet& set, con
   }
   // the hashed operator at 17-32 columns per launch: the wide kernel's generating variant - one generated entry feeds the MFMAs of
   // both 16-column groups (Tune::sym_gen_wide = 0: two groups of the 16-column kernel, every entry generated twice)
-  if (o.kind == DAV_KIND_HASHED && R == 2 && kk > 16 && wide > 0 && e->tune.sym_gen_wide) {
+  // (round 6: the reference's matrix-free test operator in its polynomial form too - GEN = 2 / 3 of that kernel)
+  if ((o.kind == DAV_KIND_HASHED || (o.kind == DAV_KIND_HARNESS && !o.harness_libm)) && R == 2 && kk > 16 && wide > 0 && e->tune.sym_gen_wide) {
     launch_matvec_symw_generated(e->stream, op_params(o), e->n, e->sym_nb, pl->items, pl->nitems, pl->zslot_begin, xt, kk, slabD, slabT,
                                  (npair + 1) / 2, e->xt_group_stride, dstride, tstride);
     return;
@@ -321,7 +322,8 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
     // pairing shares the READS of stored tiles: nothing to share when the entries are generated
     // ... except where the generating variant of the wide kernel shares the GENERATED entries between two groups (hashed operator,
     // two-block-row schedule)
-    const bool gen_wide = o.kind == DAV_KIND_HASHED && e->tune.sym_gen_wide && e->tune.sym_wide > 0 && sym_schedule(e, 32, false) == 2;
+    const bool gen_wide = (o.kind == DAV_KIND_HASHED || (o.kind == DAV_KIND_HARNESS && !o.harness_libm)) && e->tune.sym_gen_wide && e->tune.sym_wide > 0 &&
+                          sym_schedule(e, 32, false) == 2;
     int step = (e->tune.sym_pair && !e->sym_no_pair && (o.kind == DAV_KIND_DENSE || gen_wide)) ? 32 : 16;
     // several ranks - or a communicator on a single rank (DAVIDSON_FORCE_RCCL=1: the GPU tests run the all-gather and the
     // reduce-scatter of this path through RCCL on a one-GPU box)
@@ -394,7 +396,7 @@ static int apply_sym_set(E* e, int which, OpDesc& o, const SymSet& set, bool par
         // the second operator's sweep kernels by what they read (level 2): stored tiles -> bytes, generated block rows -> entries
         // evaluated (once per 16 columns; once per 32 where the generating variant of the wide kernel runs)
         const double tiles_entries = (double)set.ntiles * SYM_TB * SYM_TB;
-        const bool gen_shared = o.kind == DAV_KIND_HASHED && R == 2 && kk > 16 && e->tune.sym_wide > 0 && e->tune.sym_gen_wide;
+        const bool gen_shared = (o.kind == DAV_KIND_HASHED || (o.kind == DAV_KIND_HARNESS && !o.harness_libm)) && R == 2 && kk > 16 && e->tune.sym_wide > 0 && e->tune.sym_gen_wide;
         if (o.kind == DAV_KIND_DENSE) CHK(timed_begin(e, 8, (use32 ? 4.0 : 8.0) * tiles_entries + 16.0 * (double)e->n * kk, &kslot));
         else CHK(timed_begin(e, 9, tiles_entries * (gen_shared ? (npair + 1) / 2 : npair), &kslot));
         if (kslot >= 0) e->ev_flops[kslot] = 4.0 * tiles_entries * kk;          // every stored / generated entry is used twice

@@ -127,6 +127,7 @@ struct OpDesc {
   int trig = 0;
   bool harness_libm = false; // harness operator: entries by the four library calls (Tune::harness_libm when the operator was set)
   double* e_table = nullptr; // device: the caller's exp(real(i) / real(n)) table (harness operator)
+  double* dadd_table = nullptr; // device, same length: the diagonal entries of operator A, poly(1) + (double)(float)(i + 1)
   double* l2_table = nullptr; // device: 2 log e_i, roundup(n, 256) + 256 entries, zero behind n (polynomial form of the harness operator)
   double* diag = nullptr;    // device, nloc_pad (local rows)
   int storage = 0;           // dense: 0 = full, 1 = symmetric-tiled (lower block triangle)

@@ -485,7 +485,7 @@ extern "C" int dav_set_dense_generated(dav_handle_t e, int which, uint64_t seed,
 OpParams op_params(const OpDesc& o) {
   OpParams p{};
   p.kind = o.kind; p.seed = o.seed; p.sparsity = o.sparsity; p.use_diag = o.use_diag; p.diag_val = o.diag_val;
-  p.trig = o.trig; p.e_table = o.e_table; p.l2_table = o.l2_table; p.libm = o.harness_libm;
+  p.trig = o.trig; p.e_table = o.e_table; p.l2_table = o.l2_table; p.dadd_table = o.dadd_table; p.libm = o.harness_libm;
   return p;
 }
 
@@ -535,6 +535,19 @@ extern "C" int dav_set_operator_harness(dav_handle_t e, int which, const double*
   if (e->n > 0 && l2[(size_t)e->n - 1] - l2[0] > 2.0 * (1.0 + 1e-6)) o.harness_libm = true;
   if (!o.l2_table) HIPCHK(pool_malloc(&o.l2_table, sizeof(double) * l2n));
   HIPCHK(hipMemcpyAsync(o.l2_table, l2.data(), sizeof(double) * l2n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  // the diagonal ENTRIES of operator A - poly(x = 1) * 1 + real(i) (src/tests/test_utils.f90:49), rounded as the kernels round it: the
+  // Horner form at x = 1 is the sum of the coefficients, highest first, one rounding per step - as a table for the wide generating
+  // kernel's diagonal tiles
+  double c0 = 0.0;
+  {
+    static const double cf[] = {DAV_HARNESS_COS_COEFFS};
+    c0 = cf[DAV_HARNESS_COS_DEGREE];
+    for (int k = DAV_HARNESS_COS_DEGREE - 1; k >= 0; --k) c0 = std::fma(c0, 1.0, cf[k]);
+  }
+  for (size_t i = 0; i < l2n; ++i) l2[i] = (int64_t)i < e->n ? c0 + (double)(float)(i + 1) : 0.0;
+  if (!o.dadd_table) HIPCHK(pool_malloc(&o.dadd_table, sizeof(double) * l2n));
+  HIPCHK(hipMemcpyAsync(o.dadd_table, l2.data(), sizeof(double) * l2n, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   launch_diag_free(e->stream, op_params(o), e->row0, e->nloc, o.diag);
   CHK(refresh_diag_host(e, which));

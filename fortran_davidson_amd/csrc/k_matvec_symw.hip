@@ -55,10 +55,17 @@ __device__ __forceinline__ void symw_static_for(F&& f) { symw_static_for_impl(f,
 // Gram-layout (transposed) operands of half-step parity par, 16-row block ib, row pair j: a[P(par,ib,j) .. +3] (x = +0..1, y = +2..3)
 #define SYMW_RING(k, u) (224 - 16 * NSLOT + 16 * (k) + 4 * (u))
 #define SYMW_XJ(s, u, bcb) (224 + 16 * (s) + 4 * (u) + 2 * (bcb))
-#define SYMW_P(par, ib, j) (128 + 16 * (par) + 8 * (ib) + 4 * (j))
+#define SYMW_P(par, ib, j) (SYMW_PBASE + 16 * (par) + 8 * (ib) + 4 * (j))       // SYMW_PBASE: constexpr of the kernel (128; the harness variants: 168)
 // fp32 tiles: raw ring slot k, load u in FIXED VGPRs v[224 + 8 k + 2 u .. + 1] (tests/test_isa_lint.py: the compiler stays below v224)
 #define SYMW_RAW(k, u) (224 + 8 * (k) + 2 * (u))
-constexpr int symw_fixed_lo() { return 128; }   // first fixed register (tests/test_isa_lint.py)
+// harness operator (GEN >= 2; the ring registers are free there): 2 log e of rows 2c, 2c + 1 of half-step hs: a[LROW(hs) .. + 3]; of tile
+// column 4u + g of the unit: a[LCOL(u) .. + 1]
+#ifndef SYMW_HARN_GROUP
+#define SYMW_HARN_GROUP 1          // tile columns (= 2 Horner chains each) evaluated together in the burst
+#endif
+#define SYMW_LROW(hs) (200 + 4 * (hs))
+#define SYMW_LCOL(u) (216 + 2 * (u))
+constexpr int symw_fixed_lo(bool harness) { return harness ? 168 : 128; }   // first fixed register (tests/test_isa_lint.py)
 
 __device__ double symw_zero_page[16 * 16];     // B operand of a tile that is not there
 
@@ -111,15 +118,28 @@ __device__ __forceinline__ i32x4 symw_desc(const void* p, int bytes) {
 // entry feeds 2 NB = 4 MFMAs instead of the 2 of the 16-column kernels (matvec_sym9_kernel<2, GEN>), whose 32- and 64-column
 // blocks regenerate the whole operator per 16 columns - the generator (26 VALU instructions per 64 entries, on the issue port the
 // MFMAs use) is paid once per 32 columns.
-template <int NB, bool TALL, bool F32, bool GEN>
+// GEN = 2 / 3 (round 6): the reference's matrix-free test operator (src/tests/test_utils.f90:72-116; cos / sin) in its one-variable form
+// (common.h: dav_harness_poly - x = 1 - |l_i - l_j| from a table of 2 log e, a degree-17 / 19 polynomial: 19 / 21 fp64 VALU instructions
+// per entry) on the same data path.  The table values a wave needs - its 128 rows (8 per lane, fixed for the work item) and a unit's 16
+// tile columns (4 per lane) - wait in accumulation registers of the range the stored variants use for their load ring (a200.. : SYMW_LROW /
+// SYMW_LCOL): the rows are put there once, the columns of unit q + 1 are loaded straight into them in half-step 2 of unit q (their
+// last reader was that half-step's burst), and each burst fetches its 12 words with v_accvgpr_read - 12 instructions next to 160.
+template <int NB, bool TALL, bool F32, int GEN>
 __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restrict__ tiles_any, const int64_t* __restrict__ row_off,
                                                              const int* __restrict__ items, const int* __restrict__ zslot_begin,
                                                              const double* __restrict__ xt, double* __restrict__ slabD,
                                                              double* __restrict__ slabT, int kcols, int nwg, int64_t xt_gstride,
                                                              int64_t slabD_gstride, int64_t slabT_gstride, int nb, OpParams op, int64_t n) {
   static_assert(!TALL || NB == 1, "two slices per wave: 16 columns per workgroup");
-  static_assert(!GEN || (NB == 2 && !TALL && !F32), "generated entries: 32 columns, two block rows per workgroup");
-  constexpr bool REGT = F32 || GEN;     // the sub-blocks reach the MFMAs and the transposition through ordinary registers
+  static_assert(GEN == 0 || (NB == 2 && !TALL && !F32), "generated entries: 32 columns, two block rows per workgroup");
+  constexpr bool HARN = GEN >= 2;       // the reference's matrix-free test operator (GEN = 2: cos, 3: sin), polynomial form
+  // The harness variants run at the limit of the 256 ordinary registers (128 of direct partials, 64 of transposed ones, 32 of generated
+  // sub-blocks, and the burst's Horner chains): the allocator parks a few dozen lane constants in accumulation registers - the lowest
+  // free ones, a128 up.  So these variants leave a128-a167 to it and keep their own fixed registers above (the ring's range is free
+  // where nothing is loaded): Gram-layout operands a168-a199, table values a200-a223, X_J a224-a255.  tests/test_isa_lint.py checks that
+  // compiler-generated code stays below symw_fixed_lo(harness).
+  constexpr int SYMW_PBASE = symw_fixed_lo(HARN);
+  constexpr bool REGT = F32 || GEN != 0;     // the sub-blocks reach the MFMAs and the transposition through ordinary registers
   (void)op; (void)n;
   static_assert(!F32 || (NB == 1 && !TALL), "fp32 tiles: 16 columns, two block rows per workgroup");
   using TileT = std::conditional_t<F32, float, double>;
@@ -222,12 +242,12 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
   // (a scalar instruction costs ~5 cycles of matrix-pipe time here, profiles/ubench/r03_fatwave_vgpr_acc.log).
   constexpr int64_t UNIT_BYTES = 16 * SYM_TB * (int64_t)sizeof(TileT);
   const int64_t unit0 = (int64_t)J0 * UPJ * UNIT_BYTES;
-  const char* const trow_max = GEN ? nullptr : symw_uniform(reinterpret_cast<const char*>(tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
+  const char* const trow_max = GEN != 0 ? nullptr : symw_uniform(reinterpret_cast<const char*>(tiles + row_off[Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
   const char* trow_own[NSL];
   unsigned qlim_d[NSL];              // units whose tile is stored for this wave's slice (J <= I): q < qlim_d
 #pragma unroll
   for (int sl = 0; sl < NSL; ++sl) {
-    trow_own[sl] = GEN ? nullptr : symw_uniform(reinterpret_cast<const char*>(tiles + row_off[have_row[sl] ? Is[sl] : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
+    trow_own[sl] = GEN != 0 ? nullptr : symw_uniform(reinterpret_cast<const char*>(tiles + row_off[have_row[sl] ? Is[sl] : Imax] * (int64_t)(SYM_TB * SYM_TB) + 128 * rhalf) + unit0);
     qlim_d[sl] = symw_uniform(have_row[sl] ? (Is[sl] >= J0 ? (unsigned)(Is[sl] - J0 + 1) * UPJ : 0u) : 0u);
   }
   // position i of the sequence: unit i / NSL, slice i % NSL
@@ -310,8 +330,91 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
   // wave - masked like stored ones - through dav_hashed_entry with its bounds).  All conditions are wave-uniform.
   const uint64_t seedmix = op.seed * 0x9E3779B97F4A7C15ull;
   const double gscale = op.sparsity * (1.0 / 9007199254740992.0);
-  auto generate = [&](unsigned st, f64x2 (&wv)[4]) {
-    if constexpr (GEN) {
+  // harness operator: the table values of this wave's rows into their accumulation registers (once per work item); a wave without a
+  // block row generates - and masks - the tile of block row Imax, as the stored kernels read it
+  const int Irow = have_row[0] ? Is[0] : Imax;
+  auto acc_read = [&](auto regc) {
+    constexpr int RG = decltype(regc)::value;
+    unsigned lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_accvgpr_read_b32 %1, a%c3" : "=v"(lo), "=v"(hi) : "i"(RG), "i"(RG + 1));
+    return __hiloint2double((int)hi, (int)lo);
+  };
+  // the 4 table values of unit q's tile columns 4u + g, straight into a[SYMW_LCOL]: one 16-value window per unit
+  const unsigned lcoff = g * (unsigned)sizeof(double);
+  auto lcol_desc = [&](unsigned q) {
+    q = q < nunits ? q : nunits - 1;
+    return symw_desc(reinterpret_cast<const char*>(op.l2_table + (int64_t)J0 * SYM_TB) + (int64_t)q * (16 * (int64_t)sizeof(double)), 16 * (int)sizeof(double));
+  };
+  auto lcol_load = [&](auto uc, const i32x4& d, auto fresh) {
+    constexpr int U = decltype(uc)::value;
+    const unsigned vo = lcoff;
+    const i32x4 dd = d;
+    if constexpr (U == 0 && decltype(fresh)::value)
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[%c0:%c1], %2, %3, 0 offen offset:%c4"
+                   :: "i"(SYMW_LCOL(U)), "i"(SYMW_LCOL(U) + 1), "v"(vo), "s"(dd), "i"(4 * U * (int)sizeof(double)) : "memory");
+    else
+      asm volatile("buffer_load_dwordx2 a[%c0:%c1], %2, %3, 0 offen offset:%c4"
+                   :: "i"(SYMW_LCOL(U)), "i"(SYMW_LCOL(U) + 1), "v"(vo), "s"(dd), "i"(4 * U * (int)sizeof(double)) : "memory");
+  };
+  if constexpr (HARN) {
+    symw_static_for<4>([&](auto hsc) {
+      constexpr int hs = decltype(hsc)::value;
+      const f64x2 lr = *reinterpret_cast<const f64x2*>(op.l2_table + (int64_t)Irow * SYM_TB + 128 * rhalf + 32 * hs + 2 * c);
+      const unsigned x0 = (unsigned)__double2loint(lr.x), x1 = (unsigned)__double2hiint(lr.x), y0 = (unsigned)__double2loint(lr.y), y1 = (unsigned)__double2hiint(lr.y);
+      asm volatile("v_accvgpr_write_b32 a%c0, %4\n\tv_accvgpr_write_b32 a%c1, %5\n\tv_accvgpr_write_b32 a%c2, %6\n\tv_accvgpr_write_b32 a%c3, %7"
+                   :: "i"(SYMW_LROW(hs)), "i"(SYMW_LROW(hs) + 1), "i"(SYMW_LROW(hs) + 2), "i"(SYMW_LROW(hs) + 3), "v"(x0), "v"(x1), "v"(y0), "v"(y1));
+    });
+  }
+  auto generate = [&](unsigned st, f64x2 (&wv)[4], auto hsc) {
+    constexpr int HSG = decltype(hsc)::value;           // half-step of step st (compile-time: it selects registers)
+    (void)HSG;
+    if constexpr (HARN) {
+      st = st < 4 * nunits ? st : 4 * nunits - 1;
+      const unsigned q = st >> 2;
+      const int J = J0 + (int)(q / UPJ);
+      if (J < Irow && ((int64_t)Irow + 1) * SYM_TB <= n) {
+        // strictly below the diagonal, inside the matrix: x = 1 - |l_row - l_col|, one polynomial per entry
+        // (2 SYMW_HARN_GROUP Horner chains at a time; all eight at once would need 32 more live registers than the wave has, and the
+        // allocator would take them from the accumulation registers this kernel names by hand - tests/test_isa_lint.py checks that it does not)
+        const double r0 = acc_read(std::integral_constant<int, SYMW_LROW(HSG)>{}), r1 = acc_read(std::integral_constant<int, SYMW_LROW(HSG) + 2>{});
+        symw_static_for<4 / SYMW_HARN_GROUP>([&](auto hc) {
+          constexpr int H = decltype(hc)::value;
+          symw_static_for<SYMW_HARN_GROUP>([&](auto jc) {
+            constexpr int U = SYMW_HARN_GROUP * H + decltype(jc)::value;
+            const double lc = acc_read(std::integral_constant<int, SYMW_LCOL(U)>{});
+            wv[U].x = dav_harness_poly<GEN == 3>(r0, lc);
+            wv[U].y = dav_harness_poly<GEN == 3>(r1, lc);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+        // the diagonal tile, the ragged last block row, tiles that are "not there" for this wave (masked like stored ones)
+        // (a few tiles per run, but the code sits in the loop sixteen times: 32-bit indices - the table is indexed by row / column,
+        // n < 2^31 - and one entry at a time, so that this path asks for no more registers than the fast one)
+        const int Ie = (have_row[0] && q < qlim_d[0]) ? Is[0] : Imax;
+        int gi = Ie * SYM_TB + 128 * rhalf + 32 * HSG + 2 * (int)c;
+        int gj = J * SYM_TB + 16 * (int)(q % UPJ) + (int)g;
+        asm volatile("" : "+v"(gi), "+v"(gj));          // opaque: nothing of this path is computed ahead of the loop and kept in registers
+        const int nn = (int)n;
+        const double* __restrict__ l2 = op.l2_table;       // padded with zeros behind n: every index below is inside it
+        // the diagonal entries of this lane's two rows, from a table (operator A: poly(1) + real(i), one rounding each as the other
+        // kernels compute it; operator B: 1): at most one entry per row is diagonal, and the conversion in this place would cost the
+        // wave a dozen registers it does not have
+        const f64x2 dgv = GEN == 3 ? f64x2{1.0, 1.0} : *reinterpret_cast<const f64x2*>(op.dadd_table + gi);
+        auto entry = [&](int i, int j, double dg) {
+          const double v = dav_harness_poly<GEN == 3>(l2[i], l2[j]);
+          const double e = i == j ? dg : v;
+          return (i < nn && j < nn) ? e : 0.0;
+        };
+        symw_static_for<4>([&](auto uc) {
+          constexpr int U = decltype(uc)::value;
+          wv[U].x = entry(gi, gj + 4 * U, dgv.x);
+          __builtin_amdgcn_sched_barrier(0);
+          wv[U].y = entry(gi + 1, gj + 4 * U, dgv.y);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    } else if constexpr (GEN != 0) {
       st = st < 4 * nunits ? st : 4 * nunits - 1;
       const unsigned q = st >> 2, hs = st & 3;
       const int J = J0 + (int)(q / UPJ);
@@ -439,20 +542,25 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
   static_assert(DEPTH == 3 && NSLOT == 4, "the counts below hold for a 4-slot ring with 3 half-steps of lookahead");
   constexpr auto younger = [](int hs) { return 4 + (NBL / 2) * (hs == 0 ? 0 : hs == 2 ? 2 : 1); };
   i32x4 ud[3];                                                  // descriptors of units q, q + 1, q + 2
-  if constexpr (!GEN) { ud[0] = unit_desc(0); ud[1] = unit_desc(1); ud[2] = unit_desc(2); }
+  if constexpr (GEN == 0) { ud[0] = unit_desc(0); ud[1] = unit_desc(1); ud[2] = unit_desc(2); }
   symw_static_for<NB>([&](auto bc) {
     const i32x4 d = x_desc(0, decltype(bc)::value);
     symw_static_for<4>([&](auto uc) { x_load(std::integral_constant<int, 0>{}, uc, bc, d, std::true_type{}); });
   });
-  if constexpr (!GEN) {
+  if constexpr (GEN == 0) {
     symw_static_for<DEPTH>([&](auto sc) {
       constexpr int st = decltype(sc)::value;
       symw_static_for<4>([&](auto uc) { t_load(std::integral_constant<int, st % NSLOT>{}, uc, ud[st / 4], st % 4, std::true_type{}); });
     });
     asm volatile("s_waitcnt vmcnt(%c0)" :: "i"(4 * (DEPTH - 1)) : "memory");
   }
-  if constexpr (GEN) {
-    generate(0, wide[0]);
+  if constexpr (GEN != 0) {
+    if constexpr (HARN) {
+      const i32x4 ld0 = lcol_desc(0);
+      symw_static_for<4>([&](auto uc) { lcol_load(uc, ld0, std::true_type{}); });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    generate(0, wide[0], std::integral_constant<int, 0>{});
     symw_static_for<4>([&](auto uc) { ds_w_reg(uc, wide[0][decltype(uc)::value]); });
   } else if constexpr (F32) {
     widen(std::integral_constant<int, 0>{}, wide[0]);
@@ -479,7 +587,10 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
 #pragma unroll
     for (int bcb = 0; bcb < NB; ++bcb) xd[bcb] = x_desc(q + 1, bcb);
     i32x4 udn;
-    if constexpr (!GEN) udn = unit_desc(q + 3);
+    if constexpr (GEN == 0) udn = unit_desc(q + 3);
+    i32x4 lcd;                                         // harness variant: the table window of unit q + 1's tile columns
+    if constexpr (HARN) lcd = lcol_desc(q + 1);
+    (void)lcd;
     // the sums of strip st (units 4 st .. 4 st + 3) were staged by position NSL (4 st + 3) + NSL + 1 of the sequence; the barrier
     // of the next even position publishes them: 4 st + 6 (TALL: 8 st + 10)
     constexpr unsigned FP = 4 * NSL, F0 = TALL ? 10 : 6;
@@ -504,19 +615,21 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
 #endif
       // GEN: the only vector-memory loads of the loop are X_J of unit q + 1, issued in half-steps 0 and 1 of unit q: all landed
       // long before the next unit's half-step 0 asks for them
-      if constexpr (!GEN) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" :: "i"(younger(hs)) : "memory");
-      else if constexpr (hs == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // (harness variant: the table values of unit q + 1's tile columns were loaded in half-step 2 and are first read by the burst of
+      // half-step 3, which generates step 4 (q + 1))
+      if constexpr (GEN == 0) asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)" :: "i"(younger(hs)) : "memory");
+      else if constexpr (hs == 0 || (HARN && hs == 3)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if DAV_SYMW_STAMPS > 1
       STAMP(w1);
       st_vm += w1 - w0;
 #endif
       if constexpr (F32) widen(std::integral_constant<int, (hs + 1) % NSLOT>{}, wide[(hs + 1) & 1]);   // ONE VALU burst per half-step
-      if constexpr (GEN) {
+      if constexpr (GEN != 0) {
         // the generator of step s + 1, pinned as ONE burst in front of this half-step's MFMAs (VALU instructions between MFMAs
         // cost 12.5 + 4 n cycles per gap, profiles/ubench/r03_valucost.log; the scheduler would spread them)
         __builtin_amdgcn_sched_barrier(0);
-        generate(4 * q + hs + 1, wide[(hs + 1) & 1]);
+        generate(4 * q + hs + 1, wide[(hs + 1) & 1], std::integral_constant<int, (hs + 1) & 3>{});
         __builtin_amdgcn_sched_barrier(0);
       }
       // The memory operations of the half-step, one slot behind every second MFMA: the transposition of step s + 1 (ring slot
@@ -536,7 +649,8 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
             else ds_w(WS{}, std::integral_constant<int, k>{});
           } else if constexpr (k < 8) ds_r(NP{}, std::integral_constant<int, k - 4>{});
           else if constexpr (k < 12) {
-            if constexpr (!GEN) t_load(LS{}, std::integral_constant<int, k - 8>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4, old);
+            if constexpr (GEN == 0) t_load(LS{}, std::integral_constant<int, k - 8>{}, ud[(hs + DEPTH) / 4], (hs + DEPTH) % 4, old);
+            else if constexpr (HARN && hs == 2) lcol_load(std::integral_constant<int, k - 8>{}, lcd, old);
           } else if constexpr (hs < 2) x_load(XS{}, std::integral_constant<int, k - 12>{}, std::integral_constant<int, hs>{}, xd[hs < 2 ? hs : 0], old);
           // the exchange (compiler-visible LDS operations: the asm statements around them keep them in their slots)
           if constexpr (SET == 0 && hs == 0 && k < 8) z_write(zcs[1 - PP], (q >> 1) - 1, k);
@@ -626,7 +740,7 @@ __global__ __launch_bounds__(256, 1) void matvec_symw_kernel(const void* __restr
       st_mf += fb - fa;
 #endif
     });
-    if constexpr (!GEN) { ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn; }
+    if constexpr (GEN == 0) { ud[0] = ud[1]; ud[1] = ud[2]; ud[2] = udn; }
 #ifdef DAV_SYMW_STAMPS
     unsigned long long t4;
     STAMP(t4);
@@ -709,7 +823,7 @@ void launch_matvec_symw(hipStream_t st, int nbw, bool tall, bool tiles_f32, cons
   const OpParams op{};
   const int64_t n = 0;
 #define SYMW_LAUNCH(NBW, T, F)                                                                                                          \
-  hipLaunchKernelGGL((matvec_symw_kernel<NBW, T, F, false>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
+  hipLaunchKernelGGL((matvec_symw_kernel<NBW, T, F, 0>), grid, block, 0, st, tiles, row_off, items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, \
                      nwg, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
   if (tiles_f32) SYMW_LAUNCH(1, false, true);
   else if (nbw == 2) SYMW_LAUNCH(2, false, false);
@@ -722,6 +836,11 @@ void launch_matvec_symw(hipStream_t st, int nbw, bool tall, bool tiles_f32, cons
 void launch_matvec_symw_generated(hipStream_t st, OpParams op, int64_t n, int nb, const int* items_dev, int nitems, const int* zslot_begin_dev,
                                   const double* xt, int kcols, double* slabD, double* slabT, int nwg, int64_t xt_gstride, int64_t slabD_gstride,
                                   int64_t slabT_gstride) {
-  hipLaunchKernelGGL((matvec_symw_kernel<2, false, false, true>), dim3(nitems * nwg), dim3(256), 0, st, (const void*)nullptr, (const int64_t*)nullptr,
-                     items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, nwg, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n);
+#define SYMW_GEN_LAUNCH(G)                                                                                                                       \
+  hipLaunchKernelGGL((matvec_symw_kernel<2, false, false, G>), dim3(nitems * nwg), dim3(256), 0, st, (const void*)nullptr, (const int64_t*)nullptr, \
+                     items_dev, zslot_begin_dev, xt, slabD, slabT, kcols, nwg, xt_gstride, slabD_gstride, slabT_gstride, nb, op, n)
+  // the reference's test operator in its polynomial form (GEN = 2: cos, 3: sin); the hashed operator (1)
+  if (op.kind == DAV_KIND_HARNESS) { if (op.trig != 0) SYMW_GEN_LAUNCH(3); else SYMW_GEN_LAUNCH(2); }
+  else SYMW_GEN_LAUNCH(1);
+#undef SYMW_GEN_LAUNCH
 }

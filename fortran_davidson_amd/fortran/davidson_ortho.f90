@@ -302,7 +302,7 @@ contains
              if (nnull > 0) return
           else if (relative_tests .and. ortho_early()) then
              ! the FIRST pass already sees dependence that is exact up to rounding (remaining pivot at the noise level of the Gram
-             ! product: the corrections of a banded matrix, section 0 of DESIGN.md): replaced before the block is swept, instead of a
+             ! product: the corrections of a banded matrix, docs/history/DESIGN_rounds_1_to_5.md section 0): replaced before the block is swept, instead of a
              ! sweep of noise columns, a second pass that finds them, and a second sweep.  Conservative (dependent_columns: noise)
              do j = 1, kt
                 w(j) = 64.0_dp * epsilon(1.0_dp) * g(j, j) * d(j) * d(j)          ! d(j)**2 = 1 / gp(j, j) before the scaling

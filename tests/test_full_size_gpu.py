@@ -469,28 +469,31 @@ def test_reference_test_operator_generated_in_the_symmetric_sweep_at_n100000():
         # atan2 + sqrt + log + cos): the operator applied to unit vectors returns its columns - every entry within 1e-13 of the oracle's
         # library-call chain, relative; 16 columns (two-block-row kernel) and 8 (four-block-row kernel), columns in the first, a middle and
         # the ragged last block row
-        cols = np.array([0, 1, 255, 256, 257, 1023, 1024, 40000, 50001, 65535, 65536, 99839, 99840, 99900, 99998, 99999])
-        U = np.zeros((n, 16))
-        U[cols, np.arange(16)] = 1.0
+        # ... and 32 (the wide generating kernel, matvec_symw_kernel<2, ., ., 2>: every entry generated once for both 16-column groups)
+        cols = np.array([0, 1, 255, 256, 257, 1023, 1024, 40000, 50001, 65535, 65536, 99839, 99840, 99900, 99998, 99999,
+                         2, 128, 511, 512, 767, 768, 12345, 33333, 77777, 88063, 88064, 99583, 99584, 99700, 99841, 99997])
+        U = np.zeros((n, 32))
+        U[cols, np.arange(32)] = 1.0
         e.panel_put(PANEL_V, 0, U)
         want = np.stack([O.compute_matrix_on_the_fly(int(j) + 1, n, tab) for j in cols], axis=1)
-        for c0, k in ((0, 16), (8, 8)):
+        for c0, k in ((0, 16), (8, 8), (0, 32)):
             e.apply(OP_A, PANEL_V, c0, k, PANEL_W, 0)
             got = e.panel_get(PANEL_W, 0, k)
             rel = np.abs(got - want[:, c0:c0 + k]) / np.abs(want[:, c0:c0 + k])
             assert rel.max() < 1e-13, (k, float(rel.max()), np.unravel_index(np.argmax(rel), rel.shape))
     # the second operator of the reference's tests (sin instead of cos, unit diagonal: src/tests/test_utils.f90:53-66,98-116), same check
     from fortran_davidson_amd.engine_c import PANEL_BV
-    with fd.CEngine(n=n, max_cols=16, gev=True) as e:
+    with fd.CEngine(n=n, max_cols=32, gev=True) as e:
         e.set_storage(1)
         e.set_operator_harness(OP_A, tab)
         e.set_operator_harness(OP_B, tab)
         e.panel_put(PANEL_V, 0, U)
-        e.apply(OP_B, PANEL_V, 0, 16, PANEL_BV, 0)
-        got = e.panel_get(PANEL_BV, 0, 16)
         want_b = np.stack([O.compute_stx_on_the_fly(int(j) + 1, n, tab) for j in cols], axis=1)
-        rel = np.abs(got - want_b) / np.abs(want_b)
-        assert rel.max() < 1e-13, (float(rel.max()), np.unravel_index(np.argmax(rel), rel.shape))
+        for k in (16, 32):
+            e.apply(OP_B, PANEL_V, 0, k, PANEL_BV, 0)
+            got = e.panel_get(PANEL_BV, 0, k)
+            rel = np.abs(got - want_b[:, :k]) / np.abs(want_b[:, :k])
+            assert rel.max() < 1e-13, (k, float(rel.max()), np.unravel_index(np.argmax(rel), rel.shape))
     with fd.DavidsonEngine(n, 3, 20, gev=True, storage="symmetric") as eng:
         eng.set_harness_operator(1)
         eng.set_identity(2)

@@ -8,7 +8,10 @@ test checks the EMITTED code for them:
   2. no VALU instruction writes a register that an MFMA reads within the next two instructions (2 wait states);
   3. a register written by an MFMA is read by a non-MFMA instruction only after an `s_nop 15` (+ `s_nop 3`): 18+ wait states -
      or after three later MFMAs of the wave (each holds the matrix pipe for 16 passes: the result is two MFMAs old at least);
-  4. no register moves between the halves (v_accvgpr_*) and no scratch in the kernel at all;
+  4. no scratch in the kernel at all, and no register moves between the halves (v_accvgpr_*) - except in the harness variants (GEN = 2 / 3,
+     round 6), which run at the limit of the ordinary registers: there the compiler parks lane constants in accumulation registers, so
+     these variants keep their fixed registers ABOVE a168 (symw_fixed_lo(true)) and rule 1 checks that the compiler stays below; their own
+     v_accvgpr_read / _write of the table values stand inside asm statements;
   5. no buffer load reads a scalar register that a VALU instruction wrote fewer than 5 wait states before.
 """
 import os
@@ -21,7 +24,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fortran_davidson_amd", "csrc", "k_matvec_symw.hip")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FIXED_LO = {1: 128, 2: 128}   # first fixed accumulation register (symw_fixed_lo in the kernel file), by columns / 16 per workgroup
+def fixed_lo(name):
+    """first fixed accumulation register of a kernel variant (symw_fixed_lo in the kernel file): 128; the harness variants 168"""
+    return 168 if _is_harness(name) else 128
+
+
+def _is_harness(name):
+    return re.search(r"ELi([23])EEv", name) is not None
 
 
 def _regs(tok):
@@ -70,20 +79,22 @@ def kernels(tmp_path_factory):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-c",
                     "-o", str(out) + ".o", SRC], check=True, capture_output=True, timeout=600)
     ks = _kernels(out.read_text())
-    assert len(ks) == 5, list(ks)          # <1>, <2>, <1, TALL>, <1, F32>, <2, GEN>
+    assert len(ks) == 7, list(ks)          # <1>, <2>, <1, TALL>, <1, F32>, <2, GEN = 1 (hashed), 2 (harness cos), 3 (harness sin)>
+    assert sum(_is_harness(k) for k in ks) == 2
     return ks
 
 
 def test_resources(kernels):
     for name, lines in kernels.items():
         text = "\n".join(lines)
-        assert "v_accvgpr" not in text, name
         assert "scratch_" not in text, name
+        if not _is_harness(name):
+            assert "v_accvgpr" not in text, name
 
 
 def test_compiler_code_stays_out_of_the_fixed_registers(kernels):
     for name, lines in kernels.items():
-        lo = FIXED_LO[int(re.search(r"kernelILi(\d)E", name).group(1))]
+        lo = fixed_lo(name)
         in_asm = False
         for ln in lines:
             if "#ASMSTART" in ln:
