@@ -548,7 +548,11 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBPS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round(tflops / FP64_MFMA_PEAK_TFLOPS, 4) if mfma_bound
                         else round(st.apply_bytes / (st.apply_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "traffic": tr_solve[0], "traffic_source": tr_solve[1],
+                "traffic": tr_solve[0],
+                # where `traffic` comes from, as a short string among the first keys (the driver's record keeps those): an OFFLINE figure
+                "traffic_source": (f"{tr_solve[1]['source']} (offline rocprofv3 --pmc passes at commit {tr_solve[1].get('collected_at_commit')})"
+                                   if tr_solve[1] else None),
+                "traffic_provenance": tr_solve[1],
                 "launches": launches, "avg_launch_ms": round(kms, 4), "columns_per_launch": round(cols_per_launch, 1),
                 "flops_per_launch": round(st.apply_flops / launches, 0),
                 "algorithmic_bytes_per_launch": round(st.apply_bytes / max(st.applies, 1) , 0),
@@ -1059,11 +1063,11 @@ def main():
     if rank == 0:
         # the driver's record keeps the first ~20 scalar keys of `roofline` and cuts strings at ~120 characters: what a reader needs to
         # recompute both fractions comes first, the long texts last
-        first = ["bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches", "ms_per_solve", "non_kernel_ms_per_solve",
+        first = ["bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms", "launches", "ms_per_solve", "non_kernel_ms_per_solve",
                  "hbm_N", "hbm_k", "hbm_algorithmic_bytes", "hbm_ms_end_to_end", "hbm_GBps_end_to_end", "hbm_frac", "hbm_frac_kernel_only",
                  "hbm_traffic", "hbm_frac_of_measured_read", "hbm_k16_frac", "apply_non_kernel_ms_per_solve", "flops_per_launch",
                  "algorithmic_bytes_per_launch", "columns_per_launch", "kernel"]
-        last = ["note", "traffic_source"]
+        last = ["note", "traffic_provenance"]
         roofline = {**{k_: roofline[k_] for k_ in first if k_ in roofline},
                     **{k_: v_ for k_, v_ in roofline.items() if k_ not in first and k_ not in last},
                     **{k_: roofline[k_] for k_ in last if k_ in roofline}}
