@@ -669,8 +669,10 @@ contains
                if (nconv > 0) then
                   call check_dav(dav_panel_transform(h, DAV_PANEL_V, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
                        DAV_PANEL_X, int(lockbase + nlock, c_int)), "dav_panel_transform")
+                  ! (into the residue panel: the correction of this iteration has been made, nothing reads it before the next Ritz phase;
+                  ! the scratch panel S is what a contraction of more than 64 columns goes through - dav_restart below)
                   call check_dav(dav_panel_transform(h, DAV_PANEL_BV, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
-                       DAV_PANEL_S, 0_c_int), "dav_panel_transform")
+                       DAV_PANEL_R, 0_c_int), "dav_panel_transform")
                end if
             else
                do jj = 1, nconv
@@ -694,7 +696,7 @@ contains
                do jj = 1, nconv
                   eye_k(jj, jj) = 1.0_dp
                end do
-               call check_dav(dav_panel_transform(h, DAV_PANEL_S, 0_c_int, int(nconv, c_int), eye_k, int(nconv, c_int64_t), int(nconv, c_int), &
+               call check_dav(dav_panel_transform(h, DAV_PANEL_R, 0_c_int, int(nconv, c_int), eye_k, int(nconv, c_int64_t), int(nconv, c_int), &
                     DAV_PANEL_V, int(nlock, c_int)), "dav_panel_transform")
                call block_orthonormalise(dev, n, nlock, nconv)
             end if

@@ -3,7 +3,8 @@ generalized_eigensolver_dense_locking): iteration counts exactly, eigenvalues to
 numbers of wanted pairs, couplings, restart widths, both storages, DPR and (small orders) GJD; half of the matrices get a clustered
 lowest diagonal so that the pairs lock at different iterations.  Checker tool (uses the oracle: lives under tests/, not collected by
 pytest; a fixed-seed slice runs in tests/test_parity_sweeps_gpu.py):
-    python tests/locking_parity_sweep.py [ncases] [seed]"""
+    python tests/locking_parity_sweep.py [ncases] [seed] [only]
+`only` = comma-separated case numbers (the #n of a printed line): every case is still drawn, only those are solved."""
 import os
 import sys
 import time
@@ -15,6 +16,7 @@ from oracle import davidson_oracle as O
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = {int(x) for x in sys.argv[3].split(",")} if len(sys.argv) > 3 else None
 bad = 0
 done = 0
 t0 = time.time()
@@ -41,6 +43,11 @@ for case in range(ncases):
         B = O.generate_diagonal_dominant(n, sp, 1.0, seed=seed + 1)
         if rng.integers(2):
             B[np.arange(n), np.arange(n)] = 1.0 + 9.0 * rng.random(n)
+    if only is not None and case not in only:
+        continue
+    if os.environ.get("SWEEP_DRY"):                # list the cases without solving them (to find the #n of a logged line)
+        print(f"#{case:<4d}{method} gev={int(gev)} n={n:5d} lowest={lowest:2d} sparsity={sp:g} max_dim={max_dim} storage={storage:9s} tol={tol:g} seed={seed:3d}")
+        continue
     lam_o, vec_o, it_o = O.generalized_eigensolver_dense_locking(A, lowest, method, 80, tol, max_dim, second_matrix=B)
     with fd.DavidsonEngine(n, lowest, max_dim, gev=gev, storage=storage) as eng:
         eng.set_correction_policy("locking")
@@ -54,6 +61,6 @@ for case in range(ncases):
     ok = (it == it_o if method == "DPR" else it <= it_o) and np.abs(lam - lam_o).max() < 1e-8 * max(1.0, np.abs(lam_o).max()) and (res < tol or not conv)
     done += 1
     bad += not ok
-    print(f"{method} gev={int(gev)} n={n:5d} lowest={lowest:2d} sparsity={sp:g} max_dim={max_dim} storage={storage:9s} tol={tol:g} seed={seed:3d}: "
+    print(f"#{case:<4d}{method} gev={int(gev)} n={n:5d} lowest={lowest:2d} sparsity={sp:g} max_dim={max_dim} storage={storage:9s} tol={tol:g} seed={seed:3d}: "
           f"oracle iters {it_o:2d}, engine {it:2d}, |dlam| {np.abs(lam - lam_o).max():.1e}, residual {res:.1e}{'' if ok else '   <-- MISMATCH'}", flush=True)
 print(f"{done} cases in {time.time() - t0:.0f} s, mismatches: {bad}")

@@ -118,7 +118,9 @@ def test_locking_policy_through_restarts_on_one_and_three_ranks(nranks, storage)
 
 
 GEV_LOCKING_CASES = [(300, 3, 1e-2, None, "DPR", "full", 1), (500, 5, 3e-2, 15, "DPR", "symmetric", 1), (200, 2, 1e-2, None, "GJD", "full", 1),
-                     (400, 8, 5e-2, 24, "DPR", "symmetric", 1), (700, 6, 3e-2, 20, "DPR", "full", 3), (700, 6, 3e-2, 20, "DPR", "symmetric", 3)]
+                     (400, 8, 5e-2, 24, "DPR", "symmetric", 1), (700, 6, 3e-2, 20, "DPR", "full", 3), (700, 6, 3e-2, 20, "DPR", "symmetric", 3),
+                     # pairs that lock while the basis is wider than 64 columns (the contraction then goes through the scratch panel)
+                     (400, 12, 5e-2, 72, "DPR", "full", 1), (600, 16, 3e-2, 120, "DPR", "symmetric", 1)]
 
 
 @pytest.mark.parametrize("n,L,sp,md,method,storage,nranks", GEV_LOCKING_CASES)
