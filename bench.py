@@ -263,7 +263,7 @@ def pmc_traffic(n, storage, kernel, rank_by_grid):
         return None, None
 
 
-REHEARSAL = os.path.join(ROOT, "profiles", "experiments", "r05_ranks_rehearsal_n200000.jsonl")
+REHEARSAL = os.path.join(ROOT, "profiles", "experiments", "r06_ranks_rehearsal_n200000.jsonl")
 LINK_GBPS = 70.0            # assumed payload rate of one xGMI link in one direction (153.6 GB/s bidirectional on the data sheet)
 
 
