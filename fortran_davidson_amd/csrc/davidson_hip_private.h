@@ -35,6 +35,8 @@ int dav_bench_harness_rate(dav_handle_t h, int iters, double* entries_per_s);
 int dav_apply_inner(dav_handle_t h, int which, int src_panel, int c0, int k, int dst_panel, int d0);
 /* Fraction of the block rows of a generated second operator that is kept resident as stored tiles (configs[3]); 0 when nothing is. */
 int dav_resident_fraction(dav_handle_t h, int which, double* fraction);
+/* what the buffer cache (include/davidson_hip.h: dav_free_buffers) holds right now: idle device blocks, idle page-locked host blocks */
+int dav_buffer_cache_held(int64_t* device_bytes, int64_t* pinned_bytes);
 
 /* The host-side packing of a small matrix into the MFMA-B operand image the panel kernel reads (csrc/kernels.h: pg_image_index:
  * entry (i, j) at ((i / 4) * tiles_per_step + j / 16) * 64 + (j % 16) + 16 * (i % 4)); no GPU needed.  out == NULL: sizes only. */

@@ -360,6 +360,16 @@ size_t pool_idle_device_bytes(int device) {
   for (const PoolBlock& b : P.idle) if (b.kind == 0 && b.device == device) sum += b.bytes;
   return sum;
 }
+// measurement door (davidson_hip_private.h): what the cache holds right now - idle device blocks (all devices), idle pinned host blocks
+extern "C" int dav_buffer_cache_held(int64_t* device_bytes, int64_t* pinned_bytes) {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  int64_t dev = 0, pin = 0;
+  for (const PoolBlock& b : P.idle) (b.kind == 0 ? dev : pin) += (int64_t)b.bytes;
+  if (device_bytes) *device_bytes = dev;
+  if (pinned_bytes) *pinned_bytes = pin;
+  return 0;
+}
 // end of a dav_destroy: what this engine returned stays; what was idle before the engine before it was destroyed goes
 void pool_begin_of_destroy() {
   Pool& P = pool();

@@ -72,3 +72,30 @@ def test_the_cache_never_holds_more_than_its_cap():
         assert res.returncode == 0, (res.stdout + res.stderr)[-2000:]
         held[cap] = int([ln for ln in res.stdout.splitlines() if ln.startswith("HELD")][0].split()[1])
     assert held["16"] < (64 << 20) and held["4096"] > 8 * 6000 * 6000 // 2
+
+
+def test_pinned_blocks_have_their_own_small_cap():
+    """Round 6 (round-5 advisor): page-locked host blocks are capped separately (DAVIDSON_BUFFER_CACHE_PINNED_MB, default 256) from
+    the device blocks - a streaming upload's two pinned staging buffers (here 2 x 96 MB) must not stay locked behind a call when the
+    cap says 64, and stay for the next upload under the default."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import fortran_davidson_amd as fd\n"
+        "from fortran_davidson_amd.engine_c import buffer_cache_held, OP_A\n"
+        "n = 3000\n"
+        "rows = np.random.default_rng(0).standard_normal((n, n)); rows = rows + rows.T\n"
+        "with fd.CEngine(n=n, max_cols=16) as e:\n"
+        "    e.dense_begin(OP_A); e.dense_put_rows(OP_A, 0, rows); e.dense_end(OP_A)\n"
+        "print('HELD', *buffer_cache_held())\n" % root)
+    held = {}
+    for cap in ("0", "256"):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, DAVIDSON_BUFFER_CACHE_PINNED_MB=cap))
+        assert res.returncode == 0, (res.stdout + res.stderr)[-2000:]
+        held[cap] = [int(x) for x in [ln for ln in res.stdout.splitlines() if ln.startswith("HELD")][0].split()[1:]]
+    assert held["0"][1] == 0 and held["0"][0] > 0            # device blocks stay, pinned ones went back
+    assert 0 < held["256"][1] <= (256 << 20)
