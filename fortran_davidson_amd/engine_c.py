@@ -393,6 +393,14 @@ def parse_text_f64(data: bytes) -> np.ndarray:
     return out
 
 
+def buffer_cache_held():
+    """(idle device bytes, idle pinned host bytes) the buffer cache holds right now (measurement door, csrc/davidson_hip_private.h)"""
+    lib = hip_lib()
+    d, h = C.c_int64(), C.c_int64()
+    lib.dav_buffer_cache_held(C.byref(d), C.byref(h))
+    return d.value, h.value
+
+
 def free_buffers() -> None:
     """Return the buffer cache's idle device / pinned blocks (kept from the engine destroyed last) to the device."""
     hip_lib().dav_free_buffers()
