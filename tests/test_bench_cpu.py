@@ -18,7 +18,7 @@ def test_cpu_share_is_what_the_job_may_use():
 
 
 def test_scaling_model_from_the_one_gpu_rehearsal_of_eight_ranks():
-    """bench.scaling_model on the rehearsal log (P ranks taking turns on one GPU, profiles/experiments/r05_ranks_rehearsal_n200000.jsonl):
+    """bench.scaling_model on the rehearsal log (P ranks taking turns on one GPU, profiles/experiments/r06_ranks_rehearsal_n200000.jsonl):
     per-rank times are MEASURED, the link rate is the assumption.  With the collectives in program order the model clears six-fold
     at 8 GPUs where the exchanges use the direct links of the mesh, and stays under it if every collective were a ring on ONE link."""
     assert bench.rehearsal_inputs().keys() >= {1, 2, 4, 8}

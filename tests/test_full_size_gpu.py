@@ -250,7 +250,7 @@ def test_config5_n1000000_matrix_free_eight_ranks(storage, monkeypatch):
     assert out[0][1] == 4
     per_rank_gb = (free0 - min(o[2] for o in out)) / nranks / 1e9
     assert per_rank_gb < 40.0, per_rank_gb             # panels 0.9 GB + partial-sum slabs of the rank's share of the generated triangle
-    _experiment_log(f"r05_eight_ranks_n1000000_{storage}.json",
+    _experiment_log(f"r06_eight_ranks_n1000000_{storage}.json",
                     {"n": n, "ranks": nranks, "storage": storage, "iters": out[0][1], "per_rank_device_GB": round(per_rank_gb, 2),
                      "sweep_kernel_ms_per_launch_by_rank": [round(o[3], 2) for o in out], "collectives_by_rank": [o[4] for o in out],
                      "note": "ranks take turns on the one GPU (DAV_TEST_SERIALIZE=1): a rank's kernel times are those of a rank that owns a GPU"})
@@ -344,7 +344,7 @@ def test_config3_n200000_eight_ranks_dealt_tiles(monkeypatch):
     assert per_rank_gb < 26.0, per_rank_gb             # 20.1 GB of tiles + partial-sum slabs + panels + exchange buffers
     recs = [o[3] for o in out]
     sweep = [r_["sweep_kernel_ms"] for r_ in recs]
-    _experiment_log("r05_eight_ranks_n200000.json",
+    _experiment_log("r06_eight_ranks_n200000.json",
                     {"n": n, "ranks": nranks, "lowest": L, "iters": out[0][1], "per_rank_device_GB": round(per_rank_gb, 2),
                      "sweep_kernel_ms_per_solve_min_max": [round(min(sweep), 3), round(max(sweep), 3)], "by_rank": recs,
                      "note": "ranks take turns on the one GPU (DAV_TEST_SERIALIZE=1): kernel / local times are those of a rank that owns a GPU; "

@@ -149,7 +149,7 @@ def test_configs2_at_full_order_over_a_real_four_rank_communicator():
     assert abs(c["allgather_MB_per_solve"] - 153.6) < 1.0 and abs(c["reduce_scatter_MB_per_solve"] - 204.8) < 1.0
     try:                                                  # kept for profiles/experiments/ (gpurun_out/ travels back from the GPU box)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "r05_rccl_one_gpu_4ranks_n200000.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "r06_rccl_one_gpu_4ranks_n200000.json"), "w") as f:
             json.dump({"note": "bench.py --gpus 4 --headline-only at N=200000 over a REAL 4-rank RCCL communicator whose ranks share one GPU (loopback "
                                "socket transport: the times are of that transport and of four processes time-slicing one device)",
                        "value": line["value"], "iters_per_solve": line["config"]["iters_per_solve"], "eigenvalues": line["eigenvalues"], "comm": c}, f, indent=1)
