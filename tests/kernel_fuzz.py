@@ -1,5 +1,5 @@
-"""Randomised check of the kernels behind the C ABI against numpy: block sweeps W = Op X (dense host / device-generated / hashed
-operator, full rows and symmetric tiles with the one-, two- and four-block-row schedules forced at any order, 1-64 columns at random
+"""Randomised check of the kernels behind the C ABI against numpy: block sweeps W = Op X (dense host / device-generated / hashed /
+the reference's matrix-free test operators in both forms, full rows and symmetric tiles with the one-, two- and four-block-row schedules forced at any order, 1-64 columns at random
 offsets), Gram blocks P^T Q and panel products P M at random shapes and offsets.  Matrices come from the oracle's generator
 (test infrastructure: this tool lives under tests/, not collected by pytest):
     python tests/kernel_fuzz.py [ncases] [seed]"""
@@ -27,15 +27,26 @@ for case in range(ncases):
     n = int(rng.choice([17, 64, 255, 256, 257, 300, 511, 777, 1024, 1300, 2049, 2305, 3333, 5000]))
     storage = int(rng.integers(2))
     sched = str(rng.choice(["0", "1", "2", "4"])) if storage == 1 else "0"
-    kind = str(rng.choice(["host", "generated", "hashed"]))
+    kind = str(rng.choice(["host", "generated", "hashed", "harness", "harness_sin"]))
     os.environ["DAV_SYM_R"] = sched
     os.environ["DAV_SYM_GEN_WIDE"] = str(int(rng.integers(2)))
     seed = int(rng.integers(1, 1000))
     sp = float(rng.choice([1e-3, 1e-1, 1.0]))
     maxc = 96
-    with fd.CEngine(n=n, max_cols=maxc) as e:
+    libm = int(rng.integers(4) == 0)                       # the reference's test operator: a quarter of the cases by the formula as written
+    os.environ["DAV_HARNESS_LIBM"] = str(libm)
+    with fd.CEngine(n=n, max_cols=maxc, gev=kind == "harness_sin") as e:
         e.set_storage(storage)
-        if kind == "host":
+        if kind.startswith("harness"):
+            # the reference's matrix-free test operators (cos: A, sin: B; src/tests/test_utils.f90:72-116) against the oracle's statement
+            tab = O.harness_exp_table(n)
+            mtx, stx = O.harness_matrices(n)
+            e.set_operator_harness(OP_A, tab)
+            A = mtx
+            if kind == "harness_sin":
+                e.set_operator_harness(1, tab)
+                A = stx
+        elif kind == "host":
             A = rng.standard_normal((n, n)); A = A + A.T
             e.set_dense_host(OP_A, A)
         else:
@@ -47,7 +58,7 @@ for case in range(ncases):
         for _ in range(3):
             k = int(rng.integers(1, min(64, maxc) + 1))
             c0 = int(rng.integers(0, maxc - k + 1)); d0 = int(rng.integers(0, maxc - k + 1))
-            e.apply(OP_A, PANEL_V, c0, k, PANEL_W, d0)
+            e.apply(1 if kind == "harness_sin" else OP_A, PANEL_V, c0, k, PANEL_W, d0)
             err = relerr(e.panel_get(PANEL_W, d0, k), A @ X[:, c0:c0 + k])
             if not err < 1e-12 * max(1.0, np.sqrt(n) / 8):
                 msgs.append(f"apply k={k} c0={c0} d0={d0} err={err:.2e}")
@@ -68,5 +79,5 @@ for case in range(ncases):
             if not err < 1e-13 * max(1.0, p / 4):
                 msgs.append(f"panel p={p} q={q} p0={p0} d0={d0} err={err:.2e}")
     bad += bool(msgs)
-    print(f"n={n:5d} storage={storage} schedule={sched} {kind:9s}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}", flush=True)
+    print(f"n={n:5d} storage={storage} schedule={sched} {kind + (' libm' if libm and kind.startswith('harness') else ''):16s}: {'ok' if not msgs else 'MISMATCH ' + '; '.join(msgs)}", flush=True)
 print(f"{ncases} cases in {time.time() - t0:.0f} s, mismatches: {bad}")
