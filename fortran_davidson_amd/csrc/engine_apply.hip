@@ -216,7 +216,7 @@ static int coll_path_trial(E* e, int which, OpDesc& o, const SymSet& set, const 
   // the block in program order: THE result (timed like any other apply of the solve)
   int rc = apply_sym_set(e, which, o, set, false, false, src, k, dst, timed, false);
   if (rc != 0) { e->tune = saved; return rc; }
-  bool setup_ok = pool_malloc(&scratch_blk, sizeof(double) * blk) == hipSuccess && pool_malloc(&cmp_dev, sizeof(double) * 3 * 64) == hipSuccess &&
+  bool setup_ok = pool_malloc(&scratch_blk, sizeof(double) * blk) == hipSuccess && pool_malloc(&cmp_dev, sizeof(double) * 3 * (size_t)k) == hipSuccess &&
                   hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
   CollTrial& t = e->coll_trial;
   t = CollTrial();
@@ -229,7 +229,7 @@ static int coll_path_trial(E* e, int which, OpDesc& o, const SymSet& set, const 
     fprintf(stderr, "davidson (rank %d): no memory for the collective-path trial - program order\n", e->rank);
     return 0;
   }
-  std::vector<double> cmp_host(3 * 64);
+  std::vector<double> cmp_host(3 * (size_t)k);
   for (int path = 0; path < 3; ++path) {
     e->tune.coll_direct = path == COLL_PATH_DIRECT ? 1 : 0;
     e->tune.sym_overlap = path == COLL_PATH_SECOND_STREAM ? 1 : 0;
