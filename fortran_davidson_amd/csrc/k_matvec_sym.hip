@@ -36,7 +36,7 @@ __device__ __forceinline__ const double* sym_tile(const double* tiles, const int
 }
 
 // ---- two waves per SIMD -----------------------------------------------------------------------------------
-// Measured on gfx950 (scratch microbenchmarks): while a wave has a v_mfma_f64_16x16x4 in
+// Measured on gfx950 (profiles/ubench/r01_mfma_f64_overlap.log): while a wave has a v_mfma_f64_16x16x4 in
 // flight it issues nothing else - every VALU / DS / VMEM instruction of that wave adds its own issue time
 // (4-5 cycles, 18+ for a 16-byte global load) on top of the 64 cycles per MFMA; a SECOND wave on the same
 // SIMD, however, issues in the shadow of those MFMAs at full MFMA rate for the first.  A workgroup has 8 waves: wave (w, h) owns tile columns

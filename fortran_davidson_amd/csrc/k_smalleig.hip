@@ -12,7 +12,7 @@
 // of a Davidson basis are close to diagonal (after a restart exactly diagonal), so 3-6 sweeps suffice.  The symmetric matrix lives in LDS (column-major, odd
 // stride); the accumulated rotations too when both fit (m <= 96), else in global memory (L2).  Eigenvalues leave
 // ascending (ties by index), eigenvectors in the matching order.  One workgroup: the order is at most 128, the sweeps
-// are latency (barrier) bound, not throughput bound - measured against the host in DESIGN.md.
+// are latency (barrier) bound, not throughput bound - measured against the host in docs/history/DESIGN_rounds_1_to_5.md section 10.
 #include "kernels.h"
 #include <algorithm>
 
