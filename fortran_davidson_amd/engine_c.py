@@ -318,6 +318,11 @@ class CEngine:
         w = np.ascontiguousarray(words, dtype=np.float64)
         self._chk(self.lib.dav_ranks_agree(self.h, _dp(w), C.c_int(w.size)))
 
+    def agree_inputs(self, words):
+        """the inputs of a solve, verified across the ranks in a fixed-size collective whenever they differ from the last verified ones"""
+        w = np.ascontiguousarray(words, dtype=np.float64)
+        self._chk(self.lib.dav_agree_inputs(self.h, _dp(w), C.c_int(w.size)))
+
     def agree_next(self, words):
         w = np.ascontiguousarray(words, dtype=np.float64)
         self._chk(self.lib.dav_agree_next(self.h, _dp(w), C.c_int(w.size)))

@@ -725,6 +725,31 @@ def test_ranks_that_disagree_on_a_control_decision_stop_with_a_message():
     assert all("ranks disagree" in o for o in out), out
 
 
+def test_solve_inputs_are_verified_in_a_fixed_size_collective_when_they_change():
+    """dav_agree_inputs (round 6; round-5 advisor): the per-iteration control words ride on all-reduces whose element count follows
+    from the basis width, so ranks that differ in `lowest` or `max_dim_sub` would enter those with different counts.  The INPUTS of a
+    solve are therefore verified in a collective of fixed size - at the first solve of an engine and whenever they change; a repeated
+    solve with the same inputs adds no collective; inputs that differ between the ranks are an error ON EVERY RANK."""
+    nranks = 3
+
+    def work(r, e):
+        e.reset_stats()
+        e.agree_inputs([500.0, 3.0, 30.0, 100.0, 1e-8, 0.0, 0.0, 1.0, 0.0])
+        assert e.stats().collectives == 1                        # the first solve of an engine always verifies
+        e.agree_inputs([500.0, 3.0, 30.0, 100.0, 1e-8, 0.0, 0.0, 1.0, 0.0])
+        assert e.stats().collectives == 1                        # unchanged inputs: no collective
+        e.agree_inputs([500.0, 4.0, 40.0, 100.0, 1e-8, 0.0, 0.0, 1.0, 0.0])
+        assert e.stats().collectives == 2                        # every rank changed them together: verified again
+        try:
+            e.agree_inputs([500.0, 4.0 if r != 2 else 5.0, 41.0, 100.0, 1e-8, 0.0, 0.0, 1.0, 0.0])      # rank 2 asks for other `lowest`
+        except fd.DavidsonHipError as exc:
+            return str(exc)
+        return "no error"
+
+    out = _run_ranks(nranks, lambda r: fd.CEngine(n=500, max_cols=16, rank=r, nranks=nranks), work)
+    assert all("ranks disagree" in o for o in out), out
+
+
 def test_control_words_ride_on_the_next_all_reduced_result():
     """dav_agree_next (round 5): the driver's control words wait in the engine and ride on the next all-reduced small result - no
     collective of their own (the count shows it); identical words pass, different words fail the fetch ON EVERY RANK."""
