@@ -122,7 +122,7 @@ contains
     real(dp), allocatable :: hm(:, :), sm(:, :), theta(:), y(:, :), errors(:)
     logical, allocatable :: has_converged(:)
     logical :: host_ops, done, lazy_x, have_all_pairs
-    real(dp) :: t0, t1, phase_s(8), tol_unwanted, adaptive_c
+    real(dp) :: t0, phase_s(8), tol_unwanted, adaptive_c
     type(device_ortho) :: dev
 
     phase_s = 0.0_dp
@@ -185,7 +185,7 @@ contains
     else
        call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
     end if
-    call lap(1)
+    call lap(phase_s, t0, 1)
 
     iters = max_iterations + 1
     done = .false.
@@ -194,7 +194,8 @@ contains
           print *, "generalized_eigensolver: the 'locking' policy serves device operators with the Rayleigh-Ritz problem on the host"
           error stop
        end if
-       call locking_loop()
+       call davidson_locking_loop(h, n, lowest, meth, pol, max_iterations, tolerance, max_dim, cap, gev, hm, sm, ld, m, dev, refresh_every, &
+            adaptive_c, eigenvalues, iters, done, phase_s, t0)
     end if
     outer_loop: do i = 1, merge(0, max_iterations, pol == POLICY_LOCKING)
        ! 3. Rayleigh-Ritz on the host (the only LAPACK call on the path)
@@ -233,10 +234,10 @@ contains
              else
                 call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, lowest)
              end if
-             call lap(2)
+             call lap(phase_s, t0, 2)
              call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(lowest, c_int), int(lowest, c_int), y, &
                   int(m, c_int64_t), theta, DAV_METHOD_NONE, errors), "dav_ritz_residual_correction")
-             call lap(3)
+             call lap(phase_s, t0, 3)
              if (sticky) then
                 do j = 1, lowest
                    if (errors(j) < tolerance) has_converged(j) = .true.
@@ -262,7 +263,7 @@ contains
              call lapack_rayleigh_ritz(hm(1:m, 1:m), theta, y, nvec)
           end if
        end if
-       call lap(2)
+       call lap(phase_s, t0, 2)
 
        ! 4. Ritz vectors, residues, their norms and the DPR correction - one fused device phase
        phase = meth
@@ -293,7 +294,7 @@ contains
           call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(ncorr, c_int), int(lowest, c_int), y, &
                int(m, c_int64_t), theta, int(phase, c_int), errors), "dav_ritz_residual_correction")
        end if
-       call lap(3)
+       call lap(phase_s, t0, 3)
        eigenvalues = theta(1:lowest)
        if (trace_iterations()) print "(a, i0, a, i0, a, es10.3, a, es10.3, a, i0)", "davidson trace: iteration ", i, " m=", m, &
             " max residual ", maxval(errors(1:lowest)), " min ", minval(errors(1:lowest)), " below tolerance ", &
@@ -334,7 +335,7 @@ contains
                 end do
                 call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), theta, 300_c_int, 1.0e-10_dp, &
                      tols, inner), "dav_gjd_correction")
-                call lap(8)
+                call lap(phase_s, t0, 8)
              end if
           else
              ! only the wanted pairs that have not converged: keep their columns, drop the others
@@ -363,7 +364,7 @@ contains
                 end do
                 call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), theta_sel, 300_c_int, &
                      1.0e-10_dp, tols, inner), "dav_gjd_correction")
-                call lap(8)
+                call lap(phase_s, t0, 8)
              else
                 call check_dav(dav_panel_select(h, DAV_PANEL_V, int(m, c_int), int(kt, c_int), sel), "dav_panel_select")
                 if (have_pre) then                       ! keep the same columns of the prefetched Gram blocks
@@ -379,11 +380,11 @@ contains
              else
                 call block_orthonormalise(dev, n, m, kt)
              end if
-             call lap(4)
+             call lap(phase_s, t0, 4)
              call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
-             call lap(5)
+             call lap(phase_s, t0, 5)
              call check_dav(dav_project_dev(h, int(m, c_int), int(kt, c_int)), "dav_project")
-             call lap(6)
+             call lap(phase_s, t0, 6)
           else
              ! first Gram-Schmidt pass only (the block is then orthonormal to ~1e-8) ...
              if (have_pre) then
@@ -391,15 +392,15 @@ contains
              else
                 call block_orthonormalise(dev, n, m, kt, only_first=.true., last_pass=opass)
              end if
-             call lap(4)
+             call lap(phase_s, t0, 4)
              ! 6. ... one block sweep of A over the new columns as that pass left them ...
              call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
              if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
-             call lap(5)
+             call lap(phase_s, t0, 5)
              ! ... and the last pass together with the projection: one reduction, one round trip (the pass is linear, so the
              ! images A*T and B*T follow T, and the new rows / columns of H (and S) follow on the host)
-             call project_with_last_pass(opass + 1)
-             call lap(6)
+             call project_with_last_pass(h, n, m, kt, gev, hm, sm, ld, dev, opass + 1, fun_a, fun_b)
+             call lap(phase_s, t0, 6)
           end if
           m = m + kt
        else
@@ -428,7 +429,7 @@ contains
              call check_dav(dav_expand(h, 0_c_int, int(kt, c_int)), "dav_expand")
              if (host_ops) call apply_host_block(h, n, 0, kt, fun_a, fun_b)
           end if
-          call lap(7)
+          call lap(phase_s, t0, 7)
           hm = 0.0_dp
           sm = 0.0_dp
           if (drr) then
@@ -436,7 +437,7 @@ contains
           else
              call check_dav(dav_project(h, 0_c_int, int(kt, c_int), hm, ld, sm, ld), "dav_project")
           end if
-          call lap(6)
+          call lap(phase_s, t0, 6)
           m = kt
        end if
     end do outer_loop
@@ -454,324 +455,7 @@ contains
 
   contains
 
-    !> The last orthonormalisation pass of the block V(:, m+1:m+kt) (already swept: W, B*V hold its images) fused with the
-    !> projection: dav_project_ortho returns [V T]^T (A T), [V T]^T (B T), C = V^T T and G = T^T T in one fetch; the pass
-    !> T <- (T - V C) M is applied to T and its images (dav_ortho_apply_all) and to the projected blocks here:
-    !>   V^T A T'' = (Hv - H C) M,   T''^T A T'' = M^T (Ht - C^T Hv - Hv^T C + C^T H C) M   (A symmetric, as everywhere).
-    !> A pass that does not leave the block clean (rank-deficient corrections: rare) falls back to the separate passes, a second
-    !> sweep of the block and dav_project.
-    subroutine project_with_last_pass(first_pass)
-      integer, intent(in) :: first_pass
-      integer, parameter :: max_pass = 8
-      real(dp), allocatable, target :: hraw(:, :), sraw(:, :)
-      real(dp), allocatable :: c2(:, :), g2(:, :), mm(:, :)
-      logical, allocatable :: null_cols(:)
-      real(dp) :: wmin, wmax
-      integer :: nnull, p, pass
-      p = m + kt
-      allocate(hraw(p, kt), c2(max(m, 1), kt), g2(kt, kt), mm(kt, kt), null_cols(kt))
-      if (gev) then
-         allocate(sraw(p, kt))
-         call check_dav(dav_project_ortho(h, int(m, c_int), int(kt, c_int), hraw, int(p, c_int64_t), c_loc(sraw), &
-              int(p, c_int64_t), c2, int(max(m, 1), c_int64_t), g2, int(kt, c_int64_t)), "dav_project_ortho")
-      else
-         call check_dav(dav_project_ortho(h, int(m, c_int), int(kt, c_int), hraw, int(p, c_int64_t), c_null_ptr, &
-              0_c_int64_t, c2, int(max(m, 1), c_int64_t), g2, int(kt, c_int64_t)), "dav_project_ortho")
-      end if
-      pass = first_pass
-      do
-         call ortho_pass_transform(pass, m, kt, c2, g2, mm, wmin, wmax, null_cols, nnull)
-         if (nnull > 0) then
-            ! numerically null columns (rank-deficient corrections: rare): they are replaced by fresh directions, which have no
-            ! images yet - separate passes, a second sweep of the block and dav_project
-            call block_orthonormalise(dev, n, m, kt, first_pass=pass)
-            call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
-            if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
-            call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
-            return
-         end if
-         call check_dav(dav_ortho_apply_all(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), mm, &
-              int(kt, c_int64_t)), "dav_ortho_apply_all")
-         call transform_projected(hm, hraw, c2, mm, m, kt)
-         if (gev) call transform_projected(sm, sraw, c2, mm, m, kt)
-         if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) exit          ! orthonormal to rounding
-         if (pass >= max_pass) then
-            print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
-            exit
-         end if
-         ! one more pass (a block whose second pass still found it ill-conditioned): its Gram blocks; the images and the projected
-         ! blocks keep following the block - no second sweep
-         pass = pass + 1
-         call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), g2, &
-              int(kt, c_int64_t)), "dav_ortho_gram")
-      end do
-      hm(1:m, m + 1:p) = hraw(1:m, :)
-      hm(m + 1:p, 1:m) = transpose(hraw(1:m, :))
-      hm(m + 1:p, m + 1:p) = hraw(m + 1:p, :)
-      if (gev) then
-         sm(1:m, m + 1:p) = sraw(1:m, :)
-         sm(m + 1:p, 1:m) = transpose(sraw(1:m, :))
-         sm(m + 1:p, m + 1:p) = sraw(m + 1:p, :)
-      end if
-    end subroutine project_with_last_pass
 
-    !> Opt-in policy "locking" (see engine_set_correction_policy; oracle/davidson_oracle.py: generalized_eigensolver_dense_locking
-    !> states the same loop in the reference's building blocks).  Basis columns 1..nlock are the locked Ritz vectors (W carries
-    !> their images), nlock+1..m the active basis; hm is the projected matrix of all m columns, of which only the active block is
-    !> ever solved.  A contraction V <- V Z, W <- W Z (dav_restart with the m x keep matrix Z) does the locking rotation and the
-    !> collapse restart in one product.
-    subroutine locking_loop()
-      integer :: nlock, want, ma, nconv, want_new, m_rest, keep_a, keep, jj, col, it, lockbase
-      real(dp), allocatable :: th(:), ya(:, :), yfull(:, :), err(:), theta_lock(:), z(:, :), lam(:), ysel(:, :), th_sel(:), yconv(:, :), za(:, :), &
-           eye_k(:, :), perm(:, :)
-      integer, allocatable :: rest(:), order(:)
-      logical, allocatable :: conv(:)
-      logical :: grow
-      allocate(theta_lock(lowest), lam(lowest))
-      nlock = 0
-      ! generalized problems: basis columns 1..nlock are GUARD vectors (an orthonormal basis of span(B X_locked), see the header of this
-      ! procedure's caller); the locked eigenvectors themselves wait in the Ritz-vector panel behind its first `lowest` columns
-      lockbase = lowest
-      do it = 1, max_iterations
-         want = lowest - nlock
-         ma = m - nlock
-         call check_dav(dav_agree_next(h, [real(it, dp), real(m, dp), real(nlock, dp), real(want, dp), tolerance, real(pol, dp), &
-              real(meth, dp)], 7_c_int), "dav_agree_next")
-         if (allocated(th)) deallocate(th, ya, yfull, err, conv)
-         allocate(th(ma), ya(ma, ma), yfull(m, want), err(want), conv(want))
-         if (gev) then
-            call lapack_rayleigh_ritz(hm(nlock + 1:m, nlock + 1:m), th, ya, ma, sm(nlock + 1:m, nlock + 1:m))
-         else
-            call lapack_rayleigh_ritz(hm(nlock + 1:m, nlock + 1:m), th, ya, ma)
-         end if
-         call lap(2)
-         yfull = 0.0_dp
-         yfull(nlock + 1:m, :) = ya(:, 1:want)
-         call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(want, c_int), int(want, c_int), yfull, &
-              int(m, c_int64_t), th, int(meth, c_int), err), "dav_ritz_residual_correction")
-         call lap(3)
-         conv = err < tolerance
-         nconv = count(conv)
-         if (trace_iterations()) print "(a, i0, a, i0, a, i0, a, es10.3, a, i0)", "davidson trace (locking): iteration ", it, " m=", m, &
-              " locked=", nlock, " max residual ", maxval(err), " newly below tolerance ", nconv
-         want_new = want - nconv
-         m_rest = ma - nconv
-         ! Ritz vectors that stay active, in ascending order of their values
-         if (allocated(rest)) deallocate(rest)
-         allocate(rest(m_rest))
-         col = 0
-         do jj = 1, ma
-            if (jj <= want) then
-               if (conv(jj)) cycle
-            end if
-            col = col + 1
-            rest(col) = jj
-         end do
-         ! the Ritz vectors that converge now (ma x nconv), in the order they are locked in
-         if (allocated(yconv)) deallocate(yconv)
-         allocate(yconv(ma, max(nconv, 1)))
-         col = 0
-         do jj = 1, want
-            if (conv(jj)) then
-               col = col + 1
-               yconv(:, col) = ya(:, jj)
-               theta_lock(nlock + col) = th(jj)
-            end if
-         end do
-         if (want_new == 0) then
-            ! every wanted pair is locked or has just converged: Ritz vectors in ascending order of the eigenvalues
-            lam(1:lowest) = theta_lock(1:lowest)
-            allocate(order(lowest))
-            call ascending_order(lam, order)
-            eigenvalues = lam(order)
-            if (gev) then
-               ! the vectors locked earlier wait in the Ritz-vector panel; those of this iteration join them, then one permutation
-               call check_dav(dav_panel_transform(h, DAV_PANEL_V, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
-                    DAV_PANEL_X, int(lockbase + nlock, c_int)), "dav_panel_transform")
-               allocate(perm(lowest, lowest))
-               perm = 0.0_dp
-               do jj = 1, lowest
-                  perm(order(jj), jj) = 1.0_dp
-               end do
-               call check_dav(dav_panel_transform(h, DAV_PANEL_X, int(lockbase, c_int), int(lowest, c_int), perm, int(lowest, c_int64_t), &
-                    int(lowest, c_int), DAV_PANEL_X, 0_c_int), "dav_panel_transform")
-            else
-               allocate(ysel(m, lowest))
-               ysel = 0.0_dp
-               do jj = 1, lowest
-                  if (order(jj) <= nlock) then
-                     ysel(order(jj), jj) = 1.0_dp
-                  else
-                     ysel(nlock + 1:m, jj) = yconv(:, order(jj) - nlock)
-                  end if
-               end do
-               call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), ysel, int(m, c_int64_t)), "dav_ritz_vectors")
-            end if
-            iters = it
-            done = .true.
-            return
-         end if
-         kt = min(want_new, n - m)
-         grow = ((m_rest + want_new <= max_dim) .or. (m_rest <= 2 * want_new)) .and. (m + kt <= cap) .and. kt > 0
-         if (grow) then
-            ! the corrections of the pairs that stay wanted, compacted to the front of the block behind the basis
-            if (allocated(sel)) deallocate(sel, th_sel)
-            allocate(sel(kt), th_sel(kt))
-            col = 0
-            do jj = 1, want
-               if (.not. conv(jj) .and. col < kt) then
-                  col = col + 1
-                  sel(col) = int(jj - 1, c_int)
-                  th_sel(col) = th(jj)
-               end if
-            end do
-            if (meth == DAV_METHOD_GJD) then
-               call check_dav(dav_panel_select(h, DAV_PANEL_X, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
-               call check_dav(dav_panel_select(h, DAV_PANEL_R, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
-               if (allocated(tols)) deallocate(tols)
-               allocate(tols(kt))
-               do jj = 1, kt
-                  tols(jj) = gjd_tol_wanted(err(sel(jj) + 1), tolerance, adaptive_c)
-               end do
-               call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), th_sel, 300_c_int, 1.0e-10_dp, tols, inner), &
-                    "dav_gjd_correction")
-               call lap(8)
-            else
-               call check_dav(dav_panel_select(h, DAV_PANEL_V, int(m, c_int), int(kt, c_int), sel), "dav_panel_select")
-            end if
-            keep_a = m_rest
-         else
-            keep_a = min(2 * want_new, m_rest)          ! collapse restart of the active basis (src/davidson.f90:218)
-         end if
-         keep = nlock + nconv + keep_a
-         if (nconv > 0 .or. keep < m) then
-            ! Z = [e_1 .. e_nlock | the pairs just locked | Ritz vectors kept active]
-            if (allocated(z)) deallocate(z)
-            allocate(z(m, keep))
-            z = 0.0_dp
-            do jj = 1, nlock
-               z(jj, jj) = 1.0_dp
-            end do
-            if (allocated(za)) deallocate(za)
-            allocate(za(ma, keep_a))
-            do jj = 1, keep_a
-               za(:, jj) = ya(:, rest(jj))
-            end do
-            if (gev) then
-               ! The Ritz vectors of a generalized problem are S-orthonormal: the kept ones are made Euclidean-orthonormal (as after a
-               ! restart of the reference policy); the pairs just locked leave the basis altogether - their eigenvectors X = V_a y go to
-               ! the Ritz-vector panel, and what takes their columns are their GUARD vectors B X = (B V_a) y: the pairs still wanted are
-               ! B-orthogonal to the locked ones, x^T (B x_l) = 0, so the search space is kept orthogonal to span(B X_locked) instead of
-               ! span(X_locked); the remaining Ritz vectors already are (y_j^T S y_l = 0).  The guard columns carry NO images (W, B V
-               ! stay zero there): nothing ever projects on them - which is why the generalized loop makes its orthonormalisation
-               ! passes before the sweep (below) instead of fusing the last one with the projection, whose update reads W of every column
-               if (keep_a > 0) call restart_transform(za, ma, keep_a)
-               if (nconv > 0) then
-                  call check_dav(dav_panel_transform(h, DAV_PANEL_V, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
-                       DAV_PANEL_X, int(lockbase + nlock, c_int)), "dav_panel_transform")
-                  ! (into the residue panel: the correction of this iteration has been made, nothing reads it before the next Ritz phase;
-                  ! the scratch panel S is what a contraction of more than 64 columns goes through - dav_restart below)
-                  call check_dav(dav_panel_transform(h, DAV_PANEL_BV, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
-                       DAV_PANEL_R, 0_c_int), "dav_panel_transform")
-               end if
-            else
-               do jj = 1, nconv
-                  z(nlock + 1:m, nlock + jj) = yconv(:, jj)
-               end do
-            end if
-            z(nlock + 1:m, nlock + nconv + 1:keep) = za
-            ! (a growing iteration keeps every active Ritz vector, keep = m: the correction block behind column m stays where it is)
-            call check_dav(dav_restart(h, int(m, c_int), int(keep, c_int), z, int(m, c_int64_t)), "dav_restart")
-            hm(1:keep, 1:keep) = lapack_matmul("T", "N", z, lapack_matmul("N", "N", hm(1:m, 1:m), z))
-            if (gev) sm(1:keep, 1:keep) = lapack_matmul("T", "N", z, lapack_matmul("N", "N", sm(1:m, 1:m), z))
-            if (keep < m) hm(keep + 1:m, :) = 0.0_dp
-            if (keep < m) hm(:, keep + 1:m) = 0.0_dp
-            if (gev .and. keep < m) sm(keep + 1:m, :) = 0.0_dp
-            if (gev .and. keep < m) sm(:, keep + 1:m) = 0.0_dp
-            if (gev .and. nconv > 0) then
-               ! the guard vectors of the pairs just locked into their columns, orthonormal to the guards before them and to each other
-               if (allocated(eye_k)) deallocate(eye_k)
-               allocate(eye_k(nconv, nconv))
-               eye_k = 0.0_dp
-               do jj = 1, nconv
-                  eye_k(jj, jj) = 1.0_dp
-               end do
-               call check_dav(dav_panel_transform(h, DAV_PANEL_R, 0_c_int, int(nconv, c_int), eye_k, int(nconv, c_int64_t), int(nconv, c_int), &
-                    DAV_PANEL_V, int(nlock, c_int)), "dav_panel_transform")
-               call block_orthonormalise(dev, n, nlock, nconv)
-            end if
-            nlock = nlock + nconv
-            if (grow .and. keep < m) then
-               print *, "locking_loop: internal error (a growing iteration keeps every active Ritz vector)"
-               error stop
-            end if
-            m = keep
-            nrestart = nrestart + 1
-            if (mod(nrestart, refresh_every) == 0) then
-               ! W was contracted, not recomputed: every refresh_every-th contraction re-applies the operator (as after restarts) - to
-               ! the active columns (generalized problems: the guard columns carry no images)
-               if (gev) then
-                  call check_dav(dav_expand(h, int(nlock, c_int), int(m - nlock, c_int)), "dav_expand")
-               else
-                  call check_dav(dav_expand(h, 0_c_int, int(m, c_int)), "dav_expand")
-               end if
-               call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
-            end if
-            call lap(7)
-         end if
-         if (grow) then
-            if (gev) then
-               ! all passes, the sweep, the plain projection (see above: the fused last pass would read images of the guard columns)
-               call block_orthonormalise(dev, n, m, kt)
-               call lap(4)
-               call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
-               call lap(5)
-               call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
-               call lap(6)
-            else
-               call block_orthonormalise(dev, n, m, kt, only_first=.true., last_pass=opass)
-               call lap(4)
-               call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
-               call lap(5)
-               call project_with_last_pass(opass + 1)
-               call lap(6)
-            end if
-            m = m + kt
-         end if
-      end do
-      ! not converged: what is locked plus the current Ritz pairs of the active basis (the caller prints the warning)
-      lam(1:nlock) = theta_lock(1:nlock)
-      if (nlock < lowest) lam(nlock + 1:lowest) = th(1:lowest - nlock)
-      allocate(order(lowest))
-      call ascending_order(lam, order)
-      eigenvalues = lam(order)
-      if (size(yfull, 1) == m .or. gev) then
-         if (gev) then
-            ! the current Ritz vectors of the pairs still wanted behind the locked ones (the last iteration's active basis: ya)
-            want = lowest - nlock
-            if (want > 0 .and. size(ya, 1) == m - nlock) call check_dav(dav_panel_transform(h, DAV_PANEL_V, int(nlock, c_int), int(m - nlock, c_int), &
-                 ya(:, 1:want), int(m - nlock, c_int64_t), int(want, c_int), DAV_PANEL_X, int(lockbase + nlock, c_int)), "dav_panel_transform")
-            allocate(perm(lowest, lowest))
-            perm = 0.0_dp
-            do jj = 1, lowest
-               perm(order(jj), jj) = 1.0_dp
-            end do
-            call check_dav(dav_panel_transform(h, DAV_PANEL_X, int(lockbase, c_int), int(lowest, c_int), perm, int(lowest, c_int64_t), &
-                 int(lowest, c_int), DAV_PANEL_X, 0_c_int), "dav_panel_transform")
-         else
-            allocate(ysel(m, lowest))
-            ysel = 0.0_dp
-            do jj = 1, lowest
-               if (order(jj) <= nlock) then
-                  ysel(order(jj), jj) = 1.0_dp
-               else if (order(jj) - nlock <= size(yfull, 2)) then
-                  ysel(:, jj) = yfull(:, order(jj) - nlock)
-               end if
-            end do
-            call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), ysel, int(m, c_int64_t)), "dav_ritz_vectors")
-         end if
-      end if
-    end subroutine locking_loop
 
     !> X(:, 1:lowest) = V(:, 1:m) * Y(:, 1:lowest) for the Ritz pairs of this iteration (see lazy_x above)
     subroutine finish_ritz_vectors()
@@ -779,14 +463,363 @@ contains
            "dav_ritz_vectors")
     end subroutine finish_ritz_vectors
 
-    subroutine lap(slot)
-      integer, intent(in) :: slot
-      t1 = tick()
-      phase_s(slot) = phase_s(slot) + (t1 - t0)
-      t0 = t1
-    end subroutine lap
 
   end subroutine davidson_device_loop
+
+  !> wall time since the last lap goes to phase `slot` (davidson_engine%phase_seconds)
+  subroutine lap(phase_s, t0, slot)
+    real(dp), intent(inout) :: phase_s(8), t0
+    integer, intent(in) :: slot
+    real(dp) :: t1
+    t1 = tick()
+    phase_s(slot) = phase_s(slot) + (t1 - t0)
+    t0 = t1
+  end subroutine lap
+
+  !> The last orthonormalisation pass of the block V(:, m+1:m+kt) (already swept: W, B*V hold its images) fused with the
+  !> projection: dav_project_ortho returns [V T]^T (A T), [V T]^T (B T), C = V^T T and G = T^T T in one fetch; the pass
+  !> T <- (T - V C) M is applied to T and its images (dav_ortho_apply_all) and to the projected blocks here:
+  !>   V^T A T'' = (Hv - H C) M,   T''^T A T'' = M^T (Ht - C^T Hv - Hv^T C + C^T H C) M   (A symmetric, as everywhere).
+  !> A pass that does not leave the block clean (rank-deficient corrections: rare) falls back to the separate passes, a second
+  !> sweep of the block and dav_project.
+  subroutine project_with_last_pass(h, n, m, kt, gev, hm, sm, ld, dev, first_pass, fun_a, fun_b)
+    type(c_ptr), intent(in) :: h
+    integer, intent(in) :: n, m, kt
+    logical, intent(in) :: gev
+    real(dp), intent(inout), contiguous :: hm(:, :), sm(:, :)   !< the projected matrices (cap x cap): their new rows / columns are filled here
+    integer(c_int64_t), intent(in) :: ld
+    type(device_ortho), intent(inout) :: dev
+    integer, intent(in) :: first_pass
+    procedure(block_operator), optional :: fun_a, fun_b     !< host callbacks (the matrix-free front end): the fallback path re-applies them
+    logical :: host_ops
+    integer, parameter :: max_pass = 8
+    real(dp), allocatable, target :: hraw(:, :), sraw(:, :)
+    real(dp), allocatable :: c2(:, :), g2(:, :), mm(:, :)
+    logical, allocatable :: null_cols(:)
+    real(dp) :: wmin, wmax
+    integer :: nnull, p, pass
+    host_ops = present(fun_a)
+    p = m + kt
+    allocate(hraw(p, kt), c2(max(m, 1), kt), g2(kt, kt), mm(kt, kt), null_cols(kt))
+    if (gev) then
+       allocate(sraw(p, kt))
+       call check_dav(dav_project_ortho(h, int(m, c_int), int(kt, c_int), hraw, int(p, c_int64_t), c_loc(sraw), &
+            int(p, c_int64_t), c2, int(max(m, 1), c_int64_t), g2, int(kt, c_int64_t)), "dav_project_ortho")
+    else
+       call check_dav(dav_project_ortho(h, int(m, c_int), int(kt, c_int), hraw, int(p, c_int64_t), c_null_ptr, &
+            0_c_int64_t, c2, int(max(m, 1), c_int64_t), g2, int(kt, c_int64_t)), "dav_project_ortho")
+    end if
+    pass = first_pass
+    do
+       call ortho_pass_transform(pass, m, kt, c2, g2, mm, wmin, wmax, null_cols, nnull)
+       if (nnull > 0) then
+          ! numerically null columns (rank-deficient corrections: rare): they are replaced by fresh directions, which have no
+          ! images yet - separate passes, a second sweep of the block and dav_project
+          call block_orthonormalise(dev, n, m, kt, first_pass=pass)
+          call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+          if (host_ops) call apply_host_block(h, n, m, kt, fun_a, fun_b)
+          call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+          return
+       end if
+       call check_dav(dav_ortho_apply_all(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), mm, &
+            int(kt, c_int64_t)), "dav_ortho_apply_all")
+       call transform_projected(hm, hraw, c2, mm, m, kt)
+       if (gev) call transform_projected(sm, sraw, c2, mm, m, kt)
+       if (pass >= 2 .and. wmin > 0.5_dp .and. wmax < 2.0_dp) exit          ! orthonormal to rounding
+       if (pass >= max_pass) then
+          print *, "Warning: block orthonormalisation did not settle in ", max_pass, " passes"
+          exit
+       end if
+       ! one more pass (a block whose second pass still found it ill-conditioned): its Gram blocks; the images and the projected
+       ! blocks keep following the block - no second sweep
+       pass = pass + 1
+       call check_dav(dav_ortho_gram(h, int(m, c_int), int(kt, c_int), c2, int(max(m, 1), c_int64_t), g2, &
+            int(kt, c_int64_t)), "dav_ortho_gram")
+    end do
+    hm(1:m, m + 1:p) = hraw(1:m, :)
+    hm(m + 1:p, 1:m) = transpose(hraw(1:m, :))
+    hm(m + 1:p, m + 1:p) = hraw(m + 1:p, :)
+    if (gev) then
+       sm(1:m, m + 1:p) = sraw(1:m, :)
+       sm(m + 1:p, 1:m) = transpose(sraw(1:m, :))
+       sm(m + 1:p, m + 1:p) = sraw(m + 1:p, :)
+    end if
+  end subroutine project_with_last_pass
+
+  !> Opt-in policy "locking" (see engine_set_correction_policy; oracle/davidson_oracle.py: generalized_eigensolver_dense_locking
+  !> states the same loop in the reference's building blocks).  Basis columns 1..nlock are the locked Ritz vectors (W carries
+  !> their images), nlock+1..m the active basis; hm is the projected matrix of all m columns, of which only the active block is
+  !> ever solved.  A contraction V <- V Z, W <- W Z (dav_restart with the m x keep matrix Z) does the locking rotation and the
+  !> collapse restart in one product.
+  subroutine davidson_locking_loop(h, n, lowest, meth, pol, max_iterations, tolerance, max_dim, cap, gev, hm, sm, ld, m, dev, refresh_every, &
+       adaptive_c, eigenvalues, iters, done, phase_s, t0)
+    type(c_ptr), intent(in) :: h
+    integer, intent(in) :: n, lowest, meth, pol, max_iterations, max_dim, cap, refresh_every
+    real(dp), intent(in) :: tolerance, adaptive_c
+    logical, intent(in) :: gev
+    real(dp), intent(inout), contiguous :: hm(:, :), sm(:, :)   !< projected matrices of all m columns (only the active block is ever solved)
+    integer(c_int64_t), intent(in) :: ld
+    integer, intent(inout) :: m                            !< basis width: locked (guard) columns first, then the active basis
+    type(device_ortho), intent(inout) :: dev
+    real(dp), intent(out) :: eigenvalues(lowest)
+    integer, intent(inout) :: iters
+    logical, intent(inout) :: done
+    real(dp), intent(inout) :: phase_s(8), t0              !< wall time by phase (davidson_engine%phase_seconds) and the last lap's clock
+    integer :: kt, inner, opass, nrestart
+    integer(c_int), allocatable :: sel(:)
+    real(dp), allocatable :: tols(:)
+    integer :: nlock, want, ma, nconv, want_new, m_rest, keep_a, keep, jj, col, it, lockbase
+    real(dp), allocatable :: th(:), ya(:, :), yfull(:, :), err(:), theta_lock(:), z(:, :), lam(:), ysel(:, :), th_sel(:), yconv(:, :), za(:, :), &
+         eye_k(:, :), perm(:, :)
+    integer, allocatable :: rest(:), order(:)
+    logical, allocatable :: conv(:)
+    logical :: grow
+    allocate(theta_lock(lowest), lam(lowest))
+    nlock = 0
+    nrestart = 0
+    ! generalized problems: basis columns 1..nlock are GUARD vectors (an orthonormal basis of span(B X_locked), see the header of this
+    ! procedure's caller); the locked eigenvectors themselves wait in the Ritz-vector panel behind its first `lowest` columns
+    lockbase = lowest
+    do it = 1, max_iterations
+       want = lowest - nlock
+       ma = m - nlock
+       call check_dav(dav_agree_next(h, [real(it, dp), real(m, dp), real(nlock, dp), real(want, dp), tolerance, real(pol, dp), &
+            real(meth, dp)], 7_c_int), "dav_agree_next")
+       if (allocated(th)) deallocate(th, ya, yfull, err, conv)
+       allocate(th(ma), ya(ma, ma), yfull(m, want), err(want), conv(want))
+       if (gev) then
+          call lapack_rayleigh_ritz(hm(nlock + 1:m, nlock + 1:m), th, ya, ma, sm(nlock + 1:m, nlock + 1:m))
+       else
+          call lapack_rayleigh_ritz(hm(nlock + 1:m, nlock + 1:m), th, ya, ma)
+       end if
+       call lap(phase_s, t0, 2)
+       yfull = 0.0_dp
+       yfull(nlock + 1:m, :) = ya(:, 1:want)
+       call check_dav(dav_ritz_residual_correction_n(h, int(m, c_int), int(want, c_int), int(want, c_int), yfull, &
+            int(m, c_int64_t), th, int(meth, c_int), err), "dav_ritz_residual_correction")
+       call lap(phase_s, t0, 3)
+       conv = err < tolerance
+       nconv = count(conv)
+       if (trace_iterations()) print "(a, i0, a, i0, a, i0, a, es10.3, a, i0)", "davidson trace (locking): iteration ", it, " m=", m, &
+            " locked=", nlock, " max residual ", maxval(err), " newly below tolerance ", nconv
+       want_new = want - nconv
+       m_rest = ma - nconv
+       ! Ritz vectors that stay active, in ascending order of their values
+       if (allocated(rest)) deallocate(rest)
+       allocate(rest(m_rest))
+       col = 0
+       do jj = 1, ma
+          if (jj <= want) then
+             if (conv(jj)) cycle
+          end if
+          col = col + 1
+          rest(col) = jj
+       end do
+       ! the Ritz vectors that converge now (ma x nconv), in the order they are locked in
+       if (allocated(yconv)) deallocate(yconv)
+       allocate(yconv(ma, max(nconv, 1)))
+       col = 0
+       do jj = 1, want
+          if (conv(jj)) then
+             col = col + 1
+             yconv(:, col) = ya(:, jj)
+             theta_lock(nlock + col) = th(jj)
+          end if
+       end do
+       if (want_new == 0) then
+          ! every wanted pair is locked or has just converged: Ritz vectors in ascending order of the eigenvalues
+          lam(1:lowest) = theta_lock(1:lowest)
+          allocate(order(lowest))
+          call ascending_order(lam, order)
+          eigenvalues = lam(order)
+          if (gev) then
+             ! the vectors locked earlier wait in the Ritz-vector panel; those of this iteration join them, then one permutation
+             call check_dav(dav_panel_transform(h, DAV_PANEL_V, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
+                  DAV_PANEL_X, int(lockbase + nlock, c_int)), "dav_panel_transform")
+             allocate(perm(lowest, lowest))
+             perm = 0.0_dp
+             do jj = 1, lowest
+                perm(order(jj), jj) = 1.0_dp
+             end do
+             call check_dav(dav_panel_transform(h, DAV_PANEL_X, int(lockbase, c_int), int(lowest, c_int), perm, int(lowest, c_int64_t), &
+                  int(lowest, c_int), DAV_PANEL_X, 0_c_int), "dav_panel_transform")
+          else
+             allocate(ysel(m, lowest))
+             ysel = 0.0_dp
+             do jj = 1, lowest
+                if (order(jj) <= nlock) then
+                   ysel(order(jj), jj) = 1.0_dp
+                else
+                   ysel(nlock + 1:m, jj) = yconv(:, order(jj) - nlock)
+                end if
+             end do
+             call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), ysel, int(m, c_int64_t)), "dav_ritz_vectors")
+          end if
+          iters = it
+          done = .true.
+          return
+       end if
+       kt = min(want_new, n - m)
+       grow = ((m_rest + want_new <= max_dim) .or. (m_rest <= 2 * want_new)) .and. (m + kt <= cap) .and. kt > 0
+       if (grow) then
+          ! the corrections of the pairs that stay wanted, compacted to the front of the block behind the basis
+          if (allocated(sel)) deallocate(sel, th_sel)
+          allocate(sel(kt), th_sel(kt))
+          col = 0
+          do jj = 1, want
+             if (.not. conv(jj) .and. col < kt) then
+                col = col + 1
+                sel(col) = int(jj - 1, c_int)
+                th_sel(col) = th(jj)
+             end if
+          end do
+          if (meth == DAV_METHOD_GJD) then
+             call check_dav(dav_panel_select(h, DAV_PANEL_X, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
+             call check_dav(dav_panel_select(h, DAV_PANEL_R, 0_c_int, int(kt, c_int), sel), "dav_panel_select")
+             if (allocated(tols)) deallocate(tols)
+             allocate(tols(kt))
+             do jj = 1, kt
+                tols(jj) = gjd_tol_wanted(err(sel(jj) + 1), tolerance, adaptive_c)
+             end do
+             call check_dav(dav_gjd_correction_n(h, int(m, c_int), int(kt, c_int), th_sel, 300_c_int, 1.0e-10_dp, tols, inner), &
+                  "dav_gjd_correction")
+             call lap(phase_s, t0, 8)
+          else
+             call check_dav(dav_panel_select(h, DAV_PANEL_V, int(m, c_int), int(kt, c_int), sel), "dav_panel_select")
+          end if
+          keep_a = m_rest
+       else
+          keep_a = min(2 * want_new, m_rest)          ! collapse restart of the active basis (src/davidson.f90:218)
+       end if
+       keep = nlock + nconv + keep_a
+       if (nconv > 0 .or. keep < m) then
+          ! Z = [e_1 .. e_nlock | the pairs just locked | Ritz vectors kept active]
+          if (allocated(z)) deallocate(z)
+          allocate(z(m, keep))
+          z = 0.0_dp
+          do jj = 1, nlock
+             z(jj, jj) = 1.0_dp
+          end do
+          if (allocated(za)) deallocate(za)
+          allocate(za(ma, keep_a))
+          do jj = 1, keep_a
+             za(:, jj) = ya(:, rest(jj))
+          end do
+          if (gev) then
+             ! The Ritz vectors of a generalized problem are S-orthonormal: the kept ones are made Euclidean-orthonormal (as after a
+             ! restart of the reference policy); the pairs just locked leave the basis altogether - their eigenvectors X = V_a y go to
+             ! the Ritz-vector panel, and what takes their columns are their GUARD vectors B X = (B V_a) y: the pairs still wanted are
+             ! B-orthogonal to the locked ones, x^T (B x_l) = 0, so the search space is kept orthogonal to span(B X_locked) instead of
+             ! span(X_locked); the remaining Ritz vectors already are (y_j^T S y_l = 0).  The guard columns carry NO images (W, B V
+             ! stay zero there): nothing ever projects on them - which is why the generalized loop makes its orthonormalisation
+             ! passes before the sweep (below) instead of fusing the last one with the projection, whose update reads W of every column
+             if (keep_a > 0) call restart_transform(za, ma, keep_a)
+             if (nconv > 0) then
+                call check_dav(dav_panel_transform(h, DAV_PANEL_V, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
+                     DAV_PANEL_X, int(lockbase + nlock, c_int)), "dav_panel_transform")
+                ! (into the residue panel: the correction of this iteration has been made, nothing reads it before the next Ritz phase;
+                ! the scratch panel S is what a contraction of more than 64 columns goes through - dav_restart below)
+                call check_dav(dav_panel_transform(h, DAV_PANEL_BV, int(nlock, c_int), int(ma, c_int), yconv, int(ma, c_int64_t), int(nconv, c_int), &
+                     DAV_PANEL_R, 0_c_int), "dav_panel_transform")
+             end if
+          else
+             do jj = 1, nconv
+                z(nlock + 1:m, nlock + jj) = yconv(:, jj)
+             end do
+          end if
+          z(nlock + 1:m, nlock + nconv + 1:keep) = za
+          ! (a growing iteration keeps every active Ritz vector, keep = m: the correction block behind column m stays where it is)
+          call check_dav(dav_restart(h, int(m, c_int), int(keep, c_int), z, int(m, c_int64_t)), "dav_restart")
+          hm(1:keep, 1:keep) = lapack_matmul("T", "N", z, lapack_matmul("N", "N", hm(1:m, 1:m), z))
+          if (gev) sm(1:keep, 1:keep) = lapack_matmul("T", "N", z, lapack_matmul("N", "N", sm(1:m, 1:m), z))
+          if (keep < m) hm(keep + 1:m, :) = 0.0_dp
+          if (keep < m) hm(:, keep + 1:m) = 0.0_dp
+          if (gev .and. keep < m) sm(keep + 1:m, :) = 0.0_dp
+          if (gev .and. keep < m) sm(:, keep + 1:m) = 0.0_dp
+          if (gev .and. nconv > 0) then
+             ! the guard vectors of the pairs just locked into their columns, orthonormal to the guards before them and to each other
+             if (allocated(eye_k)) deallocate(eye_k)
+             allocate(eye_k(nconv, nconv))
+             eye_k = 0.0_dp
+             do jj = 1, nconv
+                eye_k(jj, jj) = 1.0_dp
+             end do
+             call check_dav(dav_panel_transform(h, DAV_PANEL_R, 0_c_int, int(nconv, c_int), eye_k, int(nconv, c_int64_t), int(nconv, c_int), &
+                  DAV_PANEL_V, int(nlock, c_int)), "dav_panel_transform")
+             call block_orthonormalise(dev, n, nlock, nconv)
+          end if
+          nlock = nlock + nconv
+          if (grow .and. keep < m) then
+             print *, "locking_loop: internal error (a growing iteration keeps every active Ritz vector)"
+             error stop
+          end if
+          m = keep
+          nrestart = nrestart + 1
+          if (mod(nrestart, refresh_every) == 0) then
+             ! W was contracted, not recomputed: every refresh_every-th contraction re-applies the operator (as after restarts) - to
+             ! the active columns (generalized problems: the guard columns carry no images)
+             if (gev) then
+                call check_dav(dav_expand(h, int(nlock, c_int), int(m - nlock, c_int)), "dav_expand")
+             else
+                call check_dav(dav_expand(h, 0_c_int, int(m, c_int)), "dav_expand")
+             end if
+             call check_dav(dav_project(h, 0_c_int, int(m, c_int), hm, ld, sm, ld), "dav_project")
+          end if
+          call lap(phase_s, t0, 7)
+       end if
+       if (grow) then
+          if (gev) then
+             ! all passes, the sweep, the plain projection (see above: the fused last pass would read images of the guard columns)
+             call block_orthonormalise(dev, n, m, kt)
+             call lap(phase_s, t0, 4)
+             call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+             call lap(phase_s, t0, 5)
+             call check_dav(dav_project(h, int(m, c_int), int(kt, c_int), hm, ld, sm, ld), "dav_project")
+             call lap(phase_s, t0, 6)
+          else
+             call block_orthonormalise(dev, n, m, kt, only_first=.true., last_pass=opass)
+             call lap(phase_s, t0, 4)
+             call check_dav(dav_expand(h, int(m, c_int), int(kt, c_int)), "dav_expand")
+             call lap(phase_s, t0, 5)
+             call project_with_last_pass(h, n, m, kt, gev, hm, sm, ld, dev, opass + 1)
+             call lap(phase_s, t0, 6)
+          end if
+          m = m + kt
+       end if
+    end do
+    ! not converged: what is locked plus the current Ritz pairs of the active basis (the caller prints the warning)
+    lam(1:nlock) = theta_lock(1:nlock)
+    if (nlock < lowest) lam(nlock + 1:lowest) = th(1:lowest - nlock)
+    allocate(order(lowest))
+    call ascending_order(lam, order)
+    eigenvalues = lam(order)
+    if (size(yfull, 1) == m .or. gev) then
+       if (gev) then
+          ! the current Ritz vectors of the pairs still wanted behind the locked ones (the last iteration's active basis: ya)
+          want = lowest - nlock
+          if (want > 0 .and. size(ya, 1) == m - nlock) call check_dav(dav_panel_transform(h, DAV_PANEL_V, int(nlock, c_int), int(m - nlock, c_int), &
+               ya(:, 1:want), int(m - nlock, c_int64_t), int(want, c_int), DAV_PANEL_X, int(lockbase + nlock, c_int)), "dav_panel_transform")
+          allocate(perm(lowest, lowest))
+          perm = 0.0_dp
+          do jj = 1, lowest
+             perm(order(jj), jj) = 1.0_dp
+          end do
+          call check_dav(dav_panel_transform(h, DAV_PANEL_X, int(lockbase, c_int), int(lowest, c_int), perm, int(lowest, c_int64_t), &
+               int(lowest, c_int), DAV_PANEL_X, 0_c_int), "dav_panel_transform")
+       else
+          allocate(ysel(m, lowest))
+          ysel = 0.0_dp
+          do jj = 1, lowest
+             if (order(jj) <= nlock) then
+                ysel(order(jj), jj) = 1.0_dp
+             else if (order(jj) - nlock <= size(yfull, 2)) then
+                ysel(:, jj) = yfull(:, order(jj) - nlock)
+             end if
+          end do
+          call check_dav(dav_ritz_vectors(h, int(m, c_int), int(lowest, c_int), ysel, int(m, c_int64_t)), "dav_ritz_vectors")
+       end if
+    end if
+  end subroutine davidson_locking_loop
 
   subroutine device_ortho_gram(be, m, kt, c, g)
     class(device_ortho), intent(inout) :: be
