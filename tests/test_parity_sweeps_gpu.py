@@ -30,15 +30,15 @@ def test_dpr_solves_against_the_oracle_on_a_fixed_seed_slice():
 
 
 def test_structured_matrices_against_the_oracle_on_a_fixed_seed_slice():
-    """80 STRUCTURED problems (tests/structured_parity_sweep.py: banded, block diagonal, sparse, permuted / repeated diagonals,
+    """40 STRUCTURED problems (tests/structured_parity_sweep.py: banded, block diagonal, sparse, permuted / repeated diagonals,
     negative and scaled spectra, strong coupling; DPR and GJD, standard and generalized - second operators near the identity and far from
     it -, both storages) - the classes whose
     correction blocks are rank deficient by structure: wherever the oracle's statement of the reference converges so does the
     engine, to the same eigenvalues; DPR iteration counts equal, GJD never more."""
-    out = run_tool("structured_parity_sweep.py", 80, 9)
+    out = run_tool("structured_parity_sweep.py", 40, 9)
     assert re.search(r"mismatches: 0, iteration counts differ", out), out[-3000:]
     rows = [ln for ln in out.splitlines() if "oracle iters" in ln]
-    assert len(rows) == 80
+    assert len(rows) == 40
     for ln in rows:
         m = re.search(r"oracle iters\s+(\d+), engine\s+(\d+)", ln)
         ref_it, eng_it = int(m.group(1)), int(m.group(2))
@@ -67,13 +67,13 @@ def test_known_iteration_count_differences_of_the_structured_sweep_stay_bounded(
 
 
 def test_locking_policy_against_its_oracle_statement_on_a_fixed_seed_slice():
-    """48 random problems, a third of them generalized (DPR and GJD, clustered and plain diagonals, restart widths, both storages) under the opt-in
+    """32 random problems, a third of them generalized (DPR and GJD, clustered and plain diagonals, restart widths, both storages) under the opt-in
     "locking" policy: iteration counts equal to the oracle's statement of the policy, eigenvalues to 1e-8, residuals below the
     tolerance."""
-    out = run_tool("locking_parity_sweep.py", 48, 3)
+    out = run_tool("locking_parity_sweep.py", 32, 3)
     assert re.search(r"mismatches: 0\b", out), out[-3000:]
     rows = [ln for ln in out.splitlines() if "oracle iters" in ln]
-    assert len(rows) >= 30 and sum(" gev=1 " in ln for ln in rows) >= 8          # a third of them generalized (round 6)
+    assert len(rows) >= 20 and sum(" gev=1 " in ln for ln in rows) >= 5          # a third of them generalized (round 6)
 
 
 def test_fresh_problems_against_the_compiled_reference_on_a_fixed_seed_slice():
